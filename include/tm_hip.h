@@ -1,0 +1,216 @@
+/*
+ * tm_hip.h — C ABI of the MI355X-native triplet-feature RANSAC hot path (libtm_hip.so).
+ *
+ * The reference (richard-vock/triplet_match) has no FFI: its boundary is the C++ template API
+ * model<Point> / scene<Point> / *_traits<Point>. This header is the plain-C layer
+ * those templates are re-hosted on (include/triplet_match/ headers); every entry point names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions: opaque handles; int status return (0 = TM_OK, negative = error, text via
+ * tm_last_error()); caller-owned buffers; no exceptions cross the ABI; one HIP stream per context;
+ * a context and the handles created from it are used by one thread at a time.
+ * Pointers are HOST pointers unless the parameter name starts with `d_` (device, on the ctx device).
+ *
+ * Layouts:
+ *   surfel  48 B = 12 x f32  [x y z 1 | nx ny nz 0 | rgba tx ty tz]  (pcl::PointSurfel; the tangent
+ *           aliases data_c[1..3], include/common:62-70)
+ *   pose    16 x f32 column-major 4x4, maps scene -> model (include/impl/scene.hpp:538-567)
+ *   feature 4 x f32; key 4 x u32; table entry (u32 i, u32 j) = model point indices
+ */
+#ifndef TM_HIP_H_
+#define TM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_OK 0
+#define TM_ERR_INVALID -1         /* bad argument */
+#define TM_ERR_NOT_INITIALIZED -2 /* reference: std::runtime_error "Cannot query uninitialized model" */
+#define TM_ERR_HIP -3             /* HIP runtime error, text in tm_last_error() */
+#define TM_ERR_EMPTY -4           /* no valid pair (reference crashes, include/impl/model.hpp:151) */
+#define TM_ERR_UNSUPPORTED -5
+#define TM_ERR_NO_DEVICE -6       /* no gfx950 device / HIP not usable: there is no CPU fallback */
+#define TM_ERR_CAPACITY -7        /* output buffer too small; *count holds the required size */
+
+#define TM_TRAITS_IDENTITY 0 /* include/identity_traits */
+#define TM_TRAITS_PLANE 1    /* include/plane_traits */
+#define TM_TRAITS_PLANE2 2   /* include/plane2_traits */
+#define TM_TRAITS_CYLINDER 3 /* include/cylinder_traits, opencl/cylinder.cl */
+#define TM_STATE_FLOATS 37   /* traits state: radius, threshold, origin[3], g2l[16], l2g[16] */
+
+#define TM_QUERY_LIMIT_DEFAULT 200 /* include/impl/scene.hpp:19 */
+#define TM_VOXEL_MARGIN 5          /* include/impl/model.hpp:48 */
+
+typedef struct tm_ctx tm_ctx;
+typedef struct tm_model tm_model;
+typedef struct tm_scene tm_scene;
+
+const char* tm_last_error(void);
+const char* tm_version(void);
+
+/* ---- context ---- */
+int tm_ctx_create(int device_id, tm_ctx** ctx);
+int tm_ctx_destroy(tm_ctx* ctx);
+int tm_ctx_synchronize(tm_ctx* ctx);
+void* tm_ctx_stream(tm_ctx* ctx); /* hipStream_t all kernels of this ctx are launched on */
+/* device scratch owned by the ctx (for callers without their own allocator) */
+int tm_device_alloc(tm_ctx* ctx, uint64_t bytes, void** d_ptr);
+int tm_device_free(tm_ctx* ctx, void* d_ptr);
+int tm_memcpy_h2d(tm_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
+int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+/* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline) */
+int tm_ctx_enable_timing(tm_ctx* ctx, int on);
+int tm_ctx_last_score_timing(tm_ctx* ctx, float* ms, uint64_t* evaluations, uint64_t* passing,
+                             uint64_t* hypotheses);
+
+/* ---- scalar descriptor functions, host side ----
+ * replace: feature() include/impl/feature.hpp:16-34; discretize() x2 src/discretize.cpp:20-30;
+ * discretize_feature() include/impl/feature.hpp:38-46; valid() :50-88; valid_bounds() :91-114;
+ * std::hash<Matrix<u32,Dim,1>> = murmur<Dim> include/impl/discretize.hpp:5-56 */
+uint32_t tm_murmur3_32(const uint32_t* words, int n_words, uint32_t seed);
+uint32_t tm_hash_key(const uint32_t* key, int dim); /* seed 42 */
+uint32_t tm_discretize_range(float value, float min_value, float range_value, uint32_t steps);
+uint32_t tm_discretize_step(float value, float step_size);
+float    tm_atan2f(float y, float x);
+void     tm_feature(const float* surfel0, const float* surfel1, float feature[4]);
+void     tm_discretize_feature(const float feature[4], const float bmin[4], const float bmax[4],
+                               float distance_step_count, float angle_step, uint32_t key[4]);
+int      tm_valid(const float feature[4], const float bmin[4], const float bmax[4]);
+void     tm_valid_bounds(const float bmin[4], const float bmax[4], float min_rel_dist,
+                         float max_rel_dist, float out_min[4], float out_max[4]);
+/* replaces scene::impl::base_transform_ include/impl/scene.hpp:538-567 */
+void     tm_base_transform(const float src_i[3], const float src_j[3], const float src_t[3],
+                           const float tgt_i[3], const float tgt_j[3], const float tgt_t[3],
+                           float pose16[16]);
+uint32_t tm_early_drop_upper(uint32_t tried, uint32_t subset_size, uint32_t corrs);
+
+/* batched descriptor kernel (device): features + keys of n (a,b) index pairs into a surfel array.
+ * bounds may be NULL (then keys are not produced). Parity entry point for "bit-exact triplet keys". */
+int tm_features_batch(tm_ctx* ctx, const float* surfels, uint32_t n_points, const uint32_t* ab_pairs,
+                      uint32_t n_pairs, const float bmin[4], const float bmax[4],
+                      float distance_step_count, float angle_step, float* features4,
+                      uint32_t* keys4, uint32_t* hashes);
+
+/* ---- model: replaces model<Point> (include/model:15-66, include/impl/model.hpp) ---- */
+/* model(cloud, discretization_params); `resolution` = cloud->resolution() (mean 1-NN distance) */
+int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,
+                    float distance_step_count, float angle_step, tm_model** model);
+int tm_model_destroy(tm_model* model);
+/* init() part A, include/impl/model.hpp:34-66,81-94: bbox, diameter, to_voxel, voxel NN grid */
+int tm_model_build_voxels(tm_model* model);
+/* init() part B, include/impl/model.hpp:96-149: `subset` is subset_ after the tangent/curvature
+ * filter (:96-99). Builds feature bounds and the key -> (i,j) table. */
+int tm_model_build_pairs(tm_model* model, const uint32_t* subset, uint32_t n_subset,
+                         float min_diameter_factor, float max_diameter_factor);
+int tm_model_get_info(const tm_model* model, float* diameter, uint32_t* cloud_size,
+                      uint32_t* point_count /* tangent-subset size, model.hpp:219-221 */,
+                      float* resolution);
+/* extents(), voxel_transform(), margin(): include/model:49-55 */
+int tm_model_get_grid(const tm_model* model, int extents[3], float to_voxel16[16]);
+int tm_model_download_voxels(const tm_model* model, uint32_t* voxels, uint64_t cap, uint64_t* count);
+/* feature_bounds(): include/model:61 */
+int tm_model_get_feature_bounds(const tm_model* model, float bmin[4], float bmax[4]);
+/* number of table entries and of pass-1 valid pairs (pair_count() is uninitialised in the
+ * reference, include/impl/model.hpp:223-225) */
+int tm_model_get_pair_counts(const tm_model* model, uint64_t* entries, uint64_t* valid_pairs,
+                             uint32_t* distinct_keys);
+/* table dump for parity: distinct keys sorted lexicographically, CSR offsets (n_keys+1), entries in
+ * canonical query order (libstdc++ equal_range order = reverse insertion) */
+int tm_model_download_table(const tm_model* model, uint32_t* keys4, uint32_t* offsets,
+                            uint32_t key_cap, uint32_t* pairs_ij, uint64_t pair_cap);
+/* query(feature): include/impl/model.hpp:169-178. Writes min(cap, total) entries in canonical
+ * order, *count_total = equal_range size. TM_ERR_NOT_INITIALIZED before build_pairs. */
+int tm_model_query(const tm_model* model, const float feature[4], uint32_t* pairs_ij, uint32_t cap,
+                   uint32_t* count_total);
+int tm_model_query_key(const tm_model* model, const uint32_t key[4], uint32_t* pairs_ij,
+                       uint32_t cap, uint32_t* count_total);
+/* voxel_query(pos): include/impl/model.hpp:180-192. *found = 0 for nullopt. */
+int tm_model_voxel_query(const tm_model* model, const float pos4[4], uint32_t* index, int* found);
+
+/* ---- scene: replaces scene<Point> (include/scene:10-59, include/impl/scene.hpp) ---- */
+/* scene(cloud) + tangent_mask_ (include/impl/scene.hpp:42,50-53) */
+int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
+                    tm_scene** scene);
+int tm_scene_destroy(tm_scene* scene);
+/* mask_ (include/impl/scene.hpp:41,87-90); NULL clears */
+int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);
+uint32_t tm_scene_size(const tm_scene* scene);
+
+/* hypothesis generation: inner body of find_in_subset, include/impl/scene.hpp:288-319, for an
+ * ordered batch of scene (i,j) sample pairs: filters -> feature -> valid -> query (first
+ * query_limit entries) -> base_transform_ -> optional force_up. Output compacted in visit order:
+ * pose (16 f32) and provenance (pair index, m_i, m_j, entry rank). If more than `cap` hypotheses
+ * exist the first `cap` are written and *count = cap (total in *count_total). */
+int tm_generate_hypotheses(tm_scene* scene, tm_model* model, const uint32_t* ij_pairs,
+                           uint32_t n_pairs, float min_diameter_factor, float max_diameter_factor,
+                           int force_up, int query_limit, float* poses16, uint32_t* provenance4,
+                           uint32_t cap, uint32_t* count, uint32_t* count_total);
+/* same with device-resident input/output (bench / pipelines): d_ij_pairs, d_poses16, d_provenance4 */
+int tm_generate_hypotheses_dev(tm_scene* scene, tm_model* model, const uint32_t* d_ij_pairs,
+                               uint32_t n_pairs, float min_diameter_factor,
+                               float max_diameter_factor, int force_up, int query_limit,
+                               float* d_poses16, uint32_t* d_provenance4, uint32_t cap,
+                               uint32_t* count, uint32_t* count_total);
+
+/* inlier scoring: project_ (include/impl/scene.hpp:411-510) for a batch of poses, full pass (no
+ * early drop), over `subset` (scene indices, NULL = all points = finish_find :100-106).
+ * counts[h] = number of correspondences; scores[h] = sum |ref . ref_n| / |model cloud| (:509).
+ * mode: TM_SCORE_AUTO picks the grid-culled kernel; TM_SCORE_BRUTEFORCE visits every point. */
+#define TM_SCORE_AUTO 0
+#define TM_SCORE_BRUTEFORCE 1
+#define TM_SCORE_CULLED 2
+int tm_score_hypotheses(tm_scene* scene, tm_model* model, int traits_kind, const float* poses16,
+                        uint32_t n_hyp, const int32_t* subset, uint32_t n_subset, float dist_thres,
+                        int mode, uint32_t* counts, double* scores);
+int tm_score_hypotheses_dev(tm_scene* scene, tm_model* model, int traits_kind,
+                            const float* d_poses16, uint32_t n_hyp, float dist_thres, int mode,
+                            uint32_t* d_counts, double* d_scores);
+/* early-drop rule of project_ (include/impl/scene.hpp:422-426,492-506) evaluated exactly for a
+ * batch: dropped_at[h] = checkpoint index (0..17) or -1, counts/scores/saved as project_ returns */
+int tm_score_hypotheses_early_drop(tm_scene* scene, tm_model* model, const float* poses16,
+                                   uint32_t n_hyp, const int32_t* subset, uint32_t n_subset,
+                                   float dist_thres, float accept_prob, uint32_t* counts,
+                                   double* scores, int32_t* dropped_at, uint32_t* saved);
+
+/* finish_find (include/impl/scene.hpp:100-106): correspondences of one pose over all points,
+ * ascending scene index; *score normalised by |model cloud| */
+int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pose16[16],
+                               float dist_thres, uint32_t* scene_corrs, uint32_t* model_corrs,
+                               uint32_t cap, uint32_t* count, double* score);
+
+/* ---- best-hypothesis record and its reduction (new functionality) ---- */
+typedef struct tm_best_record {
+    uint32_t inlier_count;
+    uint32_t hyp_id; /* global hypothesis id, 0xFFFFFFFF = none */
+    double score;
+    float pose[16];
+    uint32_t pad[4];
+} tm_best_record; /* 96 bytes */
+/* local argmax over a scored batch on the device: order = count desc, score desc, id asc */
+int tm_best_of_batch(tm_ctx* ctx, const uint32_t* d_counts, const double* d_scores,
+                     const float* d_poses16, uint32_t n_hyp, uint32_t id_offset, uint32_t id_stride,
+                     tm_best_record* best);
+/* deterministic selection among records (host); used after the RCCL all-gather */
+int tm_best_select(const tm_best_record* records, uint32_t n, tm_best_record* best);
+
+/* ---- traits projector math (host side; replaces the statics of the include/<kind>_traits headers) ---- */
+int   tm_traits_init_from_samples(int kind, const float* model_state, const float* samples,
+                                  float* state); /* returns 1 if the sample set is rejected */
+int   tm_traits_project(int kind, const float* state, const float xyz[3], float uvw[3]);
+void  tm_traits_unproject(int kind, const float* state, const float uvw[3], float xyz[3]);
+void  tm_traits_tangent(int kind, const float* state, const float* surfel, float out[3]);
+void  tm_traits_normal(int kind, const float* state, const float* surfel, float out[3]);
+float tm_traits_intrinsic_distance(int kind, const float* state, const float p0[3],
+                                   const float p1[3]);
+/* batched device projection of a cloud into uvw space (pos, traits tangent, traits normal):
+ * out surfels have pos = uvw; valid[i] = 0 where project() returns nullopt */
+int tm_traits_project_cloud(tm_ctx* ctx, int kind, const float* state, const float* surfels,
+                            uint32_t n, float* uvw_surfels, int32_t* valid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TM_HIP_H_ */

@@ -1,0 +1,334 @@
+"""GPU parity tests proper: every call goes through the C ABI (libtm_hip.so) and is compared with
+the CPU oracle on the same seeded inputs. Bar: bit-exact for keys, hashes, table contents, voxel
+indices, inlier counts, correspondences and (here) poses; scores (fp64 sums of fp32 terms,
+order-free fixed-point accumulation on the GPU) to 1e-9 relative."""
+import numpy as np
+import pytest
+
+from conftest import random_poses_near_truth, sample_pairs
+from oracle import tmo
+from triplet_match_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+DT = 3.0
+SCORE_RTOL = 1e-9
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_device_descriptor_kernel_bit_exact(gpu_ctx, small_case):
+    model, subset = small_case["model"], small_case["subset"]
+    rng = np.random.default_rng(3)
+    ab = rng.choice(subset, size=(4000, 2))
+    ab = ab[ab[:, 0] != ab[:, 1]]
+    bmin = np.array([0.25, 0, 0, 0.25], np.float32)
+    bmax = np.array([1.45, 1.6, 1.6, 1.45], np.float32)
+    step = capi.default_angle_step()
+    feats, keys, hashes = gpu_ctx.features_batch(model, ab, bmin, bmax, 20.0, step)
+    for t in range(len(ab)):
+        f = tmo.feature(model[ab[t, 0]], model[ab[t, 1]])
+        assert np.array_equal(bits(feats[t]), bits(f)), t
+        k = tmo.discretize_feature(f, bmin, bmax, 20.0, step)
+        assert np.array_equal(keys[t], k), t
+        assert hashes[t] == tmo.murmur_key(k)
+
+
+def test_descriptor_bin_edges(gpu_ctx):
+    """perpendicular / parallel configurations sit exactly on angle-bin edges."""
+    s = np.zeros((4, 12), np.float32)
+    s[1, 0] = 1.0
+    s[2, 1] = 0.5
+    s[3, 0:3] = [0.3, 0.3, 0.0]
+    s[0, 9:12] = [0, 1, 0]
+    s[1, 9:12] = [1, 0, 0]
+    s[2, 9:12] = [0, 0, 1]
+    s[3, 9:12] = np.array([1, 1, 0], np.float32) / np.float32(np.sqrt(2))
+    ab = np.array([[a, b] for a in range(4) for b in range(4) if a != b], np.uint32)
+    bmin = np.array([0.1, 0, 0, 0.1], np.float32)
+    bmax = np.array([1.2, 1.6, 1.6, 1.2], np.float32)
+    step = float(np.float32(0.17453294))
+    feats, keys, hashes = gpu_ctx.features_batch(s, ab, bmin, bmax, 20.0, step)
+    for t in range(len(ab)):
+        f = tmo.feature(s[ab[t, 0]], s[ab[t, 1]])
+        assert np.array_equal(bits(feats[t]), bits(f))
+        assert np.array_equal(keys[t], tmo.discretize_feature(f, bmin, bmax, 20.0, step))
+    assert keys[0][1] == 9  # 90 degrees / 10 degrees lands on bin 9 exactly
+
+
+def test_voxel_grid_bit_exact(gpu_small, oracle_small):
+    g, o = gpu_small["model"], oracle_small["model"]
+    eg, tg = g.grid()
+    eo, to = o.grid()
+    assert np.array_equal(eg, eo) and np.array_equal(bits(tg), bits(to))
+    assert abs(g.diameter - o.diameter) == 0.0
+    vg, vo = g.voxels(), o.voxels()
+    assert vg.shape == vo.shape
+    assert np.array_equal(vg, vo)
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        p = np.append(rng.random(3) * 1.4 - 0.2, 1.0).astype(np.float32)
+        assert g.voxel_query(p) == o.voxel_query(p)
+
+
+def test_voxel_grid_with_ties_and_degenerate_axis(gpu_ctx):
+    """planar cloud (one axis has range 0 -> scale 1, ext 1) with duplicated points (ties)."""
+    rng = np.random.default_rng(5)
+    n = 400
+    s = np.zeros((n, 12), np.float32)
+    s[:, 0:2] = rng.random((n, 2))
+    s[:, 3] = 1
+    s[:, 6] = 1
+    s[n // 2:, 0:3] = s[:n // 2, 0:3]  # exact duplicates: lowest index must win
+    res = 0.05
+    g = capi.Model(gpu_ctx, s, res)
+    g.build_voxels()
+    o = tmo.Model(s, res)
+    o.build_voxels(threads=4, brute=True)
+    assert np.array_equal(g.grid()[0], o.grid()[0])
+    vg, vo = g.voxels(), o.voxels()
+    assert np.array_equal(vg, vo) and vg.max() < n // 2
+
+
+def test_pair_table_bit_exact(gpu_small, oracle_small, small_case):
+    g, o = gpu_small["model"], oracle_small["model"]
+    bg, bo = g.feature_bounds(), o.feature_bounds()
+    assert np.array_equal(bits(bg[0]), bits(bo[0])) and np.array_equal(bits(bg[1]), bits(bo[1]))
+    pc = g.pair_counts()
+    assert pc["entries"] == o.pair_count() and pc["valid_pairs"] == o.valid_count()
+    keys, offs, pairs = g.table()
+    okeys, ocounts = o.table_keys()
+    assert np.array_equal(keys, okeys)
+    assert np.array_equal(np.diff(offs.astype(np.int64)), ocounts.astype(np.int64))
+    for k in range(len(keys)):
+        ent, total = o.query_key(keys[k])
+        assert np.array_equal(pairs[offs[k]:offs[k + 1]], ent), keys[k]
+    assert g.info()["point_count"] == len(small_case["subset"])
+
+
+def test_query_matches_container_order_and_limit(gpu_small, oracle_small, small_case):
+    g, o = gpu_small["model"], oracle_small["model"]
+    model, subset = small_case["model"], small_case["subset"]
+    rng = np.random.default_rng(8)
+    hits = 0
+    for _ in range(60):
+        i, j = rng.choice(subset, size=2, replace=False)
+        f = tmo.feature(model[i], model[j])
+        eo, to = o.query(f, cap=200)
+        eg, tg = g.query(f, cap=200)
+        assert tg == to and np.array_equal(eg, eo)
+        hits += to > 0
+    assert hits > 10
+    # a key that cannot exist
+    eg, tg = g.query_key([19, 9, 9, 18])
+    assert tg == 0 and len(eg) == 0
+
+
+def test_query_uninitialised_model_errors(gpu_ctx, small_case):
+    m = capi.Model(gpu_ctx, small_case["model"], small_case["resolution"])
+    with pytest.raises(capi.TmError) as e:
+        m.query([1.0, 0.5, 0.5, 1.0])
+    assert e.value.code == capi.ERR_NOT_INITIALIZED and "uninitialized" in str(e.value)
+    with pytest.raises(capi.TmError):
+        m.build_pairs(small_case["subset"][:1])  # fewer than two points -> empty table
+
+
+def test_hypothesis_generation_bit_exact(gpu_small, oracle_small, small_case):
+    pairs = sample_pairs(small_case, oracle_small["model"], n_first=40, per_first=8)
+    # add pairs that must be filtered: i == j, non-tangent j, out-of-window
+    tm = small_case["scene"]["tangent_mask"]
+    nont = int(np.nonzero(tm == 0)[0][0])
+    extra = np.array([[pairs[0, 0], pairs[0, 0]], [pairs[0, 0], nont]], np.uint32)
+    pairs = np.concatenate([extra, pairs])
+    po, vo = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs)
+    pg, vg, total = gpu_small["scene"].generate_hypotheses(gpu_small["model"], pairs)
+    assert total == len(po) and len(pg) == len(po) and len(po) > 500
+    assert np.array_equal(vg, vo)
+    assert np.array_equal(bits(pg), bits(po))  # poses bit for bit
+    # capacity truncation keeps the first `cap` in visit order
+    pg2, vg2, total2 = gpu_small["scene"].generate_hypotheses(gpu_small["model"], pairs, cap=100)
+    assert total2 == total and np.array_equal(vg2, vo[:100])
+    # query_limit
+    po3, vo3 = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs, query_limit=7)
+    pg3, vg3, _ = gpu_small["scene"].generate_hypotheses(gpu_small["model"], pairs, query_limit=7)
+    assert np.array_equal(vg3, vo3) and vo3[:, 3].max() == 6
+    # force_up (ordered compaction)
+    po4, vo4 = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs, force_up=True)
+    pg4, vg4, total4 = gpu_small["scene"].generate_hypotheses(gpu_small["model"], pairs, force_up=True)
+    assert total4 == len(po4) < len(po)
+    assert np.array_equal(vg4, vo4) and np.array_equal(bits(pg4), bits(po4))
+
+
+def test_inlier_counts_bit_exact_full_scene(gpu_small, oracle_small, small_case):
+    pairs = sample_pairs(small_case, oracle_small["model"], n_first=30, per_first=6)
+    poses, _ = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs)
+    poses = np.concatenate([poses[:1500], random_poses_near_truth(small_case, 40)])
+    co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, threads=8)
+    cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT,
+                                                  mode=capi.SCORE_BRUTEFORCE)
+    assert np.array_equal(cg, co)
+    assert co.max() > 1500  # the planted poses are in the batch
+    assert np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    cg2, sg2 = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT, mode=capi.SCORE_AUTO)
+    assert np.array_equal(cg2, co) and np.allclose(sg2, so, rtol=SCORE_RTOL, atol=1e-15)
+
+
+def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
+    poses = random_poses_near_truth(small_case, 30)
+    inst0 = np.nonzero(small_case["scene"]["instance_id"] == 0)[0]
+    sub = oracle_small["scene"].radius_subset(int(inst0[0]), oracle_small["model"].diameter)
+    co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, subset=sub)
+    cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT, subset=sub)
+    assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    # empty subset
+    cg0, sg0 = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT,
+                                                    subset=np.zeros(0, np.int32))
+    assert not cg0.any() and not sg0.any()
+    # mask half of instance 0
+    mask = np.zeros(small_case["scene"]["surfels"].shape[0], np.int32)
+    mask[inst0[::2]] = 1
+    oracle_small["scene"].set_mask(mask)
+    gpu_small["scene"].set_mask(mask)
+    try:
+        co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT)
+        cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+        assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    finally:
+        oracle_small["scene"].set_mask(None)
+        gpu_small["scene"].set_mask(None)
+    co, _, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT)
+    cg, _ = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+    assert np.array_equal(cg, co)
+
+
+def test_dist_thres_boundary(gpu_small, oracle_small, small_case):
+    """d2 <= d2max on the GPU must equal !(sqrtf(d2) > thres) on the CPU for any threshold."""
+    poses = random_poses_near_truth(small_case, 12)
+    for dt in (0.25, 0.5, 1.0, 1.7, 2.3, 6.0):
+        co, _, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, dt)
+        cg, _ = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, dt)
+        assert np.array_equal(cg, co), dt
+
+
+def test_extract_correspondences_equals_finish_find(gpu_small, oracle_small, small_case):
+    for T in small_case["scene"]["poses_scene_to_model"]:
+        P = synth.pose_colmajor(T)
+        sco, mco, so, _ = oracle_small["scene"].project(oracle_small["model"], P, 0.5, DT)
+        scg, mcg, sg = gpu_small["scene"].extract_correspondences(gpu_small["model"], P, DT)
+        assert np.array_equal(scg, sco) and np.array_equal(mcg, mco)
+        assert abs(sg - so) <= SCORE_RTOL * abs(so)
+
+
+def test_early_drop_rule_bit_exact(gpu_small, oracle_small, small_case):
+    pairs = sample_pairs(small_case, oracle_small["model"], n_first=20, per_first=5)
+    poses, _ = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs)
+    poses = np.concatenate([poses[:300], random_poses_near_truth(small_case, 30)])
+    inst0 = np.nonzero(small_case["scene"]["instance_id"] == 0)[0]
+    sub = oracle_small["scene"].radius_subset(int(inst0[0]), oracle_small["model"].diameter)
+    rng = np.random.default_rng(1)
+    sub_shuffled = sub.copy()
+    rng.shuffle(sub_shuffled)
+    for subset in (None, sub, sub_shuffled):
+        cg, sg, dg, vg = gpu_small["scene"].score_hypotheses_early_drop(
+            gpu_small["model"], poses, DT, 0.5, subset=subset)
+        n_dropped = 0
+        for h in range(len(poses)):
+            sc, mc, score, saved = oracle_small["scene"].project(
+                oracle_small["model"], poses[h], 0.5, DT, subset=subset, early_out=True)
+            assert cg[h] == len(sc), (h, cg[h], len(sc))
+            assert vg[h] == saved
+            assert (dg[h] >= 0) == (saved > 0 or dg[h] >= 0)
+            assert abs(sg[h] - score) <= SCORE_RTOL * max(abs(score), 1e-30)
+            n_dropped += dg[h] >= 0
+        assert 0 < n_dropped < len(poses)
+
+
+def test_best_of_batch(gpu_ctx, gpu_small, small_case):
+    poses = random_poses_near_truth(small_case, 64)
+    n = len(poses)
+    d_p = gpu_ctx.alloc(n * 64)
+    d_c = gpu_ctx.alloc(n * 4)
+    d_s = gpu_ctx.alloc(n * 8)
+    try:
+        gpu_ctx.h2d(d_p, poses)
+        gpu_small["scene"].score_hypotheses_dev(gpu_small["model"], d_p, n, DT, d_c, d_s)
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        gpu_ctx.d2h(counts, d_c)
+        gpu_ctx.d2h(scores, d_s)
+        rec = gpu_ctx.best_of_batch(d_c, d_s, d_p, n, id_offset=1000, id_stride=3)
+        order = sorted(range(n), key=lambda i: (-int(counts[i]), -scores[i], i))
+        assert rec.hyp_id == 1000 + 3 * order[0] and rec.inlier_count == counts[order[0]]
+        assert np.array_equal(np.array(rec.pose[:], np.float32), poses[order[0]])
+        cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+        assert np.array_equal(cg, counts) and np.array_equal(sg, scores)  # deterministic scores
+    finally:
+        for p in (d_p, d_c, d_s):
+            gpu_ctx.free(p)
+
+
+def test_generate_and_score_device_resident(gpu_ctx, gpu_small, oracle_small, small_case):
+    pairs = sample_pairs(small_case, oracle_small["model"], n_first=30, per_first=6)
+    cap = 4096
+    d_ij = gpu_ctx.alloc(pairs.nbytes)
+    d_p = gpu_ctx.alloc(cap * 64)
+    d_v = gpu_ctx.alloc(cap * 16)
+    d_c = gpu_ctx.alloc(cap * 4)
+    d_s = gpu_ctx.alloc(cap * 8)
+    try:
+        gpu_ctx.h2d(d_ij, pairs)
+        n, total = gpu_small["scene"].generate_hypotheses_dev(gpu_small["model"], d_ij, len(pairs),
+                                                             d_p, d_v, cap)
+        gpu_small["scene"].score_hypotheses_dev(gpu_small["model"], d_p, n, DT, d_c, d_s)
+        counts = np.zeros(n, np.uint32)
+        gpu_ctx.d2h(counts, d_c)
+        po, _ = oracle_small["scene"].generate_hypotheses(oracle_small["model"], pairs)
+        co, _, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], po[:n], 0.5, DT, threads=8)
+        assert total == len(po) and np.array_equal(counts, co)
+    finally:
+        for p in (d_ij, d_p, d_v, d_c, d_s):
+            gpu_ctx.free(p)
+
+
+def test_nonfinite_scene_points_are_ignored(gpu_ctx, gpu_small, oracle_small, small_case):
+    s = small_case["scene"]["surfels"].copy()
+    s[::97, 0] = np.nan
+    s[5::101, 2] = np.inf
+    tmask = small_case["scene"]["tangent_mask"]
+    gs = capi.Scene(gpu_ctx, s, tmask)
+    os_ = tmo.Scene(s, tmask)
+    poses = random_poses_near_truth(small_case, 10)
+    co, _, _ = os_.score_hypotheses(oracle_small["model"], poses, 0.5, DT)
+    cg, _ = gs.score_hypotheses(gpu_small["model"], poses, DT)
+    assert np.array_equal(cg, co)
+
+
+def test_traits_project_cloud_bit_exact(gpu_ctx):
+    rng = np.random.default_rng(6)
+    n = 3000
+    theta = rng.random(n) * 2 * np.pi
+    h = rng.random(n) * 2
+    r = 0.5 + rng.normal(size=n) * 0.01
+    nrm = np.stack([np.cos(theta), np.sin(theta), np.zeros(n)], 1)
+    s = np.zeros((n, 12), np.float32)
+    s[:, 0:3] = np.array([1, 2, 3]) + r[:, None] * nrm + np.stack([0 * h, 0 * h, h], 1)
+    s[:, 3] = 1
+    s[:, 4:7] = -nrm
+    s[::3, 9:12] = [0, 0, 1]
+    ms = np.zeros(capi.STATE_FLOATS, np.float32)
+    ms[1] = 0.02
+    st = capi.traits_init_from_samples(capi.CYLINDER, ms, np.concatenate([s[0], s[7]]))
+    for kind in (capi.IDENTITY, capi.PLANE, capi.PLANE2, capi.CYLINDER):
+        out, valid = gpu_ctx.traits_project_cloud(kind, st, s)
+        for i in range(0, n, 7):
+            uvw = tmo.traits_project(kind, st, s[i, 0:3])
+            assert (uvw is not None) == bool(valid[i])
+            if uvw is None:
+                continue
+            assert np.array_equal(bits(out[i, 0:3]), bits(uvw)), (kind, i)
+            if np.linalg.norm(s[i, 9:12]) > 0:
+                assert np.array_equal(bits(out[i, 9:12]), bits(tmo.traits_tangent(kind, st, s[i])))
+                assert np.array_equal(bits(out[i, 4:7]), bits(tmo.traits_normal(kind, st, s[i])))
+        assert 0 < valid.sum() <= n

@@ -1,0 +1,550 @@
+"""ctypes binding of libtm_hip.so (include/tm_hip.h) with numpy-facing wrappers.
+
+This is plumbing for tests, bench.py and smoke(): the product is the C ABI itself. There is no
+fallback of any kind — if the HIP library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtm_hip.so")
+
+OK, ERR_INVALID, ERR_NOT_INITIALIZED, ERR_HIP, ERR_EMPTY, ERR_UNSUPPORTED, ERR_NO_DEVICE, \
+    ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
+IDENTITY, PLANE, PLANE2, CYLINDER = 0, 1, 2, 3
+STATE_FLOATS = 37
+SCORE_AUTO, SCORE_BRUTEFORCE, SCORE_CULLED = 0, 1, 2
+
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class BestRecord(C.Structure):
+    _fields_ = [("inlier_count", C.c_uint32), ("hyp_id", C.c_uint32), ("score", C.c_double),
+                ("pose", C.c_float * 16), ("pad", C.c_uint32 * 4)]
+
+
+assert C.sizeof(BestRecord) == 96
+
+# every symbol include/tm_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "tm_last_error": (C.c_char_p, []),
+    "tm_version": (C.c_char_p, []),
+    "tm_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "tm_ctx_destroy": (C.c_int, [vp]),
+    "tm_ctx_synchronize": (C.c_int, [vp]),
+    "tm_ctx_stream": (vp, [vp]),
+    "tm_device_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "tm_device_free": (C.c_int, [vp, vp]),
+    "tm_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "tm_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "tm_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+    "tm_ctx_last_score_timing": (C.c_int, [vp, f32p, u64p, u64p, u64p]),
+    "tm_murmur3_32": (C.c_uint32, [u32p, C.c_int, C.c_uint32]),
+    "tm_hash_key": (C.c_uint32, [u32p, C.c_int]),
+    "tm_discretize_range": (C.c_uint32, [C.c_float, C.c_float, C.c_float, C.c_uint32]),
+    "tm_discretize_step": (C.c_uint32, [C.c_float, C.c_float]),
+    "tm_atan2f": (C.c_float, [C.c_float, C.c_float]),
+    "tm_feature": (None, [f32p, f32p, f32p]),
+    "tm_discretize_feature": (None, [f32p, f32p, f32p, C.c_float, C.c_float, u32p]),
+    "tm_valid": (C.c_int, [f32p, f32p, f32p]),
+    "tm_valid_bounds": (None, [f32p, f32p, C.c_float, C.c_float, f32p, f32p]),
+    "tm_base_transform": (None, [f32p] * 7),
+    "tm_early_drop_upper": (C.c_uint32, [C.c_uint32] * 3),
+    "tm_features_batch": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, f32p, f32p, C.c_float,
+                                    C.c_float, f32p, u32p, u32p]),
+    "tm_model_create": (C.c_int, [vp, f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
+                                  C.POINTER(vp)]),
+    "tm_model_destroy": (C.c_int, [vp]),
+    "tm_model_build_voxels": (C.c_int, [vp]),
+    "tm_model_build_pairs": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_float]),
+    "tm_model_get_info": (C.c_int, [vp, f32p, u32p, u32p, f32p]),
+    "tm_model_get_grid": (C.c_int, [vp, i32p, f32p]),
+    "tm_model_download_voxels": (C.c_int, [vp, u32p, C.c_uint64, u64p]),
+    "tm_model_get_feature_bounds": (C.c_int, [vp, f32p, f32p]),
+    "tm_model_get_pair_counts": (C.c_int, [vp, u64p, u64p, u32p]),
+    "tm_model_download_table": (C.c_int, [vp, u32p, u32p, C.c_uint32, u32p, C.c_uint64]),
+    "tm_model_query": (C.c_int, [vp, f32p, u32p, C.c_uint32, u32p]),
+    "tm_model_query_key": (C.c_int, [vp, u32p, u32p, C.c_uint32, u32p]),
+    "tm_model_voxel_query": (C.c_int, [vp, f32p, u32p, C.POINTER(C.c_int)]),
+    "tm_scene_create": (C.c_int, [vp, f32p, C.c_uint32, i32p, C.POINTER(vp)]),
+    "tm_scene_destroy": (C.c_int, [vp]),
+    "tm_scene_set_mask": (C.c_int, [vp, i32p]),
+    "tm_scene_size": (C.c_uint32, [vp]),
+    "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
+                                         C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
+    "tm_generate_hypotheses_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_int,
+                                             C.c_int, vp, vp, C.c_uint32, u32p, u32p]),
+    "tm_score_hypotheses": (C.c_int, [vp, vp, C.c_int, f32p, C.c_uint32, i32p, C.c_uint32,
+                                      C.c_float, C.c_int, u32p, f64p]),
+    "tm_score_hypotheses_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, C.c_float, C.c_int, vp,
+                                          vp]),
+    "tm_score_hypotheses_early_drop": (C.c_int, [vp, vp, f32p, C.c_uint32, i32p, C.c_uint32,
+                                                 C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
+    "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
+                                             f64p]),
+    "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.POINTER(BestRecord)]),
+    "tm_best_select": (C.c_int, [C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
+    "tm_traits_init_from_samples": (C.c_int, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_project": (C.c_int, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_unproject": (None, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_tangent": (None, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_normal": (None, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_intrinsic_distance": (C.c_float, [C.c_int, f32p, f32p, f32p]),
+    "tm_traits_project_cloud": (C.c_int, [vp, C.c_int, f32p, f32p, C.c_uint32, f32p, i32p]),
+}
+
+_lib = None
+
+
+class TmError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("tm error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    """Load libtm_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libtm_hip.so is not built: run `python -m triplet_match_amd.build` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise TmError(rc, lib().tm_last_error().decode(errors="replace"))
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+def _u(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(u32p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(i32p)
+
+
+def default_angle_step():
+    """10 degrees in radians computed in f32 (reference apps/triplet_match.cpp:19)."""
+    return float(np.float32(10.0) * np.float32(np.pi) / np.float32(180.0))
+
+
+# ---- host scalar functions -------------------------------------------------------------------
+def murmur3_32(words, seed):
+    w, p = _u(words)
+    return int(lib().tm_murmur3_32(p, len(w), seed))
+
+
+def hash_key(key):
+    w, p = _u(key)
+    return int(lib().tm_hash_key(p, len(w)))
+
+
+def discretize_range(v, mn, rng, steps):
+    return int(lib().tm_discretize_range(v, mn, rng, steps))
+
+
+def discretize_step(v, step):
+    return int(lib().tm_discretize_step(v, step))
+
+
+def atan2f(y, x):
+    return float(lib().tm_atan2f(y, x))
+
+
+def feature(s0, s1):
+    a, pa = _f(s0)
+    b, pb = _f(s1)
+    out = np.zeros(4, np.float32)
+    lib().tm_feature(pa, pb, out.ctypes.data_as(f32p))
+    return out
+
+
+def discretize_feature(f, bmin, bmax, distance_step_count, angle_step):
+    a, pa = _f(f)
+    b, pb = _f(bmin)
+    c, pc = _f(bmax)
+    out = np.zeros(4, np.uint32)
+    lib().tm_discretize_feature(pa, pb, pc, distance_step_count, angle_step,
+                                out.ctypes.data_as(u32p))
+    return out
+
+
+def valid(f, bmin, bmax):
+    a, pa = _f(f)
+    b, pb = _f(bmin)
+    c, pc = _f(bmax)
+    return bool(lib().tm_valid(pa, pb, pc))
+
+
+def base_transform(src_i, src_j, src_t, tgt_i, tgt_j, tgt_t):
+    arrs = [_f(x) for x in (src_i, src_j, src_t, tgt_i, tgt_j, tgt_t)]
+    out = np.zeros(16, np.float32)
+    lib().tm_base_transform(*[p for _, p in arrs], out.ctypes.data_as(f32p))
+    return out
+
+
+def early_drop_upper(tried, subset, corrs):
+    return int(lib().tm_early_drop_upper(tried, subset, corrs))
+
+
+# ---- handles -----------------------------------------------------------------------------------
+class Context:
+    def __init__(self, device=0):
+        h = vp()
+        _check(lib().tm_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def synchronize(self):
+        _check(lib().tm_ctx_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        _check(lib().tm_ctx_enable_timing(self.h, int(on)))
+
+    def last_score_timing(self):
+        ms = C.c_float(0)
+        ev, ps, hy = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().tm_ctx_last_score_timing(self.h, C.byref(ms), C.byref(ev), C.byref(ps),
+                                              C.byref(hy)))
+        return dict(ms=ms.value, evaluations=ev.value, passing=ps.value, hypotheses=hy.value)
+
+    def alloc(self, nbytes):
+        p = vp()
+        _check(lib().tm_device_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        _check(lib().tm_device_free(self.h, p))
+
+    def h2d(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().tm_memcpy_h2d(self.h, d_ptr, arr.ctypes.data_as(vp), arr.nbytes))
+
+    def d2h(self, arr, d_ptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        _check(lib().tm_memcpy_d2h(self.h, arr.ctypes.data_as(vp), d_ptr, arr.nbytes))
+
+    def features_batch(self, surfels, ab_pairs, bmin=None, bmax=None, distance_step_count=20.0,
+                       angle_step=None):
+        if angle_step is None:
+            angle_step = default_angle_step()
+        s, ps = _f(np.asarray(surfels).reshape(-1, 12))
+        ab, pab = _u(np.asarray(ab_pairs).reshape(-1, 2))
+        n = ab.shape[0]
+        feats = np.zeros((n, 4), np.float32)
+        keys = np.zeros((n, 4), np.uint32)
+        hashes = np.zeros(n, np.uint32)
+        if bmin is not None:
+            b0, pb0 = _f(bmin)
+            b1, pb1 = _f(bmax)
+        else:
+            pb0 = pb1 = None
+        _check(lib().tm_features_batch(self.h, ps, s.shape[0], pab, n, pb0, pb1,
+                                       distance_step_count, angle_step,
+                                       feats.ctypes.data_as(f32p), keys.ctypes.data_as(u32p),
+                                       hashes.ctypes.data_as(u32p)))
+        return feats, keys, hashes
+
+    def best_of_batch(self, d_counts, d_scores, d_poses, n_hyp, id_offset=0, id_stride=1):
+        rec = BestRecord()
+        _check(lib().tm_best_of_batch(self.h, d_counts, d_scores, d_poses, n_hyp, id_offset,
+                                      id_stride, C.byref(rec)))
+        return rec
+
+    def traits_project_cloud(self, kind, state, surfels):
+        st, pst = _f(state)
+        s, ps = _f(np.asarray(surfels).reshape(-1, 12))
+        out = np.zeros_like(s)
+        valid_ = np.zeros(s.shape[0], np.int32)
+        _check(lib().tm_traits_project_cloud(self.h, kind, pst, ps, s.shape[0],
+                                             out.ctypes.data_as(f32p), valid_.ctypes.data_as(i32p)))
+        return out, valid_
+
+
+def best_select(records):
+    arr = (BestRecord * len(records))(*records)
+    out = BestRecord()
+    _check(lib().tm_best_select(arr, len(records), C.byref(out)))
+    return out
+
+
+class Model:
+    """model<Point> over the C ABI (reference include/model:15-66)."""
+
+    def __init__(self, ctx, surfels, resolution, distance_step_count=20.0, angle_step=None):
+        if angle_step is None:
+            angle_step = default_angle_step()
+        self.ctx = ctx
+        s, p = _f(np.asarray(surfels).reshape(-1, 12))
+        self.n = s.shape[0]
+        h = vp()
+        _check(lib().tm_model_create(ctx.h, p, self.n, resolution, distance_step_count, angle_step,
+                                     C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tm_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def build_voxels(self):
+        _check(lib().tm_model_build_voxels(self.h))
+
+    def build_pairs(self, subset, min_diameter_factor=0.2, max_diameter_factor=1.0):
+        s, p = _u(subset)
+        _check(lib().tm_model_build_pairs(self.h, p, s.size, min_diameter_factor,
+                                          max_diameter_factor))
+
+    def info(self):
+        d, r = C.c_float(0), C.c_float(0)
+        n, pc = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().tm_model_get_info(self.h, C.byref(d), C.byref(n), C.byref(pc), C.byref(r)))
+        return dict(diameter=d.value, cloud_size=n.value, point_count=pc.value, resolution=r.value)
+
+    @property
+    def diameter(self):
+        return self.info()["diameter"]
+
+    def grid(self):
+        ext = np.zeros(3, np.int32)
+        tv = np.zeros(16, np.float32)
+        _check(lib().tm_model_get_grid(self.h, ext.ctypes.data_as(i32p), tv.ctypes.data_as(f32p)))
+        return ext, tv
+
+    def voxels(self):
+        cnt = C.c_uint64(0)
+        _check(lib().tm_model_download_voxels(self.h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, np.uint32)
+        _check(lib().tm_model_download_voxels(self.h, out.ctypes.data_as(u32p), out.size,
+                                              C.byref(cnt)))
+        return out
+
+    def feature_bounds(self):
+        a = np.zeros(4, np.float32)
+        b = np.zeros(4, np.float32)
+        _check(lib().tm_model_get_feature_bounds(self.h, a.ctypes.data_as(f32p),
+                                                 b.ctypes.data_as(f32p)))
+        return a, b
+
+    def pair_counts(self):
+        e, v, k = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        _check(lib().tm_model_get_pair_counts(self.h, C.byref(e), C.byref(v), C.byref(k)))
+        return dict(entries=e.value, valid_pairs=v.value, distinct_keys=k.value)
+
+    def table(self):
+        pc = self.pair_counts()
+        keys = np.zeros((pc["distinct_keys"], 4), np.uint32)
+        offs = np.zeros(pc["distinct_keys"] + 1, np.uint32)
+        pairs = np.zeros((pc["entries"], 2), np.uint32)
+        _check(lib().tm_model_download_table(self.h, keys.ctypes.data_as(u32p),
+                                             offs.ctypes.data_as(u32p), keys.shape[0],
+                                             pairs.ctypes.data_as(u32p), pairs.shape[0]))
+        return keys, offs, pairs
+
+    def query(self, f, cap=1 << 20):
+        a, pa = _f(f)
+        total = C.c_uint32(0)
+        _check(lib().tm_model_query(self.h, pa, None, 0, C.byref(total)))
+        n = min(total.value, cap)
+        out = np.zeros((n, 2), np.uint32)
+        _check(lib().tm_model_query(self.h, pa, out.ctypes.data_as(u32p), n, C.byref(total)))
+        return out, total.value
+
+    def query_key(self, key, cap=1 << 20):
+        k, pk = _u(key)
+        total = C.c_uint32(0)
+        _check(lib().tm_model_query_key(self.h, pk, None, 0, C.byref(total)))
+        n = min(total.value, cap)
+        out = np.zeros((n, 2), np.uint32)
+        _check(lib().tm_model_query_key(self.h, pk, out.ctypes.data_as(u32p), n, C.byref(total)))
+        return out, total.value
+
+    def voxel_query(self, pos4):
+        a, pa = _f(pos4)
+        idx = C.c_uint32(0)
+        found = C.c_int(0)
+        _check(lib().tm_model_voxel_query(self.h, pa, C.byref(idx), C.byref(found)))
+        return idx.value if found.value else None
+
+
+class Scene:
+    """scene<Point> over the C ABI (reference include/scene:10-59)."""
+
+    def __init__(self, ctx, surfels, tangent_mask):
+        self.ctx = ctx
+        s, p = _f(np.asarray(surfels).reshape(-1, 12))
+        self.n = s.shape[0]
+        tm, ptm = _i(tangent_mask)
+        h = vp()
+        _check(lib().tm_scene_create(ctx.h, p, self.n, ptm, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tm_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_mask(self, mask):
+        if mask is None:
+            _check(lib().tm_scene_set_mask(self.h, None))
+        else:
+            m, p = _i(mask)
+            _check(lib().tm_scene_set_mask(self.h, p))
+
+    def generate_hypotheses(self, model, ij_pairs, min_diameter_factor=0.2,
+                            max_diameter_factor=1.0, force_up=False, query_limit=200, cap=None):
+        ij, pij = _u(np.asarray(ij_pairs).reshape(-1, 2))
+        n_pairs = ij.shape[0]
+        if cap is None:
+            lim = query_limit if query_limit > 0 else 4096
+            cap = max(1, n_pairs * lim)
+        poses = np.zeros((cap, 16), np.float32)
+        prov = np.zeros((cap, 4), np.uint32)
+        cnt, tot = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().tm_generate_hypotheses(self.h, model.h, pij, n_pairs, min_diameter_factor,
+                                            max_diameter_factor, int(force_up), query_limit,
+                                            poses.ctypes.data_as(f32p), prov.ctypes.data_as(u32p),
+                                            cap, C.byref(cnt), C.byref(tot)))
+        return poses[:cnt.value].copy(), prov[:cnt.value].copy(), tot.value
+
+    def generate_hypotheses_dev(self, model, d_ij, n_pairs, d_poses, d_prov, cap,
+                                min_diameter_factor=0.2, max_diameter_factor=1.0, force_up=False,
+                                query_limit=200):
+        cnt, tot = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().tm_generate_hypotheses_dev(self.h, model.h, d_ij, n_pairs, min_diameter_factor,
+                                                max_diameter_factor, int(force_up), query_limit,
+                                                d_poses, d_prov, cap, C.byref(cnt), C.byref(tot)))
+        return cnt.value, tot.value
+
+    def score_hypotheses(self, model, poses16, dist_thres, subset=None, mode=SCORE_AUTO,
+                         traits=IDENTITY):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        if subset is None:
+            ps, ns = None, 0
+        else:
+            subset, ps = _i(subset)
+            ns = subset.size
+        _check(lib().tm_score_hypotheses(self.h, model.h, traits, pP, n, ps, ns, dist_thres, mode,
+                                         counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p)))
+        return counts, scores
+
+    def score_hypotheses_dev(self, model, d_poses, n_hyp, dist_thres, d_counts, d_scores,
+                             mode=SCORE_AUTO, traits=IDENTITY):
+        _check(lib().tm_score_hypotheses_dev(self.h, model.h, traits, d_poses, n_hyp, dist_thres,
+                                             mode, d_counts, d_scores))
+
+    def score_hypotheses_early_drop(self, model, poses16, dist_thres, accept_prob, subset=None):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        dropped = np.zeros(n, np.int32)
+        saved = np.zeros(n, np.uint32)
+        if subset is None:
+            ps, ns = None, 0
+        else:
+            subset, ps = _i(subset)
+            ns = subset.size
+        _check(lib().tm_score_hypotheses_early_drop(
+            self.h, model.h, pP, n, ps, ns, dist_thres, accept_prob, counts.ctypes.data_as(u32p),
+            scores.ctypes.data_as(f64p), dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
+        return counts, scores, dropped, saved
+
+    def extract_correspondences(self, model, pose16, dist_thres):
+        T, pT = _f(pose16)
+        sc = np.zeros(self.n, np.uint32)
+        mc = np.zeros(self.n, np.uint32)
+        cnt = C.c_uint32(0)
+        score = C.c_double(0)
+        _check(lib().tm_extract_correspondences(self.h, model.h, pT, dist_thres,
+                                                sc.ctypes.data_as(u32p), mc.ctypes.data_as(u32p),
+                                                self.n, C.byref(cnt), C.byref(score)))
+        return sc[:cnt.value].copy(), mc[:cnt.value].copy(), score.value
+
+
+# ---- traits (host scalar) ----------------------------------------------------------------------
+def traits_init_from_samples(kind, model_state, samples):
+    ms, pm = _f(model_state)
+    s, ps = _f(samples)
+    st = np.zeros(STATE_FLOATS, np.float32)
+    rej = lib().tm_traits_init_from_samples(kind, pm, ps, st.ctypes.data_as(f32p))
+    return None if rej else st
+
+
+def traits_project(kind, state, xyz):
+    s, ps = _f(state)
+    x, px = _f(xyz)
+    out = np.zeros(3, np.float32)
+    ok = lib().tm_traits_project(kind, ps, px, out.ctypes.data_as(f32p))
+    return out if ok else None
+
+
+def traits_unproject(kind, state, uvw):
+    s, ps = _f(state)
+    x, px = _f(uvw)
+    out = np.zeros(3, np.float32)
+    lib().tm_traits_unproject(kind, ps, px, out.ctypes.data_as(f32p))
+    return out
+
+
+def traits_tangent(kind, state, surfel):
+    s, ps = _f(state)
+    x, px = _f(surfel)
+    out = np.zeros(3, np.float32)
+    lib().tm_traits_tangent(kind, ps, px, out.ctypes.data_as(f32p))
+    return out
+
+
+def traits_normal(kind, state, surfel):
+    s, ps = _f(state)
+    x, px = _f(surfel)
+    out = np.zeros(3, np.float32)
+    lib().tm_traits_normal(kind, ps, px, out.ctypes.data_as(f32p))
+    return out
+
+
+def traits_intrinsic_distance(kind, state, p0, p1):
+    s, ps = _f(state)
+    a, pa = _f(p0)
+    b, pb = _f(p1)
+    return float(lib().tm_traits_intrinsic_distance(kind, ps, pa, pb))

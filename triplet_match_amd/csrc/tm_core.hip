@@ -1,0 +1,262 @@
+/* tm_core.hip — context, error text, host-side scalar API and the batched descriptor kernel. */
+#include "tm_internal.h"
+
+namespace tmx {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+int scratch_ensure(tm_ctx* ctx, size_t bytes) { return ctx->scratch.ensure(bytes); }
+
+/* one thread per (a,b) pair: descriptor, key and hash — the device twin of tm_feature /
+ * tm_discretize_feature / tm_hash_key */
+__global__ void k_features_batch(const float* __restrict__ surfels, const uint2* __restrict__ ab,
+                                 uint32_t n_pairs, int have_bounds, float lo0, float hi0,
+                                 uint32_t steps, float angle_step, float4* __restrict__ feats,
+                                 uint4* __restrict__ keys, uint32_t* __restrict__ hashes) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs) return;
+    uint2 p = ab[t];
+    const float* s0 = surfels + (size_t)p.x * 12;
+    const float* s1 = surfels + (size_t)p.y * 12;
+    feat4 f = pair_feature(make3(s0[0], s0[1], s0[2]), make3(s0[9], s0[10], s0[11]),
+                           make3(s1[0], s1[1], s1[2]), make3(s1[9], s1[10], s1[11]));
+    feats[t] = make_float4(f.f0, f.f1, f.f2, f.f3);
+    if (have_bounds) {
+        key4 k = feature_key(f, lo0, hi0, steps, angle_step);
+        keys[t] = make_uint4(k.k0, k.k1, k.k2, k.k3);
+        hashes[t] = murmur_key4(k.k0, k.k1, k.k2, k.k3);
+    }
+}
+
+}  // namespace tmx
+
+using namespace tmx;
+
+extern "C" {
+
+const char* tm_last_error(void) { return g_error.c_str(); }
+const char* tm_version(void) { return "triplet_match_amd 0.1 (gfx950)"; }
+
+int tm_ctx_create(int device_id, tm_ctx** out) {
+    TM_REQUIRE(out, TM_ERR_INVALID, "tm_ctx_create: null output");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return TM_ERR_NO_DEVICE;
+    }
+    TM_REQUIRE(device_id >= 0 && device_id < count, TM_ERR_INVALID, "tm_ctx_create: bad device id");
+    TM_HIP_CHECK(hipSetDevice(device_id));
+    tm_ctx* c = new tm_ctx();
+    c->device = device_id;
+    TM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TM_HIP_CHECK(hipEventCreate(&c->ev0));
+    TM_HIP_CHECK(hipEventCreate(&c->ev1));
+    TM_FORWARD(c->stats.alloc(16));
+    *out = c;
+    return TM_OK;
+}
+
+int tm_ctx_destroy(tm_ctx* c) {
+    if (!c) return TM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->scratch.release();
+    c->stats.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TM_OK;
+}
+
+int tm_ctx_synchronize(tm_ctx* c) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
+void* tm_ctx_stream(tm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int tm_device_alloc(tm_ctx* c, uint64_t bytes, void** d_ptr) {
+    TM_REQUIRE(c && d_ptr, TM_ERR_INVALID, "tm_device_alloc: null argument");
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return TM_OK;
+}
+int tm_device_free(tm_ctx* c, void* d_ptr) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    if (d_ptr) TM_HIP_CHECK(hipFree(d_ptr));
+    return TM_OK;
+}
+int tm_memcpy_h2d(tm_ctx* c, void* d_dst, const void* src, uint64_t bytes) {
+    TM_REQUIRE(c && d_dst && src, TM_ERR_INVALID, "tm_memcpy_h2d: null argument");
+    TM_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+int tm_memcpy_d2h(tm_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
+    TM_REQUIRE(c && dst && d_src, TM_ERR_INVALID, "tm_memcpy_d2h: null argument");
+    TM_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
+int tm_ctx_enable_timing(tm_ctx* c, int on) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    c->timing = on != 0;
+    return TM_OK;
+}
+int tm_ctx_last_score_timing(tm_ctx* c, float* ms, uint64_t* evaluations, uint64_t* passing,
+                             uint64_t* hypotheses) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    if (ms) *ms = c->last.ms;
+    if (evaluations) *evaluations = c->last.evaluations;
+    if (passing) *passing = c->last.passing;
+    if (hypotheses) *hypotheses = c->last.hypotheses;
+    return TM_OK;
+}
+
+/* ---- host scalar API ---- */
+uint32_t tm_murmur3_32(const uint32_t* words, int n_words, uint32_t seed) {
+    return murmur_words(words, n_words, seed);
+}
+uint32_t tm_hash_key(const uint32_t* key, int dim) { return murmur_words(key, dim, kMurmurSeed); }
+uint32_t tm_discretize_range(float v, float lo, float span, uint32_t steps) {
+    return quantize_range(v, lo, span, steps);
+}
+uint32_t tm_discretize_step(float v, float step) { return quantize_step(v, step); }
+float tm_atan2f(float y, float x) { return atan2_def(y, x); }
+
+void tm_feature(const float* s0, const float* s1, float out[4]) {
+    feat4 f = pair_feature(make3(s0[0], s0[1], s0[2]), make3(s0[9], s0[10], s0[11]),
+                           make3(s1[0], s1[1], s1[2]), make3(s1[9], s1[10], s1[11]));
+    out[0] = f.f0;
+    out[1] = f.f1;
+    out[2] = f.f2;
+    out[3] = f.f3;
+}
+void tm_discretize_feature(const float f[4], const float bmin[4], const float bmax[4],
+                           float distance_step_count, float angle_step, uint32_t key[4]) {
+    feat4 ff = {f[0], f[1], f[2], f[3]};
+    key4 k = feature_key(ff, bmin[0], bmax[0], (uint32_t)distance_step_count, angle_step);
+    key[0] = k.k0;
+    key[1] = k.k1;
+    key[2] = k.k2;
+    key[3] = k.k3;
+}
+int tm_valid(const float f[4], const float bmin[4], const float bmax[4]) {
+    feat4 ff = {f[0], f[1], f[2], f[3]};
+    return feature_valid(ff, bmin[0], bmax[0]) ? 1 : 0;
+}
+void tm_valid_bounds(const float bmin[4], const float bmax[4], float min_rel, float max_rel,
+                     float out_min[4], float out_max[4]) {
+    for (int d = 0; d < 4; ++d) {
+        out_min[d] = bmin[d];
+        out_max[d] = bmax[d];
+    }
+    float s0 = bmax[0] - bmin[0], s3 = bmax[3] - bmin[3];
+    out_min[0] = bmin[0] + min_rel * s0;
+    out_max[0] = bmin[0] + max_rel * s0;
+    out_min[3] = bmin[3] + min_rel * s3;
+    out_max[3] = bmin[3] + max_rel * s3;
+}
+void tm_base_transform(const float si[3], const float sj[3], const float st[3], const float ti[3],
+                       const float tj[3], const float tt[3], float pose16[16]) {
+    base_transform(make3(si[0], si[1], si[2]), make3(sj[0], sj[1], sj[2]), make3(st[0], st[1], st[2]),
+                   make3(ti[0], ti[1], ti[2]), make3(tj[0], tj[1], tj[2]), make3(tt[0], tt[1], tt[2]),
+                   pose16);
+}
+uint32_t tm_early_drop_upper(uint32_t tried, uint32_t subset_size, uint32_t corrs) {
+    return early_drop_upper(tried, subset_size, corrs);
+}
+
+int tm_features_batch(tm_ctx* c, const float* surfels, uint32_t n_points, const uint32_t* ab_pairs,
+                      uint32_t n_pairs, const float bmin[4], const float bmax[4],
+                      float distance_step_count, float angle_step, float* features4,
+                      uint32_t* keys4, uint32_t* hashes) {
+    TM_REQUIRE(c && surfels && ab_pairs && features4, TM_ERR_INVALID, "tm_features_batch: null argument");
+    if (n_pairs == 0) return TM_OK;
+    for (uint32_t i = 0; i < 2 * n_pairs; ++i)
+        TM_REQUIRE(ab_pairs[i] < n_points, TM_ERR_INVALID, "tm_features_batch: index out of range");
+    int have_bounds = (bmin && bmax && keys4 && hashes) ? 1 : 0;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    dbuf<float> d_s;
+    dbuf<uint2> d_ab;
+    dbuf<float4> d_f;
+    dbuf<uint4> d_k;
+    dbuf<uint32_t> d_h;
+    int rc = TM_OK;
+    auto cleanup = [&]() {
+        d_s.release();
+        d_ab.release();
+        d_f.release();
+        d_k.release();
+        d_h.release();
+    };
+    if ((rc = d_s.alloc((size_t)n_points * 12)) || (rc = d_ab.alloc(n_pairs)) ||
+        (rc = d_f.alloc(n_pairs)) || (rc = d_k.alloc(n_pairs)) || (rc = d_h.alloc(n_pairs))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e;
+    e = hipMemcpyAsync(d_s.p, surfels, (size_t)n_points * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_ab.p, ab_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_features_batch, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream,
+                           d_s.p, d_ab.p, n_pairs, have_bounds, have_bounds ? bmin[0] : 0.f,
+                           have_bounds ? bmax[0] : 0.f, (uint32_t)distance_step_count, angle_step,
+                           d_f.p, d_k.p, d_h.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(features4, d_f.p, (size_t)n_pairs * 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && have_bounds) {
+        e = hipMemcpyAsync(keys4, d_k.p, (size_t)n_pairs * 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(hashes, d_h.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_features_batch: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
+/* deterministic order: inlier count desc, score desc, hypothesis id asc */
+int tm_best_select(const tm_best_record* records, uint32_t n, tm_best_record* best) {
+    TM_REQUIRE(records && best, TM_ERR_INVALID, "tm_best_select: null argument");
+    tm_best_record b;
+    memset(&b, 0, sizeof(b));
+    b.hyp_id = 0xFFFFFFFFu;
+    bool have = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const tm_best_record& r = records[i];
+        if (r.hyp_id == 0xFFFFFFFFu) continue;
+        bool better = !have || r.inlier_count > b.inlier_count ||
+                      (r.inlier_count == b.inlier_count &&
+                       (r.score > b.score || (r.score == b.score && r.hyp_id < b.hyp_id)));
+        if (better) {
+            b = r;
+            have = true;
+        }
+    }
+    *best = b;
+    return TM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,286 @@
+/*
+ * tm_earlydrop.hip — project_ WITH its early-drop rule (reference include/impl/scene.hpp:420-426,
+ * 492-506), evaluated exactly for a batch of poses.
+ *
+ * The rule is sequential in the subset's scan order: checkpoint k is tested at the first unmasked,
+ * in-grid point whose 1-based position is >= tests[k] (points that `continue` at :434 / :458-460
+ * bypass the test), with the correspondence count up to and including that point. Three passes:
+ *   1. k_ed_bits   one thread per (position, hypothesis): in-grid bit and correspondence bit,
+ *                  packed with a wave ballot into 64-bit words (scan order = bit order);
+ *   2. k_ed_walk   one wave per hypothesis walks the words, finds each checkpoint's test position
+ *                  and applies the hypergeometric bound (SURVEY Q8 positive form);
+ *   3. k_ed_score  score terms of the correspondences up to the stop position.
+ * This reproduces the reference's outcome (count, dropped checkpoint, saved, score); it is the parity
+ * path for "early-drop as shipped", not a work-saving prefilter.
+ */
+#include <cstring>
+
+#include "tm_score.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace tmx {
+
+struct ed_args {
+    score_args sc;           /* sref = scene oref (original order) */
+    const float4* opos;      /* original order positions */
+    const float4* otan;      /* .w = mask */
+    const int32_t* subset;   /* scan order, or null = identity */
+    uint32_t S;
+    uint32_t words;          /* ceil(S / 64) */
+    uint32_t h0;             /* first hypothesis of this chunk */
+    unsigned long long* tail_bits;
+    unsigned long long* corr_bits;
+};
+
+__global__ __launch_bounds__(256) void k_ed_bits(ed_args a) {
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t hl = blockIdx.y;
+    bool tail = false;
+    uint32_t corr = 0;
+    if (pos < a.S) {
+        uint32_t idx = a.subset ? (uint32_t)a.subset[pos] : pos;
+        float4 P = a.opos[idx];
+        if (a.otan[idx].w == 0.f) { /* mask_, reference :434 */
+            const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+            long long fx = 0;
+            uint32_t pass = 0;
+            corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, &tail);
+        }
+    }
+    unsigned long long tb = __ballot(tail);
+    unsigned long long cb = __ballot(corr != 0);
+    if ((threadIdx.x & 63) == 0 && pos < a.S) {
+        a.tail_bits[(size_t)hl * a.words + pos / 64] = tb;
+        a.corr_bits[(size_t)hl * a.words + pos / 64] = cb;
+    }
+}
+
+struct ed_out {
+    uint32_t* counts;
+    int32_t* dropped_at;
+    uint32_t* saved;
+    uint32_t* limit; /* last position whose score term counts, or 0xFFFFFFFF for none */
+};
+
+__global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accept_thresh,
+                                                const uint32_t* __restrict__ tests) {
+    const uint32_t hl = blockIdx.x, lane = threadIdx.x;
+    const unsigned long long* tb = a.tail_bits + (size_t)hl * a.words;
+    const unsigned long long* cb = a.corr_bits + (size_t)hl * a.words;
+    uint32_t k = 0;           /* next_test */
+    uint32_t min_pos = 0;     /* earliest 0-based position the next test may run at */
+    if (tests[0] > 0) min_pos = tests[0] - 1;
+    uint32_t corr_before = 0; /* correspondences in the words before this chunk */
+    int32_t dropped = -1;
+    uint32_t drop_count = 0, drop_pos = 0;
+    for (uint32_t w0 = 0; w0 < a.words && dropped < 0; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        const unsigned long long tword = w < a.words ? tb[w] : 0ull;
+        const unsigned long long cword = w < a.words ? cb[w] : 0ull;
+        /* inclusive prefix of popcounts over lanes */
+        uint32_t pc = (uint32_t)__popcll(cword);
+        uint32_t incl = pc;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        const uint32_t chunk_end = (w0 + 64) * 64; /* exclusive, in positions */
+        while (k < 18 && min_pos < chunk_end) {
+            unsigned long long bits = tword;
+            const uint32_t wbase = w * 64;
+            if (min_pos >= wbase + 64)
+                bits = 0ull;
+            else if (min_pos > wbase)
+                bits &= ~0ull << (min_pos - wbase);
+            unsigned long long have = __ballot(bits != 0ull);
+            if (!have) break; /* no test point left in this chunk */
+            const int L = __ffsll((long long)have) - 1;
+            const unsigned long long lbits = __shfl(bits, L);
+            const unsigned long long lcorr = __shfl(cword, L);
+            const uint32_t lincl = __shfl(incl, L);
+            const uint32_t lpc = __shfl(pc, L);
+            const int b = __ffsll((long long)lbits) - 1;
+            const uint32_t pos = (w0 + (uint32_t)L) * 64 + (uint32_t)b;
+            const unsigned long long upto = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
+            const uint32_t corrs = corr_before + (lincl - lpc) + (uint32_t)__popcll(lcorr & upto);
+            const uint32_t tried = pos + 1;
+            const uint32_t upper = early_drop_upper(tried, a.S, corrs);
+            if ((float)upper < accept_thresh) { /* reference :500 */
+                dropped = (int32_t)k;
+                drop_count = corrs;
+                drop_pos = pos;
+                break;
+            }
+            ++k;
+            min_pos = pos + 1;
+            if (k < 18 && tests[k] > 0 && tests[k] - 1 > min_pos) min_pos = tests[k] - 1;
+        }
+        corr_before += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+        if (dropped >= 0) {
+            o.counts[a.h0 + hl] = drop_count;
+            o.dropped_at[a.h0 + hl] = dropped;
+            o.saved[a.h0 + hl] = a.S - (drop_pos + 1);
+            o.limit[a.h0 + hl] = drop_pos;
+        } else {
+            o.counts[a.h0 + hl] = corr_before;
+            o.dropped_at[a.h0 + hl] = -1;
+            o.saved[a.h0 + hl] = 0;
+            o.limit[a.h0 + hl] = a.S ? a.S - 1 : 0xFFFFFFFFu;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ed_score(ed_args a, const uint32_t* __restrict__ limit) {
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t hl = blockIdx.y;
+    long long fx = 0;
+    if (pos < a.S) {
+        const uint32_t lim = limit[a.h0 + hl];
+        const unsigned long long cw = a.corr_bits[(size_t)hl * a.words + pos / 64];
+        if (lim != 0xFFFFFFFFu && pos <= lim && ((cw >> (pos & 63)) & 1ull)) {
+            uint32_t idx = a.subset ? (uint32_t)a.subset[pos] : pos;
+            float4 P = a.opos[idx];
+            const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+            uint32_t pass = 0;
+            (void)eval_point(a.sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) fx += __shfl_down(fx, off);
+    if ((threadIdx.x & 63) == 0 && fx) atomicAdd(&a.sc.scores_fx[a.h0 + hl], (unsigned long long)fx);
+}
+
+}  // namespace tmx
+
+using namespace tmx;
+
+extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const float* poses16,
+                                              uint32_t n_hyp, const int32_t* subset, uint32_t n_subset,
+                                              float dist_thres, float accept_prob, uint32_t* counts,
+                                              double* scores, int32_t* dropped_at, uint32_t* saved) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(counts && scores && dropped_at && saved, TM_ERR_INVALID, "null outputs");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(poses16, TM_ERR_INVALID, "null poses");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t S = subset ? n_subset : s->n;
+    if (subset)
+        for (uint32_t k = 0; k < n_subset; ++k)
+            TM_REQUIRE(subset[k] >= 0 && (uint32_t)subset[k] < s->n, TM_ERR_INVALID,
+                       "subset index out of range");
+    if (S == 0) {
+        for (uint32_t h = 0; h < n_hyp; ++h) {
+            counts[h] = 0;
+            scores[h] = 0.0;
+            dropped_at[h] = -1;
+            saved[h] = 0;
+        }
+        return TM_OK;
+    }
+    /* checkpoints: tests[i] = (uint32)(0.05f * (i + 1) * |subset|), reference :422-426 */
+    uint32_t tests[18];
+    {
+        constexpr float step_size = 0.05f;
+        for (uint32_t i = 0; i < 18; ++i) tests[i] = (uint32_t)(step_size * (i + 1) * S);
+    }
+    const uint32_t words = (S + 63) / 64;
+    const uint64_t budget = 256ull << 20; /* bytes per bit array */
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_hyp, budget / ((uint64_t)words * 8)));
+    chunk = std::min(chunk, 65535u);
+    dbuf<float> d_poses;
+    dbuf<int32_t> d_subset, d_dropped;
+    dbuf<uint32_t> d_tests, d_counts, d_saved, d_limit;
+    dbuf<unsigned long long> d_tail, d_corr, d_fx;
+    int rc = TM_OK;
+    auto cleanup = [&]() {
+        d_poses.release();
+        d_subset.release();
+        d_dropped.release();
+        d_tests.release();
+        d_counts.release();
+        d_saved.release();
+        d_limit.release();
+        d_tail.release();
+        d_corr.release();
+        d_fx.release();
+    };
+    if ((rc = d_poses.alloc((size_t)n_hyp * 16)) || (rc = d_tests.alloc(18)) || (rc = d_counts.alloc(n_hyp)) ||
+        (rc = d_saved.alloc(n_hyp)) || (rc = d_limit.alloc(n_hyp)) || (rc = d_dropped.alloc(n_hyp)) ||
+        (rc = d_fx.alloc(n_hyp)) || (rc = d_tail.alloc((size_t)chunk * words)) ||
+        (rc = d_corr.alloc((size_t)chunk * words)) || (subset && (rc = d_subset.alloc(S)))) {
+        cleanup();
+        return rc;
+    }
+#define ED_HIP(expr)                                                      \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) {                                           \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));     \
+            cleanup();                                                    \
+            return TM_ERR_HIP;                                            \
+        }                                                                 \
+    } while (0)
+    ED_HIP(hipMemcpyAsync(d_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    ED_HIP(hipMemcpyAsync(d_tests.p, tests, sizeof(tests), hipMemcpyHostToDevice, c->stream));
+    if (subset) ED_HIP(hipMemcpyAsync(d_subset.p, subset, (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
+    ED_HIP(hipMemsetAsync(d_fx.p, 0, (size_t)n_hyp * 8, c->stream));
+    ed_args a;
+    a.sc.spos = nullptr;
+    a.sc.sref = s->oref.p;
+    a.sc.mpos = m->pos.p;
+    a.sc.mref = m->ref.p;
+    a.sc.vox = m->voxels.p;
+    a.sc.active = nullptr;
+    a.sc.poses = d_poses.p;
+    a.sc.counts = d_counts.p;
+    a.sc.scores_fx = d_fx.p;
+    a.sc.stats = c->stats.p;
+    a.sc.g = m->grid;
+    a.sc.d2max = sq_threshold(dist_thres * m->resolution);
+    a.sc.n_hyp = n_hyp;
+    a.sc.hyp_per_block = 1;
+    a.opos = s->opos.p;
+    a.otan = s->otan.p;
+    a.subset = subset ? d_subset.p : nullptr;
+    a.S = S;
+    a.words = words;
+    a.tail_bits = d_tail.p;
+    a.corr_bits = d_corr.p;
+    ed_out o;
+    o.counts = d_counts.p;
+    o.dropped_at = d_dropped.p;
+    o.saved = d_saved.p;
+    o.limit = d_limit.p;
+    const float accept_thresh = accept_prob * (float)m->n; /* accept_prob * size() in float */
+    for (uint32_t h0 = 0; h0 < n_hyp; h0 += chunk) {
+        const uint32_t nh = std::min(chunk, n_hyp - h0);
+        a.h0 = h0;
+        dim3 grid((S + 255) / 256, nh);
+        hipLaunchKernelGGL(k_ed_bits, grid, dim3(256), 0, c->stream, a);
+        ED_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ed_walk, dim3(nh), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests.p);
+        ED_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_ed_score, grid, dim3(256), 0, c->stream, a, d_limit.p);
+        ED_HIP(hipGetLastError());
+    }
+    std::vector<unsigned long long> fx(n_hyp);
+    ED_HIP(hipMemcpyAsync(counts, d_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    ED_HIP(hipMemcpyAsync(saved, d_saved.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    ED_HIP(hipMemcpyAsync(dropped_at, d_dropped.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    ED_HIP(hipMemcpyAsync(fx.data(), d_fx.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream));
+    ED_HIP(hipStreamSynchronize(c->stream));
+#undef ED_HIP
+    cleanup();
+    for (uint32_t h = 0; h < n_hyp; ++h) {
+        double raw = (double)fx[h] * (1.0 / kFx);
+        /* a dropped pass returns the raw partial sum (:502), a completed one the normalised (:509) */
+        scores[h] = dropped_at[h] >= 0 ? raw : raw / (double)m->n;
+    }
+    return TM_OK;
+}

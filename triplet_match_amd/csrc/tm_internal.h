@@ -1,0 +1,153 @@
+/* tm_internal.h — handles, error plumbing and device buffers shared by the .hip translation units. */
+#ifndef TM_INTERNAL_H_
+#define TM_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tm_hip.h"
+#include "tm_math.h"
+
+namespace tmx {
+
+void set_error(const char* fmt, ...);
+
+#define TM_HIP_CHECK(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            tmx::set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__,                  \
+                          hipGetErrorString(_e));                                              \
+            return TM_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define TM_REQUIRE(cond, code, msg)  \
+    do {                             \
+        if (!(cond)) {               \
+            tmx::set_error("%s", msg); \
+            return code;             \
+        }                            \
+    } while (0)
+
+#define TM_FORWARD(expr)          \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != TM_OK) return _rc; \
+    } while (0)
+
+/* RAII-less device buffer (freed explicitly by the owner's destroy) */
+template <typename T>
+struct dbuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return TM_ERR_HIP;
+        }
+        n = count;
+        return TM_OK;
+    }
+    int ensure(size_t count) { return (count <= n && p) ? TM_OK : alloc(count); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct score_timing {
+    float ms = 0.f;
+    uint64_t evaluations = 0, passing = 0, hypotheses = 0;
+};
+
+}  // namespace tmx
+
+struct tm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    tmx::score_timing last;
+    tmx::dbuf<unsigned char> scratch;   /* rocprim temp storage */
+    tmx::dbuf<unsigned long long> stats; /* device counters */
+};
+
+struct tm_model {
+    tm_ctx* ctx = nullptr;
+    uint32_t n = 0;
+    float resolution = 0.f;
+    float distance_step_count = 0.f, angle_step = 0.f;
+    std::vector<float> h_cloud; /* n*12 host copy (host-side query helpers) */
+    /* geometry */
+    bool grid_ready = false, voxels_ready = false, pairs_ready = false;
+    float diameter = 0.f;
+    float bbmin[3], bbmax[3];
+    int extents[3] = {0, 0, 0};
+    float to_voxel[16];
+    tmx::grid_t grid;
+    /* device SoA */
+    tmx::dbuf<float4> pos;  /* xyz, w = (|tangent| > 0.7) ? 1 : 0 ; non-finite points keep NaN */
+    tmx::dbuf<float4> ref;  /* tangent if is_tangent else normal */
+    tmx::dbuf<float4> tan4; /* raw tangent xyz (pair build / hypothesis generation) */
+    tmx::dbuf<uint32_t> voxels;
+    uint64_t voxel_count = 0;
+    /* pair table */
+    std::vector<uint32_t> subset;
+    float bmin[4], bmax[4];
+    uint64_t n_entries = 0, n_valid = 0;
+    uint32_t n_keys = 0;
+    uint32_t r1 = 0, r2 = 0;            /* packing radices of k1, k2 */
+    tmx::dbuf<uint32_t> seg_key;          /* packed key per distinct key (ascending) */
+    tmx::dbuf<uint32_t> seg_begin;        /* n_keys + 1 */
+    tmx::dbuf<uint2> entries;             /* (i,j) model indices, canonical order inside a segment */
+    tmx::dbuf<uint32_t> ht_slot;          /* open addressing: segment index + 1, 0 = empty */
+    tmx::dbuf<uint4> ht_key;              /* key stored in the slot */
+    uint32_t ht_cap = 0;                 /* power of two */
+    /* host mirrors for tm_model_query */
+    std::vector<uint32_t> h_seg_key, h_seg_begin;
+    std::vector<uint32_t> h_voxels_cache; /* lazily downloaded for tm_model_voxel_query */
+};
+
+struct tm_scene {
+    tm_ctx* ctx = nullptr;
+    uint32_t n = 0;
+    std::vector<float> h_cloud;
+    std::vector<int32_t> h_tmask, h_mask;
+    /* original order (hypothesis generation addresses points by original index) */
+    tmx::dbuf<float4> opos;  /* xyz, w = tangent_mask ? 1 : 0 */
+    tmx::dbuf<float4> otan;  /* raw tangent xyz, w = masked ? 1 : 0 */
+    tmx::dbuf<float4> oref;  /* tangent if tangent_mask else normal, w = tangent_mask */
+    /* cell-sorted order (scoring) */
+    float cell = 0.f;            /* current grid cell size, 0 = not built */
+    float gmin[3];               /* grid origin */
+    int gdim[3] = {0, 0, 0};
+    tmx::dbuf<float4> spos;       /* sorted xyz (masked / padding -> NaN), w = bits of original index */
+    tmx::dbuf<float4> sref;       /* sorted ref (tangent or normal), w = tangent_mask ? 1 : 0 */
+    tmx::dbuf<uint32_t> perm;     /* sorted -> original */
+    tmx::dbuf<uint32_t> cell_start; /* gdim product + 1 */
+    uint32_t n_sorted = 0;       /* finite points */
+    /* work buffers reused across calls */
+    tmx::dbuf<float> w_poses;
+    tmx::dbuf<uint32_t> w_counts;
+    tmx::dbuf<unsigned long long> w_scores_fx;
+    tmx::dbuf<double> w_scores;
+    tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
+    tmx::dbuf<uint2> w_pairs;
+};
+
+namespace tmx {
+int scratch_ensure(tm_ctx* ctx, size_t bytes);
+}
+
+#endif /* TM_INTERNAL_H_ */

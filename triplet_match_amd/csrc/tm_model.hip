@@ -1,0 +1,739 @@
+/*
+ * tm_model.hip — model side of the hot path: voxel NN grid (a6), pair enumeration + key table (a7),
+ * query (a8) and voxel_query (a9). Replaces model<Point>::impl (reference include/impl/model.hpp).
+ *
+ * HBM layout: pos[n] float4 (xyz, w = 1 if |tangent| > 0.7), ref[n] float4 (tangent or normal),
+ * tan4[n] float4 (raw tangent); voxels[ex*ey*ez] u32 (x fastest, reference :83); the pair table as a
+ * CSR sorted by key: seg_key[n_keys] (packed key), seg_begin[n_keys+1], entries[] (i,j), plus an
+ * open-addressing index keyed by MurmurHash3(key, seed 42) for the device-side probe.
+ */
+#include <cstring>
+
+#include "tm_internal.h"
+#include "tm_table.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace tmx {
+
+static inline bool fin3(const float* p) {
+    return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a6 — voxel NN grid. One thread owns VPT voxels; the cloud streams through LDS in tiles and every
+ * thread scans the tile (broadcast reads), keeping the strict minimum => lowest index on ties.
+ * Compute-bound brute force: 11 VALU ops per (voxel, point).
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kVoxTile = 2048; /* points per LDS tile: 32 KiB */
+constexpr int kVoxVPT = 4;     /* voxels per thread */
+
+__global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos, uint32_t n,
+                                                  grid_t g, uint64_t voxel_count,
+                                                  uint32_t* __restrict__ voxels) {
+    __shared__ float4 tile[kVoxTile];
+    float qx[kVoxVPT], qy[kVoxVPT], qz[kVoxVPT], best[kVoxVPT];
+    uint32_t besti[kVoxVPT];
+    const uint64_t base = (uint64_t)blockIdx.x * (256 * kVoxVPT);
+    const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
+    const float itx = -(g.tx * isx), ity = -(g.ty * isy), itz = -(g.tz * isz);
+    const uint64_t exy = (uint64_t)g.ex * g.ey;
+#pragma unroll
+    for (int v = 0; v < kVoxVPT; ++v) {
+        uint64_t lin = base + (uint64_t)v * 256 + threadIdx.x;
+        uint64_t l = lin < voxel_count ? lin : 0;
+        uint32_t k = (uint32_t)(l / exy);
+        uint32_t r = (uint32_t)(l - (uint64_t)k * exy);
+        uint32_t j = r / (uint32_t)g.ex;
+        uint32_t i = r - j * (uint32_t)g.ex;
+        qx[v] = isx * (float)i + itx;
+        qy[v] = isy * (float)j + ity;
+        qz[v] = isz * (float)k + itz;
+        best[v] = __builtin_inff();
+        besti[v] = 0xFFFFFFFFu;
+    }
+    for (uint32_t t0 = 0; t0 < n; t0 += kVoxTile) {
+        __syncthreads();
+        for (int s = threadIdx.x; s < kVoxTile; s += 256) {
+            uint32_t p = t0 + s;
+            tile[s] = p < n ? pos[p] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const int cnt = min((uint32_t)kVoxTile, n - t0);
+        for (int s = 0; s < cnt; ++s) {
+            float4 p = tile[s];
+#pragma unroll
+            for (int v = 0; v < kVoxVPT; ++v) {
+                float dx = p.x - qx[v], dy = p.y - qy[v], dz = p.z - qz[v];
+                float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 < best[v]) { /* NaN (non-finite point) never wins */
+                    best[v] = d2;
+                    besti[v] = t0 + s;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < kVoxVPT; ++v) {
+        uint64_t lin = base + (uint64_t)v * 256 + threadIdx.x;
+        if (lin < voxel_count) voxels[lin] = besti[v];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a7 — pair enumeration. Ordered pairs (a,b) of subset positions, a-major (reference :100).
+ * Thread = one `a`; the b side streams through LDS in chunks.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kPairChunk = 1024;
+
+struct pair_params {
+    float lower, upper;      /* diameter * {min,max}_diameter_factor (unsquared, reference :101-102) */
+    float lo0, hi0;          /* feature bounds dim 0 (pass 2) */
+    uint32_t steps;
+    float angle_step;
+    uint32_t r1, r2;
+    uint32_t n_t;
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o) {
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(b);
+#else
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+#endif
+}
+
+/* reference include/impl/model.hpp:104-111 (same in pass 2, :126-132) */
+__device__ __forceinline__ bool pair_filter(f3 pi, f3 ti, f3 pj, float lower, float upper) {
+    f3 d = pj - pi;
+    float dist = len(d);
+    d = over(d, dist);
+    if (dist < lower || dist > upper) return false;
+    if (1.f - fabsf(dot3(d, ti)) < 0.01f) return false;
+    return true;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_pairs(const float4* __restrict__ pos,
+                                               const float4* __restrict__ tan4,
+                                               const uint32_t* __restrict__ subset, pair_params pp,
+                                               uint32_t* __restrict__ bounds_ord /* 8: min4,max4 */,
+                                               unsigned long long* __restrict__ counter,
+                                               unsigned long long* __restrict__ sort_keys,
+                                               unsigned long long cap) {
+    __shared__ float4 sp[kPairChunk];
+    __shared__ float4 st[kPairChunk];
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b0 = blockIdx.y * kPairChunk;
+    const bool live = a < pp.n_t;
+    f3 pi = make3(0, 0, 0), ti = make3(0, 0, 0);
+    uint32_t ia = 0xFFFFFFFFu;
+    if (live) {
+        ia = subset[a];
+        float4 P = pos[ia], T = tan4[ia];
+        pi = make3(P.x, P.y, P.z);
+        ti = make3(T.x, T.y, T.z);
+    }
+    for (int s = threadIdx.x; s < kPairChunk; s += 256) {
+        uint32_t b = b0 + s;
+        if (b < pp.n_t) {
+            uint32_t ib = subset[b];
+            float4 P = pos[ib];
+            P.w = __uint_as_float(ib);
+            sp[s] = P;
+            st[s] = tan4[ib];
+        }
+    }
+    __syncthreads();
+    const int cnt = (int)min((uint32_t)kPairChunk, pp.n_t > b0 ? pp.n_t - b0 : 0u);
+    float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    uint32_t nvalid = 0;
+    if (live) {
+        for (int s = 0; s < cnt; ++s) {
+            float4 P = sp[s];
+            uint32_t ib = __float_as_uint(P.w);
+            if (ib == ia) continue; /* reference :104 compares the point indices */
+            f3 pj = make3(P.x, P.y, P.z);
+            if (!pair_filter(pi, ti, pj, pp.lower, pp.upper)) continue;
+            float4 T = st[s];
+            feat4 f = pair_feature(pi, ti, pj, make3(T.x, T.y, T.z));
+            if (!EMIT) {
+                mn[0] = fminf(mn[0], f.f0);
+                mx[0] = fmaxf(mx[0], f.f0);
+                mn[1] = fminf(mn[1], f.f1);
+                mx[1] = fmaxf(mx[1], f.f1);
+                mn[2] = fminf(mn[2], f.f2);
+                mx[2] = fmaxf(mx[2], f.f2);
+                mn[3] = fminf(mn[3], f.f3);
+                mx[3] = fmaxf(mx[3], f.f3);
+                ++nvalid;
+            } else {
+                if (!feature_valid(f, pp.lo0, pp.hi0)) continue;
+                key4 k = feature_key(f, pp.lo0, pp.hi0, pp.steps, pp.angle_step);
+                uint32_t packed = (k.k0 * pp.r1 + k.k1) * pp.r2 + k.k2;
+                uint32_t rank = a * pp.n_t + (b0 + (uint32_t)s);
+                unsigned long long slot = atomicAdd(counter, 1ull);
+                if (slot < cap)
+                    sort_keys[slot] = ((unsigned long long)packed << 32) | (0xFFFFFFFFu - rank);
+            }
+        }
+    }
+    if (!EMIT) {
+        /* wave reduce, then one atomic per wave and bound */
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            for (int off = 32; off > 0; off >>= 1) {
+                mn[d] = fminf(mn[d], __shfl_down(mn[d], off));
+                mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off));
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_down(nvalid, off);
+        if ((threadIdx.x & 63) == 0 && nvalid) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                atomicMin(&bounds_ord[d], f2ord(mn[d]));
+                atomicMax(&bounds_ord[4 + d], f2ord(mx[d]));
+            }
+            atomicAdd(counter, (unsigned long long)nvalid);
+        }
+    }
+}
+
+__global__ void k_mark_heads(const unsigned long long* __restrict__ keys, uint32_t n,
+                             uint32_t* __restrict__ flags) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t hi = (uint32_t)(keys[t] >> 32);
+    flags[t] = (t == 0 || hi != (uint32_t)(keys[t - 1] >> 32)) ? 1u : 0u;
+}
+
+__global__ void k_fill_segments(const unsigned long long* __restrict__ keys,
+                                const uint32_t* __restrict__ flags,
+                                const uint32_t* __restrict__ seg_of, uint32_t n, uint32_t n_t,
+                                const uint32_t* __restrict__ subset, uint32_t* __restrict__ seg_key,
+                                uint32_t* __restrict__ seg_begin, uint2* __restrict__ entries) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    unsigned long long k = keys[t];
+    uint32_t rank = 0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull);
+    uint32_t a = rank / n_t, b = rank - a * n_t;
+    entries[t] = make_uint2(subset[a], subset[b]);
+    if (flags[t]) {
+        uint32_t s = seg_of[t];
+        seg_key[s] = (uint32_t)(k >> 32);
+        seg_begin[s] = t;
+    }
+}
+
+__device__ __forceinline__ uint4 unpack_key(uint32_t packed, uint32_t r1, uint32_t r2) {
+    uint32_t k2 = packed % r2;
+    uint32_t q = packed / r2;
+    uint32_t k1 = q % r1;
+    uint32_t k0 = q / r1;
+    return make_uint4(k0, k1, k2, k0);
+}
+
+__global__ void k_ht_insert(const uint32_t* __restrict__ seg_key, uint32_t n_keys, uint32_t r1,
+                            uint32_t r2, uint32_t* __restrict__ ht_slot, uint4* __restrict__ ht_key,
+                            uint32_t cap_mask) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_keys) return;
+    uint4 k = unpack_key(seg_key[s], r1, r2);
+    uint32_t h = murmur_key4(k.x, k.y, k.z, k.w) & cap_mask;
+    for (;;) { /* table is at most half full: terminates */
+        uint32_t prev = atomicCAS(&ht_slot[h], 0u, s + 1u);
+        if (prev == 0u) {
+            ht_key[h] = k;
+            return;
+        }
+        h = (h + 1u) & cap_mask;
+    }
+}
+
+__global__ void k_query_one(const uint32_t* __restrict__ ht_slot, const uint4* __restrict__ ht_key,
+                            uint32_t cap_mask, const uint32_t* __restrict__ seg_begin, uint4 key,
+                            uint32_t* __restrict__ out /* begin, count */) {
+    key4 k = {key.x, key.y, key.z, key.w};
+    uint32_t s = ht_find(ht_slot, ht_key, cap_mask, k);
+    if (s == 0xFFFFFFFFu) {
+        out[0] = 0;
+        out[1] = 0;
+    } else {
+        out[0] = seg_begin[s];
+        out[1] = seg_begin[s + 1] - seg_begin[s];
+    }
+}
+
+/* host: bbox / diameter / to_voxel, reference include/impl/model.hpp:24-61 */
+static int setup_grid(tm_model* m) {
+    const float big = std::numeric_limits<float>::max();
+    float mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < m->n; ++i) {
+        const float* s = m->h_cloud.data() + (size_t)i * 12;
+        if (!(fin3(s) && fin3(s + 4) && fin3(s + 9))) continue;
+        ++kept;
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = std::min(mn[d], s[d]);
+            mx[d] = std::max(mx[d], s[d]);
+        }
+    }
+    if (!kept) {
+        set_error("model has no finite point");
+        return TM_ERR_EMPTY;
+    }
+    f3 range = make3(mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]);
+    m->diameter = len(range);
+    const float cell = 0.5f * m->resolution;
+    const float rg[3] = {range.x, range.y, range.z};
+    float ext[3], sc[3];
+    for (int d = 0; d < 3; ++d) {
+        ext[d] = std::max(rg[d] / cell, 1.f);
+        m->extents[d] = (int)(ext[d] + 2.f * (float)TM_VOXEL_MARGIN);
+        sc[d] = rg[d] < 1e-5f ? 1.f : ext[d] / rg[d];
+        m->bbmin[d] = mn[d];
+        m->bbmax[d] = mx[d];
+    }
+    for (int i = 0; i < 16; ++i) m->to_voxel[i] = 0.f;
+    m->to_voxel[0] = sc[0];
+    m->to_voxel[5] = sc[1];
+    m->to_voxel[10] = sc[2];
+    m->to_voxel[15] = 1.f;
+    for (int d = 0; d < 3; ++d) {
+        float t = sc[d] * (-mn[d]) + (float)TM_VOXEL_MARGIN;
+        t -= 0.5f;
+        m->to_voxel[12 + d] = t;
+    }
+    grid_t& g = m->grid;
+    g.sx = sc[0];
+    g.sy = sc[1];
+    g.sz = sc[2];
+    g.tx = m->to_voxel[12];
+    g.ty = m->to_voxel[13];
+    g.tz = m->to_voxel[14];
+    g.ex = m->extents[0];
+    g.ey = m->extents[1];
+    g.ez = m->extents[2];
+    g.fex = (float)g.ex;
+    g.fey = (float)g.ey;
+    g.fez = (float)g.ez;
+    m->grid_ready = true;
+    return TM_OK;
+}
+
+}  // namespace tmx
+
+using namespace tmx;
+
+extern "C" {
+
+int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,
+                    float distance_step_count, float angle_step, tm_model** out) {
+    TM_REQUIRE(ctx && surfels && out, TM_ERR_INVALID, "tm_model_create: null argument");
+    TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_model_create: empty cloud");
+    TM_REQUIRE(resolution > 0.f, TM_ERR_INVALID, "tm_model_create: resolution must be > 0");
+    TM_HIP_CHECK(hipSetDevice(ctx->device));
+    tm_model* m = new tm_model();
+    m->ctx = ctx;
+    m->n = n;
+    m->resolution = resolution;
+    m->distance_step_count = distance_step_count;
+    m->angle_step = angle_step;
+    m->h_cloud.assign(surfels, surfels + (size_t)n * 12);
+    std::vector<float4> pos(n), ref(n), tan4(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* s = surfels + (size_t)i * 12;
+        f3 t = make3(s[9], s[10], s[11]);
+        bool is_t = len(t) > 0.7f; /* reference include/impl/scene.hpp:469-470 */
+        pos[i] = make_float4(s[0], s[1], s[2], is_t ? 1.f : 0.f);
+        if (!fin3(s)) pos[i].x = std::numeric_limits<float>::quiet_NaN();
+        ref[i] = is_t ? make_float4(s[9], s[10], s[11], 0.f) : make_float4(s[4], s[5], s[6], 0.f);
+        tan4[i] = make_float4(s[9], s[10], s[11], 0.f);
+    }
+    int rc;
+    if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n))) {
+        tm_model_destroy(m);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(m->pos.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->ref.p, ref.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->tan4.p, tan4.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_error("tm_model_create: upload failed: %s", hipGetErrorString(e));
+        tm_model_destroy(m);
+        return TM_ERR_HIP;
+    }
+    rc = setup_grid(m);
+    if (rc) {
+        tm_model_destroy(m);
+        return rc;
+    }
+    for (int d = 0; d < 4; ++d) {
+        m->bmin[d] = std::numeric_limits<float>::max();
+        m->bmax[d] = std::numeric_limits<float>::lowest();
+    }
+    *out = m;
+    return TM_OK;
+}
+
+int tm_model_destroy(tm_model* m) {
+    if (!m) return TM_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    m->pos.release();
+    m->ref.release();
+    m->tan4.release();
+    m->voxels.release();
+    m->seg_key.release();
+    m->seg_begin.release();
+    m->entries.release();
+    m->ht_slot.release();
+    m->ht_key.release();
+    delete m;
+    return TM_OK;
+}
+
+int tm_model_build_voxels(tm_model* m) {
+    TM_REQUIRE(m, TM_ERR_INVALID, "null model");
+    TM_REQUIRE(m->grid_ready, TM_ERR_NOT_INITIALIZED, "model grid not set up");
+    tm_ctx* c = m->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    uint64_t count = (uint64_t)m->extents[0] * m->extents[1] * m->extents[2];
+    /* the reference's voxel_count is a uint32_t (include/impl/model.hpp:65) */
+    TM_REQUIRE(count <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid exceeds 2^32 cells");
+    TM_FORWARD(m->voxels.alloc(count));
+    m->voxel_count = count;
+    uint64_t per_block = 256ull * kVoxVPT;
+    uint64_t blocks = (count + per_block - 1) / per_block;
+    TM_REQUIRE(blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
+    hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->pos.p, m->n,
+                       m->grid, count, m->voxels.p);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    m->voxels_ready = true;
+    m->h_voxels_cache.clear();
+    return TM_OK;
+}
+
+int tm_model_build_pairs(tm_model* m, const uint32_t* subset, uint32_t n_t,
+                         float min_diameter_factor, float max_diameter_factor) {
+    TM_REQUIRE(m && subset, TM_ERR_INVALID, "tm_model_build_pairs: null argument");
+    TM_REQUIRE(n_t >= 2, TM_ERR_EMPTY, "tm_model_build_pairs: subset needs at least two points");
+    TM_REQUIRE(n_t < 65536, TM_ERR_UNSUPPORTED, "tm_model_build_pairs: subset >= 65536 points");
+    for (uint32_t i = 0; i < n_t; ++i)
+        TM_REQUIRE(subset[i] < m->n, TM_ERR_INVALID, "tm_model_build_pairs: index out of range");
+    tm_ctx* c = m->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    m->pairs_ready = false;
+    m->subset.assign(subset, subset + n_t);
+
+    /* key packing radices: k0 < steps; angle bins are bounded by pi / angle_step */
+    uint32_t steps = (uint32_t)m->distance_step_count;
+    TM_REQUIRE(steps >= 1 && m->angle_step > 0.f, TM_ERR_UNSUPPORTED,
+               "distance_step_count < 1 or angle_step <= 0 is not supported");
+    double abins = std::floor(3.14159265358979 / (double)m->angle_step) + 2.0;
+    TM_REQUIRE(abins < 65536.0 && (double)steps * abins * abins < 4294967296.0, TM_ERR_UNSUPPORTED,
+               "key space does not pack into 32 bits");
+    pair_params pp;
+    pp.lower = m->diameter * min_diameter_factor;
+    pp.upper = m->diameter * max_diameter_factor;
+    pp.lo0 = pp.hi0 = 0.f;
+    pp.steps = steps;
+    pp.angle_step = m->angle_step;
+    pp.r1 = pp.r2 = (uint32_t)abins;
+    pp.n_t = n_t;
+    m->r1 = pp.r1;
+    m->r2 = pp.r2;
+
+    dbuf<uint32_t> d_subset, d_bounds, d_flags, d_segof;
+    dbuf<unsigned long long> d_counter, d_keys_in, d_keys_out;
+    int rc = TM_OK;
+    auto cleanup = [&]() {
+        d_subset.release();
+        d_bounds.release();
+        d_flags.release();
+        d_segof.release();
+        d_counter.release();
+        d_keys_in.release();
+        d_keys_out.release();
+    };
+#define TM_TRY(expr)      \
+    do {                  \
+        rc = (expr);      \
+        if (rc) {         \
+            cleanup();    \
+            return rc;    \
+        }                 \
+    } while (0)
+#define TM_TRY_HIP(expr)                                                              \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__,            \
+                      hipGetErrorString(_e));                                         \
+            cleanup();                                                                \
+            return TM_ERR_HIP;                                                        \
+        }                                                                             \
+    } while (0)
+
+    TM_TRY(d_subset.alloc(n_t));
+    TM_TRY(d_bounds.alloc(8));
+    TM_TRY(d_counter.alloc(1));
+    TM_TRY_HIP(hipMemcpyAsync(d_subset.p, subset, (size_t)n_t * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t init_bounds[8];
+    for (int d = 0; d < 4; ++d) {
+        init_bounds[d] = 0xFFFFFFFFu;
+        init_bounds[4 + d] = 0u;
+    }
+    TM_TRY_HIP(hipMemcpyAsync(d_bounds.p, init_bounds, 32, hipMemcpyHostToDevice, c->stream));
+    TM_TRY_HIP(hipMemsetAsync(d_counter.p, 0, 8, c->stream));
+    dim3 grid((n_t + 255) / 256, (n_t + kPairChunk - 1) / kPairChunk);
+    /* pass 1: feature bounds over the filtered pairs (reference :103-118) */
+    hipLaunchKernelGGL(k_pairs<false>, grid, dim3(256), 0, c->stream, m->pos.p, m->tan4.p, d_subset.p,
+                       pp, d_bounds.p, d_counter.p, (unsigned long long*)nullptr, 0ull);
+    TM_TRY_HIP(hipGetLastError());
+    uint32_t h_bounds[8];
+    unsigned long long h_valid = 0;
+    TM_TRY_HIP(hipMemcpyAsync(h_bounds, d_bounds.p, 32, hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipMemcpyAsync(&h_valid, d_counter.p, 8, hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipStreamSynchronize(c->stream));
+    m->n_valid = h_valid;
+    if (h_valid == 0) {
+        cleanup();
+        set_error("no valid model pair: the reference dereferences an empty histogram here");
+        return TM_ERR_EMPTY;
+    }
+    float raw_min[4], raw_max[4];
+    for (int d = 0; d < 4; ++d) {
+        raw_min[d] = ord2f(h_bounds[d]);
+        raw_max[d] = ord2f(h_bounds[4 + d]);
+    }
+    /* valid_bounds(bounds, pi/10, 2pi, 0, 1): reference :122 */
+    tm_valid_bounds(raw_min, raw_max, 0.0f, 1.f, m->bmin, m->bmax);
+    pp.lo0 = m->bmin[0];
+    pp.hi0 = m->bmax[0];
+
+    /* pass 2: keys -> (packed key, reverse insertion rank) records, then one global radix sort */
+    TM_TRY(d_keys_in.alloc(h_valid));
+    TM_TRY(d_keys_out.alloc(h_valid));
+    TM_TRY_HIP(hipMemsetAsync(d_counter.p, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_pairs<true>, grid, dim3(256), 0, c->stream, m->pos.p, m->tan4.p, d_subset.p,
+                       pp, d_bounds.p, d_counter.p, d_keys_in.p, (unsigned long long)h_valid);
+    TM_TRY_HIP(hipGetLastError());
+    unsigned long long h_entries = 0;
+    TM_TRY_HIP(hipMemcpyAsync(&h_entries, d_counter.p, 8, hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipStreamSynchronize(c->stream));
+    if (h_entries > h_valid) h_entries = h_valid; /* cannot happen: pass 2 filters are a subset */
+    TM_REQUIRE(h_entries < 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "pair table exceeds 2^32 entries");
+    m->n_entries = h_entries;
+    const uint32_t ne = (uint32_t)h_entries;
+    if (ne == 0) {
+        cleanup();
+        set_error("no valid model pair after bounds check");
+        return TM_ERR_EMPTY;
+    }
+    size_t tmp_bytes = 0;
+    TM_TRY_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys_in.p, d_keys_out.p, (size_t)ne, 0, 64,
+                                        c->stream));
+    TM_TRY(scratch_ensure(c, tmp_bytes));
+    TM_TRY_HIP(rocprim::radix_sort_keys(c->scratch.p, tmp_bytes, d_keys_in.p, d_keys_out.p, (size_t)ne, 0,
+                                        64, c->stream));
+    /* segments */
+    TM_TRY(d_flags.alloc(ne));
+    TM_TRY(d_segof.alloc(ne));
+    hipLaunchKernelGGL(k_mark_heads, dim3((ne + 255) / 256), dim3(256), 0, c->stream, d_keys_out.p, ne,
+                       d_flags.p);
+    TM_TRY_HIP(hipGetLastError());
+    size_t scan_bytes = 0;
+    TM_TRY_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, d_flags.p, d_segof.p, 0u, (size_t)ne,
+                                       rocprim::plus<uint32_t>(), c->stream));
+    TM_TRY(scratch_ensure(c, scan_bytes));
+    TM_TRY_HIP(rocprim::exclusive_scan(c->scratch.p, scan_bytes, d_flags.p, d_segof.p, 0u, (size_t)ne,
+                                       rocprim::plus<uint32_t>(), c->stream));
+    uint32_t last_seg = 0, last_flag = 0;
+    TM_TRY_HIP(hipMemcpyAsync(&last_seg, d_segof.p + (ne - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipMemcpyAsync(&last_flag, d_flags.p + (ne - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t n_keys = last_seg + last_flag;
+    m->n_keys = n_keys;
+    TM_TRY(m->seg_key.alloc(n_keys));
+    TM_TRY(m->seg_begin.alloc((size_t)n_keys + 1));
+    TM_TRY(m->entries.alloc(ne));
+    hipLaunchKernelGGL(k_fill_segments, dim3((ne + 255) / 256), dim3(256), 0, c->stream, d_keys_out.p,
+                       d_flags.p, d_segof.p, ne, n_t, d_subset.p, m->seg_key.p, m->seg_begin.p,
+                       m->entries.p);
+    TM_TRY_HIP(hipGetLastError());
+    TM_TRY_HIP(hipMemcpyAsync(m->seg_begin.p + n_keys, &ne, 4, hipMemcpyHostToDevice, c->stream));
+    /* hash index */
+    uint32_t cap = 64;
+    while (cap < 2u * n_keys) cap <<= 1;
+    m->ht_cap = cap;
+    TM_TRY(m->ht_slot.alloc(cap));
+    TM_TRY(m->ht_key.alloc(cap));
+    TM_TRY_HIP(hipMemsetAsync(m->ht_slot.p, 0, (size_t)cap * 4, c->stream));
+    hipLaunchKernelGGL(k_ht_insert, dim3((n_keys + 255) / 256), dim3(256), 0, c->stream, m->seg_key.p,
+                       n_keys, m->r1, m->r2, m->ht_slot.p, m->ht_key.p, cap - 1);
+    TM_TRY_HIP(hipGetLastError());
+    m->h_seg_key.resize(n_keys);
+    m->h_seg_begin.resize((size_t)n_keys + 1);
+    TM_TRY_HIP(hipMemcpyAsync(m->h_seg_key.data(), m->seg_key.p, (size_t)n_keys * 4, hipMemcpyDeviceToHost,
+                              c->stream));
+    TM_TRY_HIP(hipMemcpyAsync(m->h_seg_begin.data(), m->seg_begin.p, ((size_t)n_keys + 1) * 4,
+                              hipMemcpyDeviceToHost, c->stream));
+    TM_TRY_HIP(hipStreamSynchronize(c->stream));
+    cleanup();
+#undef TM_TRY
+#undef TM_TRY_HIP
+    m->pairs_ready = true;
+    return TM_OK;
+}
+
+int tm_model_get_info(const tm_model* m, float* diameter, uint32_t* cloud_size, uint32_t* point_count,
+                      float* resolution) {
+    TM_REQUIRE(m, TM_ERR_INVALID, "null model");
+    if (diameter) *diameter = m->diameter;
+    if (cloud_size) *cloud_size = m->n;
+    if (point_count) *point_count = (uint32_t)m->subset.size();
+    if (resolution) *resolution = m->resolution;
+    return TM_OK;
+}
+
+int tm_model_get_grid(const tm_model* m, int extents[3], float to_voxel16[16]) {
+    TM_REQUIRE(m && m->grid_ready, TM_ERR_NOT_INITIALIZED, "model grid not set up");
+    if (extents)
+        for (int d = 0; d < 3; ++d) extents[d] = m->extents[d];
+    if (to_voxel16)
+        for (int i = 0; i < 16; ++i) to_voxel16[i] = m->to_voxel[i];
+    return TM_OK;
+}
+
+int tm_model_download_voxels(const tm_model* m, uint32_t* voxels, uint64_t cap, uint64_t* count) {
+    TM_REQUIRE(m, TM_ERR_INVALID, "null model");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    if (count) *count = m->voxel_count;
+    if (!voxels) return TM_OK;
+    TM_REQUIRE(cap >= m->voxel_count, TM_ERR_CAPACITY, "voxel buffer too small");
+    TM_HIP_CHECK(hipSetDevice(m->ctx->device));
+    TM_HIP_CHECK(hipMemcpyAsync(voxels, m->voxels.p, m->voxel_count * 4, hipMemcpyDeviceToHost,
+                                m->ctx->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    return TM_OK;
+}
+
+int tm_model_get_feature_bounds(const tm_model* m, float bmin[4], float bmax[4]) {
+    TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
+    for (int d = 0; d < 4; ++d) {
+        bmin[d] = m->bmin[d];
+        bmax[d] = m->bmax[d];
+    }
+    return TM_OK;
+}
+
+int tm_model_get_pair_counts(const tm_model* m, uint64_t* entries, uint64_t* valid_pairs,
+                             uint32_t* distinct_keys) {
+    TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
+    if (entries) *entries = m->n_entries;
+    if (valid_pairs) *valid_pairs = m->n_valid;
+    if (distinct_keys) *distinct_keys = m->n_keys;
+    return TM_OK;
+}
+
+int tm_model_download_table(const tm_model* m, uint32_t* keys4, uint32_t* offsets, uint32_t key_cap,
+                            uint32_t* pairs_ij, uint64_t pair_cap) {
+    TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
+    TM_REQUIRE(key_cap >= m->n_keys && pair_cap >= m->n_entries, TM_ERR_CAPACITY,
+               "table buffers too small");
+    for (uint32_t s = 0; s < m->n_keys; ++s) {
+        uint32_t p = m->h_seg_key[s];
+        uint32_t k2 = p % m->r2, q = p / m->r2, k1 = q % m->r1, k0 = q / m->r1;
+        if (keys4) {
+            keys4[4 * s + 0] = k0;
+            keys4[4 * s + 1] = k1;
+            keys4[4 * s + 2] = k2;
+            keys4[4 * s + 3] = k0;
+        }
+    }
+    if (offsets) memcpy(offsets, m->h_seg_begin.data(), ((size_t)m->n_keys + 1) * 4);
+    if (pairs_ij) {
+        TM_HIP_CHECK(hipSetDevice(m->ctx->device));
+        TM_HIP_CHECK(hipMemcpyAsync(pairs_ij, m->entries.p, m->n_entries * 8, hipMemcpyDeviceToHost,
+                                    m->ctx->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    return TM_OK;
+}
+
+int tm_model_query_key(const tm_model* m, const uint32_t key[4], uint32_t* pairs_ij, uint32_t cap,
+                       uint32_t* count_total) {
+    TM_REQUIRE(m && key, TM_ERR_INVALID, "tm_model_query: null argument");
+    if (!m->pairs_ready) {
+        set_error("Cannot query uninitialized model");
+        return TM_ERR_NOT_INITIALIZED;
+    }
+    tm_ctx* c = m->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    uint32_t* d_out = (uint32_t*)c->stats.p; /* 2 words of the ctx counter block */
+    hipLaunchKernelGGL(k_query_one, dim3(1), dim3(1), 0, c->stream, m->ht_slot.p, m->ht_key.p,
+                       m->ht_cap - 1, m->seg_begin.p, make_uint4(key[0], key[1], key[2], key[3]), d_out);
+    TM_HIP_CHECK(hipGetLastError());
+    uint32_t h_out[2] = {0, 0};
+    TM_HIP_CHECK(hipMemcpyAsync(h_out, d_out, 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (count_total) *count_total = h_out[1];
+    uint32_t take = std::min(cap, h_out[1]);
+    if (pairs_ij && take) {
+        TM_HIP_CHECK(hipMemcpyAsync(pairs_ij, m->entries.p + h_out[0], (size_t)take * 8,
+                                    hipMemcpyDeviceToHost, c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return TM_OK;
+}
+
+int tm_model_query(const tm_model* m, const float feature[4], uint32_t* pairs_ij, uint32_t cap,
+                   uint32_t* count_total) {
+    TM_REQUIRE(m && feature, TM_ERR_INVALID, "tm_model_query: null argument");
+    if (!m->pairs_ready) {
+        set_error("Cannot query uninitialized model");
+        return TM_ERR_NOT_INITIALIZED;
+    }
+    uint32_t key[4];
+    tm_discretize_feature(feature, m->bmin, m->bmax, m->distance_step_count, m->angle_step, key);
+    return tm_model_query_key(m, key, pairs_ij, cap, count_total);
+}
+
+int tm_model_voxel_query(const tm_model* m, const float pos4[4], uint32_t* index, int* found) {
+    TM_REQUIRE(m && pos4 && index && found, TM_ERR_INVALID, "tm_model_voxel_query: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    const grid_t& g = m->grid;
+    /* to_voxel * pos with the zero entries dropped: s*x + t*w */
+    float vx = g.sx * pos4[0] + g.tx * pos4[3];
+    float vy = g.sy * pos4[1] + g.ty * pos4[3];
+    float vz = g.sz * pos4[2] + g.tz * pos4[3];
+    *found = 0;
+    if (!(vx > -1.f && vx < g.fex && vy > -1.f && vy < g.fey && vz > -1.f && vz < g.fez)) return TM_OK;
+    size_t lin = (size_t)(int)vz * g.ex * g.ey + (size_t)(int)vy * g.ex + (size_t)(int)vx;
+    uint32_t v = 0;
+    TM_HIP_CHECK(hipSetDevice(m->ctx->device));
+    TM_HIP_CHECK(hipMemcpyAsync(&v, m->voxels.p + lin, 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    *index = v;
+    *found = 1;
+    return TM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,801 @@
+/*
+ * tm_scene.hip — scene side of the hot path: hypothesis generation (a10, a12 inner body), batched
+ * inlier scoring (a11/a14) and the best-record reduction. Replaces scene<Point>::impl
+ * (reference include/impl/scene.hpp).
+ *
+ * HBM layout. Original order (addressed by sample index): opos[n] float4 (xyz, w = tangent_mask),
+ * otan[n] float4 (tangent xyz, w = mask). Cell-sorted order (scoring): spos[n_pad] float4 (xyz,
+ * w = bits of the original index; masked / padded / non-finite points carry NaN in x so that they
+ * fail the in-grid test), sref[n_pad] float4 (tangent if tangent_mask else normal, w = tangent_mask),
+ * cell_start[cells+2]. Points are sorted by uniform-grid cell (x fastest) so that a wave's 64 points
+ * are spatial neighbours: the voxel-hit branch is then taken by whole waves or not at all.
+ */
+#include <cstring>
+
+#include "tm_internal.h"
+#include "tm_table.h"
+#include "tm_score.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace tmx {
+
+/* Brute force: every workgroup keeps a tile of scene points in registers and streams a chunk of
+ * hypotheses (pose in SGPRs) over it. VALU-bound: ~30 ops per evaluation on the miss path. */
+template <bool SUBSET>
+__global__ __launch_bounds__(256) void k_score_brute(score_args a) {
+    const uint32_t tile0 = blockIdx.x * kScoreTile;
+    f3 p[kScorePPT];
+#pragma unroll
+    for (int k = 0; k < kScorePPT; ++k) {
+        float4 v = a.spos[tile0 + k * 256 + threadIdx.x];
+        if (SUBSET) {
+            uint32_t orig = __float_as_uint(v.w);
+            if (!(v.x == v.x) || !a.active[orig]) v.x = __builtin_nanf("");
+        }
+        p[k] = make3(v.x, v.y, v.z);
+    }
+    const uint32_t h0 = blockIdx.y * a.hyp_per_block;
+    const uint32_t h1 = min(h0 + a.hyp_per_block, a.n_hyp);
+    unsigned long long pass_total = 0;
+    for (uint32_t h = h0; h < h1; ++h) {
+        const pose12 T = load_pose(a.poses + (size_t)h * 16);
+        uint32_t cnt = 0, pass = 0;
+        long long fx = 0;
+#pragma unroll
+        for (int k = 0; k < kScorePPT; ++k)
+            cnt += eval_point(a, T, p[k], tile0 + k * 256 + threadIdx.x, fx, pass, nullptr);
+        if (__ballot(pass != 0)) { /* wave-uniform: most (tile, hypothesis) pairs miss the grid */
+            for (int off = 32; off > 0; off >>= 1) {
+                cnt += __shfl_down(cnt, off);
+                pass += __shfl_down(pass, off);
+                fx += __shfl_down(fx, off);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                if (cnt) {
+                    atomicAdd(&a.counts[h], cnt);
+                    atomicAdd(&a.scores_fx[h], (unsigned long long)fx);
+                }
+                pass_total += pass;
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0 && pass_total) atomicAdd(&a.stats[0], pass_total);
+}
+
+__global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uint32_t n, double inv_scale,
+                                  double model_size, double* __restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = ((double)fx[t] * inv_scale) / model_size; /* reference :509 */
+}
+
+/* finish_find for one pose: per original index the matched model index or 0xFFFFFFFF */
+__global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
+                                                 uint32_t* __restrict__ match_of_orig) {
+    uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_pad) return;
+    float4 v = a.spos[s];
+    if (!(v.x == v.x)) return;
+    const pose12 T = load_pose(a.poses);
+    long long fx = 0;
+    uint32_t pass = 0, m = 0xFFFFFFFFu;
+    uint32_t hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
+    if (hit) {
+        match_of_orig[__float_as_uint(v.w)] = m;
+        atomicAdd(&a.scores_fx[0], (unsigned long long)fx);
+        atomicAdd(&a.counts[0], 1u);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * hypothesis generation
+ * ---------------------------------------------------------------------------------------------- */
+struct gen_args {
+    const float4* opos;
+    const float4* otan;
+    uint32_t n_scene;
+    const float4* mpos;
+    const float4* mtan;
+    const uint32_t* ht_slot;
+    const uint4* ht_key;
+    uint32_t cap_mask;
+    const uint32_t* seg_begin;
+    const uint2* entries;
+    float lower2, upper2; /* squared diameter window, reference include/impl/scene.hpp:117-120 */
+    float lo0, hi0;
+    uint32_t steps;
+    float angle_step;
+    uint32_t limit;
+    int force_up;
+};
+
+/* one thread per scene sample pair: filters (:290-297), feature/valid (:299-302), query (:304) */
+__global__ void k_gen_lookup(gen_args g, const uint2* __restrict__ ij, uint32_t n_pairs,
+                             uint32_t* __restrict__ seg_first, uint32_t* __restrict__ take) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs) return;
+    uint2 p = ij[t];
+    uint32_t tk = 0, first = 0;
+    if (p.x < g.n_scene && p.y < g.n_scene && p.x != p.y) {
+        float4 P1 = g.opos[p.x], T1 = g.otan[p.x];
+        float4 P2 = g.opos[p.y], T2 = g.otan[p.y];
+        bool ok = (T1.w == 0.f) && (P2.w != 0.f) && (T2.w == 0.f); /* !mask[i], tangent_mask[j], !mask[j] */
+        if (ok) {
+            f3 p1 = make3(P1.x, P1.y, P1.z), p2 = make3(P2.x, P2.y, P2.z);
+            f3 t1 = make3(T1.x, T1.y, T1.z), t2 = make3(T2.x, T2.y, T2.z);
+            f3 d = p2 - p1;
+            float sq = len2(d);
+            d = unit(d);
+            ok = !(sq < g.lower2 || sq > g.upper2);
+            ok = ok && !(1.f - fabsf(dot3(d, t1)) < 0.01f);
+            if (ok) {
+                feat4 f = pair_feature(p1, t1, p2, t2);
+                if (feature_valid(f, g.lo0, g.hi0)) {
+                    key4 k = feature_key(f, g.lo0, g.hi0, g.steps, g.angle_step);
+                    uint32_t s = ht_find(g.ht_slot, g.ht_key, g.cap_mask, k);
+                    if (s != 0xFFFFFFFFu) {
+                        first = g.seg_begin[s];
+                        tk = min(g.seg_begin[s + 1] - first, g.limit);
+                    }
+                }
+            }
+        }
+    }
+    seg_first[t] = first;
+    take[t] = tk;
+}
+
+/* one thread per hypothesis slot, slots in visit order (pair-major, table order inside a pair) */
+__global__ void k_gen_emit(gen_args g, const uint2* __restrict__ ij, uint32_t n_pairs,
+                           const uint32_t* __restrict__ seg_first, const uint32_t* __restrict__ offs,
+                           uint32_t total, uint32_t cap, float* __restrict__ poses,
+                           uint4* __restrict__ prov, uint32_t* __restrict__ keep) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    /* last pair with offs[pair] <= t */
+    uint32_t lo = 0, hi = n_pairs;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= t) lo = mid; else hi = mid;
+    }
+    uint32_t e = t - offs[lo];
+    uint2 p = ij[lo];
+    uint2 mm = g.entries[seg_first[lo] + e];
+    float4 P1 = g.opos[p.x], T1 = g.otan[p.x], P2 = g.opos[p.y];
+    float4 Mi = g.mpos[mm.x], Mj = g.mpos[mm.y], Ti = g.mtan[mm.x];
+    float T[16];
+    base_transform(make3(P1.x, P1.y, P1.z), make3(P2.x, P2.y, P2.z), make3(T1.x, T1.y, T1.z),
+                   make3(Mi.x, Mi.y, Mi.z), make3(Mj.x, Mj.y, Mj.z), make3(Ti.x, Ti.y, Ti.z), T);
+    uint32_t ok = (g.force_up && fabsf(1.f - T[10]) > 0.01f) ? 0u : 1u; /* reference :317 */
+    if (keep) keep[t] = ok;
+    if (t < cap || keep) {
+        float4* dst = (float4*)(poses + (size_t)t * 16);
+        dst[0] = make_float4(T[0], T[1], T[2], T[3]);
+        dst[1] = make_float4(T[4], T[5], T[6], T[7]);
+        dst[2] = make_float4(T[8], T[9], T[10], T[11]);
+        dst[3] = make_float4(T[12], T[13], T[14], T[15]);
+        prov[t] = make_uint4(lo, mm.x, mm.y, e);
+    }
+}
+
+__global__ void k_compact(const float4* __restrict__ poses_in, const uint4* __restrict__ prov_in,
+                          const uint32_t* __restrict__ keep, const uint32_t* __restrict__ dst_of,
+                          uint32_t total, uint32_t cap, float4* __restrict__ poses_out,
+                          uint4* __restrict__ prov_out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total || !keep[t]) return;
+    uint32_t d = dst_of[t];
+    if (d >= cap) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) poses_out[(size_t)d * 4 + k] = poses_in[(size_t)t * 4 + k];
+    prov_out[d] = prov_in[t];
+}
+
+/* argmax over a scored batch: count desc, score desc, id asc. One workgroup. */
+__global__ __launch_bounds__(1024) void k_best(const uint32_t* __restrict__ counts,
+                                               const double* __restrict__ scores,
+                                               const float* __restrict__ poses, uint32_t n,
+                                               uint32_t id_offset, uint32_t id_stride,
+                                               tm_best_record* __restrict__ out) {
+    __shared__ uint32_t s_cnt[1024];
+    __shared__ double s_sc[1024];
+    __shared__ uint32_t s_idx[1024];
+    uint32_t bc = 0, bi = 0xFFFFFFFFu;
+    double bs = -1.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        uint32_t c = counts[i];
+        double s = scores[i];
+        bool better = bi == 0xFFFFFFFFu || c > bc || (c == bc && (s > bs || (s == bs && i < bi)));
+        if (better) {
+            bc = c;
+            bs = s;
+            bi = i;
+        }
+    }
+    s_cnt[threadIdx.x] = bc;
+    s_sc[threadIdx.x] = bs;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            uint32_t c = s_cnt[threadIdx.x + off], i = s_idx[threadIdx.x + off];
+            double s = s_sc[threadIdx.x + off];
+            uint32_t mc = s_cnt[threadIdx.x], mi = s_idx[threadIdx.x];
+            double ms = s_sc[threadIdx.x];
+            bool better = i != 0xFFFFFFFFu &&
+                          (mi == 0xFFFFFFFFu || c > mc || (c == mc && (s > ms || (s == ms && i < mi))));
+            if (better) {
+                s_cnt[threadIdx.x] = c;
+                s_sc[threadIdx.x] = s;
+                s_idx[threadIdx.x] = i;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tm_best_record r;
+        uint32_t i = s_idx[0];
+        r.inlier_count = i == 0xFFFFFFFFu ? 0u : s_cnt[0];
+        r.hyp_id = i == 0xFFFFFFFFu ? 0xFFFFFFFFu : id_offset + i * id_stride;
+        r.score = i == 0xFFFFFFFFu ? 0.0 : s_sc[0];
+        for (int k = 0; k < 16; ++k) r.pose[k] = i == 0xFFFFFFFFu ? 0.f : poses[(size_t)i * 16 + k];
+        for (int k = 0; k < 4; ++k) r.pad[k] = 0;
+        *out = r;
+    }
+}
+
+/* ---- host helpers ---- */
+static inline bool fin3(const float* p) {
+    return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
+}
+
+/* sort the scene by uniform-grid cell and upload the scoring arrays */
+static int build_sorted(tm_scene* s, float cell) {
+    tm_ctx* c = s->ctx;
+    const uint32_t n = s->n;
+    const float big = std::numeric_limits<float>::max();
+    float mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = s->h_cloud.data() + (size_t)i * 12;
+        if (!fin3(p)) continue;
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = std::min(mn[d], p[d]);
+            mx[d] = std::max(mx[d], p[d]);
+        }
+    }
+    if (mn[0] > mx[0]) {
+        for (int d = 0; d < 3; ++d) mn[d] = mx[d] = 0.f;
+    }
+    float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+    if (!(cell > 0.f)) cell = ext > 0.f ? ext / 128.f : 1.f;
+    uint64_t dims[3];
+    for (;;) {
+        for (int d = 0; d < 3; ++d) dims[d] = (uint64_t)std::floor((mx[d] - mn[d]) / cell) + 1;
+        if (dims[0] * dims[1] * dims[2] <= (1ull << 24)) break;
+        cell *= 1.5f;
+    }
+    const uint32_t cells = (uint32_t)(dims[0] * dims[1] * dims[2]);
+    s->cell = cell;
+    for (int d = 0; d < 3; ++d) {
+        s->gmin[d] = mn[d];
+        s->gdim[d] = (int)dims[d];
+    }
+    std::vector<uint32_t> cid(n), start((size_t)cells + 2, 0u);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = s->h_cloud.data() + (size_t)i * 12;
+        uint32_t id = cells; /* non-finite points: trailing bucket */
+        if (fin3(p)) {
+            uint64_t ix = std::min<uint64_t>((uint64_t)((p[0] - mn[0]) / cell), dims[0] - 1);
+            uint64_t iy = std::min<uint64_t>((uint64_t)((p[1] - mn[1]) / cell), dims[1] - 1);
+            uint64_t iz = std::min<uint64_t>((uint64_t)((p[2] - mn[2]) / cell), dims[2] - 1);
+            id = (uint32_t)((iz * dims[1] + iy) * dims[0] + ix);
+        }
+        cid[i] = id;
+        start[(size_t)id + 1]++;
+    }
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    std::vector<uint32_t> perm(n), cursor(start.begin(), start.end() - 1);
+    for (uint32_t i = 0; i < n; ++i) perm[cursor[cid[i]]++] = i;
+    const uint32_t n_pad = ((n + kScoreTile - 1) / kScoreTile) * kScoreTile;
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+    std::vector<float4> spos(n_pad), sref(n_pad);
+    for (uint32_t k = 0; k < n_pad; ++k) {
+        if (k >= n) {
+            spos[k] = make_float4(nanv, 0.f, 0.f, 0.f);
+            sref[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        uint32_t i = perm[k];
+        const float* p = s->h_cloud.data() + (size_t)i * 12;
+        float w;
+        memcpy(&w, &i, 4);
+        bool dead = !fin3(p) || s->h_mask[i] != 0;
+        spos[k] = make_float4(dead ? nanv : p[0], p[1], p[2], w);
+        bool ut = s->h_tmask[i] != 0;
+        sref[k] = ut ? make_float4(p[9], p[10], p[11], 1.f) : make_float4(p[4], p[5], p[6], 0.f);
+    }
+    TM_FORWARD(s->spos.ensure(n_pad));
+    TM_FORWARD(s->sref.ensure(n_pad));
+    TM_FORWARD(s->perm.ensure(n));
+    TM_FORWARD(s->cell_start.ensure(start.size()));
+    TM_HIP_CHECK(hipMemcpyAsync(s->spos.p, spos.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->sref.p, sref.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->perm.p, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->cell_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice,
+                                c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s->n_sorted = n_pad;
+    return TM_OK;
+}
+
+static int upload_original(tm_scene* s) {
+    tm_ctx* c = s->ctx;
+    const uint32_t n = s->n;
+    std::vector<float4> opos(n), otan(n), onrm(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* p = s->h_cloud.data() + (size_t)i * 12;
+        opos[i] = make_float4(p[0], p[1], p[2], s->h_tmask[i] ? 1.f : 0.f);
+        otan[i] = make_float4(p[9], p[10], p[11], s->h_mask[i] ? 1.f : 0.f);
+        onrm[i] = s->h_tmask[i] ? make_float4(p[9], p[10], p[11], 1.f) : make_float4(p[4], p[5], p[6], 0.f);
+    }
+    TM_FORWARD(s->opos.ensure(n));
+    TM_FORWARD(s->otan.ensure(n));
+    TM_FORWARD(s->oref.ensure(n));
+    TM_HIP_CHECK(hipMemcpyAsync(s->oref.p, onrm.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->opos.p, opos.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->otan.p, otan.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
+static int check_pair(const tm_scene* s, const tm_model* m) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    return TM_OK;
+}
+
+/* launches the scoring kernels for poses already on the device; results stay on the device */
+static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* d_poses, uint32_t n_hyp,
+                        const unsigned char* d_active, uint64_t n_active, float dist_thres, int mode,
+                        uint32_t* d_counts, double* d_scores) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(traits_kind == TM_TRAITS_IDENTITY, TM_ERR_UNSUPPORTED,
+               "projected traits are scored through a model/scene built from tm_traits_project_cloud");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(mode == TM_SCORE_AUTO || mode == TM_SCORE_BRUTEFORCE || mode == TM_SCORE_CULLED,
+               TM_ERR_INVALID, "bad scoring mode");
+    if (n_hyp == 0) return TM_OK;
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_scores_fx.ensure(n_hyp));
+    TM_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)n_hyp * 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, (size_t)n_hyp * 8, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, 16 * 8, c->stream));
+    score_args a;
+    a.spos = s->spos.p;
+    a.sref = s->sref.p;
+    a.mpos = m->pos.p;
+    a.mref = m->ref.p;
+    a.vox = m->voxels.p;
+    a.active = d_active;
+    a.poses = d_poses;
+    a.counts = d_counts;
+    a.scores_fx = s->w_scores_fx.p;
+    a.stats = c->stats.p;
+    a.g = m->grid;
+    a.d2max = sq_threshold(dist_thres * m->resolution); /* thres: reference :413 */
+    a.n_hyp = n_hyp;
+    const uint32_t tiles = s->n_sorted / kScoreTile;
+    /* aim for >= ~8 workgroups per CU; keep chunks long enough to amortise the tile load */
+    uint32_t want_chunks = std::max(1u, (256u * 16u + tiles - 1) / tiles);
+    uint32_t hpb = std::max(16u, std::min(1024u, (n_hyp + want_chunks - 1) / want_chunks));
+    a.hyp_per_block = hpb;
+    dim3 grid(tiles, (n_hyp + hpb - 1) / hpb);
+    TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
+    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    if (d_active)
+        hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(k_score_brute<false>, grid, dim3(256), 0, c->stream, a);
+    TM_HIP_CHECK(hipGetLastError());
+    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    hipLaunchKernelGGL(k_finalize_scores, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream,
+                       s->w_scores_fx.p, n_hyp, 1.0 / kFx, (double)m->n, d_scores);
+    TM_HIP_CHECK(hipGetLastError());
+    if (c->timing) {
+        unsigned long long h_stats[2] = {0, 0};
+        TM_HIP_CHECK(hipMemcpyAsync(h_stats, c->stats.p, 16, hipMemcpyDeviceToHost, c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        TM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last.ms = ms;
+        c->last.evaluations = (uint64_t)n_hyp * n_active;
+        c->last.passing = h_stats[0];
+        c->last.hypotheses = n_hyp;
+    }
+    return TM_OK;
+}
+
+static uint64_t count_active(const tm_scene* s) {
+    uint64_t k = 0;
+    for (uint32_t i = 0; i < s->n; ++i)
+        if (!s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++k;
+    return k;
+}
+
+static int generate_device(tm_scene* s, tm_model* m, const uint2* d_ij, uint32_t n_pairs, float minf,
+                           float maxf, int force_up, int query_limit, float* d_poses, uint4* d_prov,
+                           uint32_t cap, uint32_t* count, uint32_t* count_total) {
+    TM_FORWARD(check_pair(s, m));
+    if (!m->pairs_ready) {
+        set_error("Cannot query uninitialized model");
+        return TM_ERR_NOT_INITIALIZED;
+    }
+    if (count) *count = 0;
+    if (count_total) *count_total = 0;
+    if (n_pairs == 0) return TM_OK;
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    gen_args g;
+    g.opos = s->opos.p;
+    g.otan = s->otan.p;
+    g.n_scene = s->n;
+    g.mpos = m->pos.p;
+    g.mtan = m->tan4.p;
+    g.ht_slot = m->ht_slot.p;
+    g.ht_key = m->ht_key.p;
+    g.cap_mask = m->ht_cap - 1;
+    g.seg_begin = m->seg_begin.p;
+    g.entries = m->entries.p;
+    float lower = m->diameter * minf, upper = m->diameter * maxf;
+    g.lower2 = lower * lower;
+    g.upper2 = upper * upper;
+    g.lo0 = m->bmin[0];
+    g.hi0 = m->bmax[0];
+    g.steps = (uint32_t)m->distance_step_count;
+    g.angle_step = m->angle_step;
+    g.limit = query_limit > 0 ? (uint32_t)query_limit : 0xFFFFFFFFu; /* reference :310 */
+    g.force_up = force_up;
+    TM_FORWARD(s->w_u32a.ensure(n_pairs));          /* seg_first */
+    TM_FORWARD(s->w_u32b.ensure((size_t)n_pairs + 1)); /* take, then offsets */
+    TM_FORWARD(s->w_u32c.ensure((size_t)n_pairs + 1));
+    uint32_t* d_first = s->w_u32a.p;
+    uint32_t* d_take = s->w_u32b.p;
+    uint32_t* d_offs = s->w_u32c.p;
+    TM_HIP_CHECK(hipMemsetAsync(d_take + n_pairs, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_gen_lookup, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, g, d_ij, n_pairs,
+                       d_first, d_take);
+    TM_HIP_CHECK(hipGetLastError());
+    size_t tmp = 0;
+    TM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp, d_take, d_offs, 0u, (size_t)n_pairs + 1,
+                                         rocprim::plus<uint32_t>(), c->stream));
+    TM_FORWARD(scratch_ensure(c, tmp));
+    TM_HIP_CHECK(rocprim::exclusive_scan(c->scratch.p, tmp, d_take, d_offs, 0u, (size_t)n_pairs + 1,
+                                         rocprim::plus<uint32_t>(), c->stream));
+    uint32_t total = 0;
+    TM_HIP_CHECK(hipMemcpyAsync(&total, d_offs + n_pairs, 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (total == 0) return TM_OK;
+    if (!force_up) {
+        hipLaunchKernelGGL(k_gen_emit, dim3((total + 255) / 256), dim3(256), 0, c->stream, g, d_ij, n_pairs,
+                           d_first, d_offs, total, cap, d_poses, d_prov, (uint32_t*)nullptr);
+        TM_HIP_CHECK(hipGetLastError());
+        if (count) *count = std::min(total, cap);
+        if (count_total) *count_total = total;
+        return TM_OK;
+    }
+    /* force_up: emit everything to a staging area, then compact the survivors in order */
+    dbuf<float> st_pose;
+    dbuf<uint4> st_prov;
+    dbuf<uint32_t> keep, dst;
+    int rc;
+    auto cleanup = [&]() {
+        st_pose.release();
+        st_prov.release();
+        keep.release();
+        dst.release();
+    };
+    if ((rc = st_pose.alloc((size_t)total * 16)) || (rc = st_prov.alloc(total)) ||
+        (rc = keep.alloc((size_t)total + 1)) || (rc = dst.alloc((size_t)total + 1))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(keep.p + total, 0, 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gen_emit, dim3((total + 255) / 256), dim3(256), 0, c->stream, g, d_ij, n_pairs,
+                           d_first, d_offs, total, total, st_pose.p, st_prov.p, keep.p);
+        e = hipGetLastError();
+    }
+    size_t tmp2 = 0;
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(nullptr, tmp2, keep.p, dst.p, 0u, (size_t)total + 1,
+                                    rocprim::plus<uint32_t>(), c->stream);
+    if (e == hipSuccess && scratch_ensure(c, tmp2) != TM_OK) {
+        cleanup();
+        return TM_ERR_HIP;
+    }
+    if (e == hipSuccess)
+        e = rocprim::exclusive_scan(c->scratch.p, tmp2, keep.p, dst.p, 0u, (size_t)total + 1,
+                                    rocprim::plus<uint32_t>(), c->stream);
+    uint32_t kept = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&kept, dst.p + total, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_compact, dim3((total + 255) / 256), dim3(256), 0, c->stream,
+                           (const float4*)st_pose.p, st_prov.p, keep.p, dst.p, total, cap, (float4*)d_poses,
+                           d_prov);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_generate_hypotheses: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    if (count) *count = std::min(kept, cap);
+    if (count_total) *count_total = kept;
+    return TM_OK;
+}
+
+}  // namespace tmx
+
+using namespace tmx;
+
+extern "C" {
+
+int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
+                    tm_scene** out) {
+    TM_REQUIRE(ctx && surfels && tangent_mask && out, TM_ERR_INVALID, "tm_scene_create: null argument");
+    TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_scene_create: empty cloud");
+    TM_HIP_CHECK(hipSetDevice(ctx->device));
+    tm_scene* s = new tm_scene();
+    s->ctx = ctx;
+    s->n = n;
+    s->h_cloud.assign(surfels, surfels + (size_t)n * 12);
+    s->h_tmask.assign(tangent_mask, tangent_mask + n);
+    s->h_mask.assign(n, 0);
+    int rc = upload_original(s);
+    if (!rc) rc = build_sorted(s, 0.f);
+    if (rc) {
+        tm_scene_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return TM_OK;
+}
+
+int tm_scene_destroy(tm_scene* s) {
+    if (!s) return TM_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    s->opos.release();
+    s->otan.release();
+    s->oref.release();
+    s->spos.release();
+    s->sref.release();
+    s->perm.release();
+    s->cell_start.release();
+    s->w_poses.release();
+    s->w_counts.release();
+    s->w_scores_fx.release();
+    s->w_scores.release();
+    s->w_u32a.release();
+    s->w_u32b.release();
+    s->w_u32c.release();
+    s->w_pairs.release();
+    delete s;
+    return TM_OK;
+}
+
+int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
+    TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
+    TM_HIP_CHECK(hipSetDevice(s->ctx->device));
+    if (mask)
+        s->h_mask.assign(mask, mask + s->n);
+    else
+        s->h_mask.assign(s->n, 0);
+    TM_FORWARD(upload_original(s));
+    return build_sorted(s, s->cell);
+}
+
+uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
+
+int tm_generate_hypotheses_dev(tm_scene* s, tm_model* m, const uint32_t* d_ij_pairs, uint32_t n_pairs,
+                               float min_diameter_factor, float max_diameter_factor, int force_up,
+                               int query_limit, float* d_poses16, uint32_t* d_provenance4, uint32_t cap,
+                               uint32_t* count, uint32_t* count_total) {
+    TM_REQUIRE(d_ij_pairs && d_poses16 && d_provenance4, TM_ERR_INVALID,
+               "tm_generate_hypotheses_dev: null argument");
+    return generate_device(s, m, (const uint2*)d_ij_pairs, n_pairs, min_diameter_factor,
+                           max_diameter_factor, force_up, query_limit, d_poses16, (uint4*)d_provenance4, cap,
+                           count, count_total);
+}
+
+int tm_generate_hypotheses(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs,
+                           float min_diameter_factor, float max_diameter_factor, int force_up,
+                           int query_limit, float* poses16, uint32_t* provenance4, uint32_t cap,
+                           uint32_t* count, uint32_t* count_total) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(ij_pairs || n_pairs == 0, TM_ERR_INVALID, "tm_generate_hypotheses: null pairs");
+    if (count) *count = 0;
+    if (count_total) *count_total = 0;
+    if (n_pairs == 0) return m->pairs_ready ? TM_OK : TM_ERR_NOT_INITIALIZED;
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    dbuf<uint2> d_ij;
+    dbuf<float> d_pose;
+    dbuf<uint4> d_prov;
+    int rc;
+    uint32_t dev_cap = std::max(cap, 1u);
+    if ((rc = d_ij.alloc(n_pairs)) || (rc = d_pose.alloc((size_t)dev_cap * 16)) ||
+        (rc = d_prov.alloc(dev_cap))) {
+        d_ij.release();
+        d_pose.release();
+        d_prov.release();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_ij.p, ij_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream);
+    uint32_t got = 0, total = 0;
+    rc = TM_OK;
+    if (e == hipSuccess)
+        rc = generate_device(s, m, d_ij.p, n_pairs, min_diameter_factor, max_diameter_factor, force_up,
+                             query_limit, d_pose.p, d_prov.p, cap, &got, &total);
+    if (e == hipSuccess && rc == TM_OK && got) {
+        if (poses16)
+            e = hipMemcpyAsync(poses16, d_pose.p, (size_t)got * 64, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && provenance4)
+            e = hipMemcpyAsync(provenance4, d_prov.p, (size_t)got * 16, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d_ij.release();
+    d_pose.release();
+    d_prov.release();
+    if (e != hipSuccess) {
+        set_error("tm_generate_hypotheses: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    if (rc) return rc;
+    if (count) *count = got;
+    if (count_total) *count_total = total;
+    return TM_OK;
+}
+
+int tm_score_hypotheses_dev(tm_scene* s, tm_model* m, int traits_kind, const float* d_poses16,
+                            uint32_t n_hyp, float dist_thres, int mode, uint32_t* d_counts,
+                            double* d_scores) {
+    TM_REQUIRE(d_poses16 && d_counts && d_scores, TM_ERR_INVALID, "tm_score_hypotheses_dev: null argument");
+    TM_FORWARD(check_pair(s, m));
+    return score_device(s, m, traits_kind, d_poses16, n_hyp, nullptr, count_active(s), dist_thres, mode,
+                        d_counts, d_scores);
+}
+
+int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* poses16, uint32_t n_hyp,
+                        const int32_t* subset, uint32_t n_subset, float dist_thres, int mode,
+                        uint32_t* counts, double* scores) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(poses16 || n_hyp == 0, TM_ERR_INVALID, "tm_score_hypotheses: null poses");
+    TM_REQUIRE(counts && scores, TM_ERR_INVALID, "tm_score_hypotheses: null outputs");
+    if (n_hyp == 0) return TM_OK;
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure((size_t)n_hyp * 16));
+    TM_FORWARD(s->w_counts.ensure(n_hyp));
+    TM_FORWARD(s->w_scores.ensure(n_hyp));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    dbuf<unsigned char> d_active;
+    uint64_t n_active = 0;
+    if (subset) {
+        std::vector<unsigned char> act(s->n, 0);
+        for (uint32_t k = 0; k < n_subset; ++k) {
+            if (subset[k] < 0 || (uint32_t)subset[k] >= s->n) {
+                set_error("tm_score_hypotheses: subset index out of range");
+                return TM_ERR_INVALID;
+            }
+            act[subset[k]] = 1;
+        }
+        for (uint32_t i = 0; i < s->n; ++i)
+            if (act[i] && !s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++n_active;
+        TM_FORWARD(d_active.alloc(s->n));
+        hipError_t e = hipMemcpyAsync(d_active.p, act.data(), s->n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            d_active.release();
+            set_error("tm_score_hypotheses: %s", hipGetErrorString(e));
+            return TM_ERR_HIP;
+        }
+    } else {
+        n_active = count_active(s);
+    }
+    int rc = score_device(s, m, traits_kind, s->w_poses.p, n_hyp, d_active.p, n_active, dist_thres, mode,
+                          s->w_counts.p, s->w_scores.p);
+    hipError_t e = hipSuccess;
+    if (rc == TM_OK) {
+        e = hipMemcpyAsync(counts, s->w_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(scores, s->w_scores.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    d_active.release();
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) {
+        set_error("tm_score_hypotheses: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
+int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres,
+                               uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t cap, uint32_t* count,
+                               double* score) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(pose16 && count, TM_ERR_INVALID, "tm_extract_correspondences: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure(16));
+    TM_FORWARD(s->w_counts.ensure(1));
+    TM_FORWARD(s->w_scores_fx.ensure(1));
+    TM_FORWARD(s->w_u32a.ensure(s->n));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, 8, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_u32a.p, 0xFF, (size_t)s->n * 4, c->stream));
+    score_args a;
+    a.spos = s->spos.p;
+    a.sref = s->sref.p;
+    a.mpos = m->pos.p;
+    a.mref = m->ref.p;
+    a.vox = m->voxels.p;
+    a.active = nullptr;
+    a.poses = s->w_poses.p;
+    a.counts = s->w_counts.p;
+    a.scores_fx = s->w_scores_fx.p;
+    a.stats = c->stats.p;
+    a.g = m->grid;
+    a.d2max = sq_threshold(dist_thres * m->resolution);
+    a.n_hyp = 1;
+    a.hyp_per_block = 1;
+    hipLaunchKernelGGL(k_extract, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
+                       s->w_u32a.p);
+    TM_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> match(s->n);
+    unsigned long long fx = 0;
+    uint32_t n_corr = 0;
+    TM_HIP_CHECK(hipMemcpyAsync(match.data(), s->w_u32a.p, (size_t)s->n * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(&fx, s->w_scores_fx.p, 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(&n_corr, s->w_counts.p, 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *count = n_corr;
+    if (score) *score = ((double)fx * (1.0 / kFx)) / (double)m->n;
+    if (scene_corrs || model_corrs) {
+        TM_REQUIRE(cap >= n_corr, TM_ERR_CAPACITY, "correspondence buffers too small");
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < s->n; ++i) { /* ascending scene index = reference scan order */
+            if (match[i] == 0xFFFFFFFFu) continue;
+            if (scene_corrs) scene_corrs[k] = i;
+            if (model_corrs) model_corrs[k] = match[i];
+            ++k;
+        }
+    }
+    return TM_OK;
+}
+
+int tm_best_of_batch(tm_ctx* c, const uint32_t* d_counts, const double* d_scores, const float* d_poses16,
+                     uint32_t n_hyp, uint32_t id_offset, uint32_t id_stride, tm_best_record* best) {
+    TM_REQUIRE(c && best, TM_ERR_INVALID, "tm_best_of_batch: null argument");
+    TM_REQUIRE((d_counts && d_scores && d_poses16) || n_hyp == 0, TM_ERR_INVALID,
+               "tm_best_of_batch: null device buffers");
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(scratch_ensure(c, sizeof(tm_best_record)));
+    hipLaunchKernelGGL(k_best, dim3(1), dim3(1024), 0, c->stream, d_counts, d_scores, d_poses16, n_hyp,
+                       id_offset, id_stride, (tm_best_record*)c->scratch.p);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipMemcpyAsync(best, c->scratch.p, sizeof(tm_best_record), hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
+}  // extern "C"

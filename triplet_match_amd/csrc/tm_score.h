@@ -1,0 +1,79 @@
+/* tm_score.h — the (hypothesis, point) evaluation shared by the scoring kernels
+ * (tm_scene.hip, tm_earlydrop.hip). Restates reference include/impl/scene.hpp:432-490. */
+#ifndef TM_SCORE_H_
+#define TM_SCORE_H_
+
+#include <cmath>
+#include <limits>
+
+#include "tm_internal.h"
+
+namespace tmx {
+
+constexpr int kScorePPT = 4;               /* points per thread held in registers */
+constexpr int kScoreTile = 256 * kScorePPT; /* points per workgroup */
+constexpr double kFx = 1099511627776.0;     /* 2^40: fixed-point scale of the score sum */
+
+struct score_args {
+    const float4* spos;
+    const float4* sref;
+    const float4* mpos;
+    const float4* mref;
+    const uint32_t* vox;
+    const unsigned char* active; /* per original index, or null */
+    const float* poses;
+    uint32_t* counts;
+    unsigned long long* scores_fx;
+    unsigned long long* stats; /* [0] = distance-passing evaluations */
+    grid_t g;
+    float d2max; /* largest f32 whose sqrtf is <= thres: d2 <= d2max <=> !(sqrtf(d2) > thres) */
+    uint32_t n_hyp;
+    uint32_t hyp_per_block;
+};
+
+/* one (hypothesis, point) evaluation = reference include/impl/scene.hpp:432-490.
+ * Returns 1 if the point becomes a correspondence; accumulates the fixed-point score term. */
+__device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12& T, f3 p,
+                                               uint32_t sorted_idx, long long& fx, uint32_t& pass,
+                                               uint32_t* model_idx, bool* in_grid = nullptr) {
+    f3 q = xform_point(T, p);
+    float vx = a.g.sx * q.x + a.g.tx;
+    float vy = a.g.sy * q.y + a.g.ty;
+    float vz = a.g.sz * q.z + a.g.tz;
+    bool in = (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez);
+    if (in_grid) *in_grid = in;
+    if (!in) return 0u;
+    uint32_t lin = ((uint32_t)(int)vz * (uint32_t)a.g.ey + (uint32_t)(int)vy) * (uint32_t)a.g.ex +
+                   (uint32_t)(int)vx;
+    uint32_t m = a.vox[lin];
+    float4 mp = a.mpos[m];
+    float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
+    float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (!(d2 <= a.d2max)) return 0u;
+    ++pass;
+    float4 sr = a.sref[sorted_idx];
+    if (sr.w != mp.w) return 0u; /* use_tangent != is_tangent, reference :472 */
+    f3 r = xform_dir(T, make3(sr.x, sr.y, sr.z));
+    float4 mr = a.mref[m];
+    float term = fabsf(dot3(r, make3(mr.x, mr.y, mr.z)));
+    fx += (long long)((double)term * kFx);
+    if (model_idx) *model_idx = m;
+    return 1u;
+}
+
+/* largest float t with sqrtf(t) <= thres (sqrtf is correctly rounded and monotone) */
+static inline float sq_threshold(float thres) {
+    if (!(thres >= 0.f)) return -1.f;
+    float t = thres * thres;
+    while (sqrtf(t) > thres) t = std::nextafter(t, 0.f);
+    for (;;) {
+        float u = std::nextafter(t, std::numeric_limits<float>::infinity());
+        if (sqrtf(u) <= thres) t = u; else break;
+    }
+    return t;
+}
+
+
+}  // namespace tmx
+
+#endif /* TM_SCORE_H_ */
