@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — scored RANSAC hypotheses/s of the triplet-match hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input, all inputs already resident
+in HBM: hypothesis generation from a batch of scene sample pairs (descriptor -> hashed match ->
+base transform, <= 200 poses per pair, capped at 65,536) -> inlier scoring of every hypothesis
+against the whole scene -> best-(count, score, pose) record (+ one RCCL all-gather of the 96-byte
+records when N > 1). Workload = BASELINE.json configs[1]: identity traits, 100k-pt model, 1M-pt
+scene, 64k hypotheses per batch. Data: seeded synthetic clouds (triplet_match_amd/synth.py).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); scene / model / table are
+replicated, sample pairs are sharded round-robin, every rank scores its own 64k batch (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model-points", type=int, default=100_000)
+    ap.add_argument("--scene-points", type=int, default=1_000_000)
+    ap.add_argument("--hyp-per-batch", type=int, default=65_536)
+    ap.add_argument("--copies", type=int, default=4)
+    ap.add_argument("--mode", choices=["auto", "brute", "culled"], default="auto")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline time")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log("warning: WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from triplet_match_amd import build as tm_build
+    if rank == 0:
+        tm_build.build()
+    if world > 1:
+        dist.barrier()
+    from triplet_match_amd import capi, synth
+
+    mode = {"auto": capi.SCORE_AUTO, "brute": capi.SCORE_BRUTEFORCE, "culled": capi.SCORE_CULLED}[args.mode]
+    DIST_THRES, ACCEPT_PROB = 3.0, 0.5
+
+    # ---- synthetic inputs (identical on every rank) ----
+    t0 = time.time()
+    model, subset = synth.synth_model(args.model_points, seed=1)
+    res = synth.resolution(model)
+    scene = synth.synth_scene(args.scene_points, args.model_points, seed=2, copies=args.copies,
+                              model_resolution=res)
+    log("[rank %d] synth %.1fs: model %d (tangent %d), scene %d (tangent %d), resolution %.5f"
+        % (rank, time.time() - t0, model.shape[0], len(subset), scene["surfels"].shape[0],
+           int(scene["tangent_mask"].sum()), res))
+
+    # ---- device setup (not timed: model init is a one-off) ----
+    ctx = capi.Context(local_rank)
+    t0 = time.time()
+    gm = capi.Model(ctx, model, res)
+    gm.build_voxels()
+    t_vox = time.time() - t0
+    t0 = time.time()
+    gm.build_pairs(subset)
+    t_pairs = time.time() - t0
+    gs = capi.Scene(ctx, scene["surfels"], scene["tangent_mask"])
+    pc = gm.pair_counts()
+    ext, _ = gm.grid()
+    log("[rank %d] model init: voxels %s in %.2fs, pair table %d entries / %d keys in %.2fs"
+        % (rank, list(ext), t_vox, pc["entries"], pc["distinct_keys"], t_pairs))
+
+    # ---- scene sample pairs (seeded, RANSAC visit order), sharded round-robin over ranks ----
+    H = args.hyp_per_batch
+    n_first = max(64, H // 400)
+    pairs_all = synth.sample_scene_pairs(scene, gm.diameter, n_first * world, 24, seed=13)
+    pairs = np.ascontiguousarray(pairs_all[rank::world])
+    d_ij = ctx.alloc(max(pairs.nbytes, 8))
+    ctx.h2d(d_ij, pairs)
+    d_poses = ctx.alloc(H * 64)
+    d_prov = ctx.alloc(H * 16)
+    d_counts = ctx.alloc(H * 4)
+    d_scores = ctx.alloc(H * 8)
+    n_hyp, total = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
+    log("[rank %d] %d sample pairs -> %d hypotheses (%d before the batch cap)" % (rank, len(pairs), n_hyp, total))
+    if n_hyp < H:
+        log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (n_hyp, H))
+
+    if world > 1:
+        rec_dev = torch.zeros(96, dtype=torch.uint8, device="cuda")
+        rec_all = torch.zeros(96 * world, dtype=torch.uint8, device="cuda")
+
+    import ctypes as C
+
+    def step():
+        n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
+        gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
+        best = ctx.best_of_batch(d_counts, d_scores, d_poses, n, id_offset=rank, id_stride=world)
+        if world > 1:
+            raw = np.frombuffer(bytes(best), dtype=np.uint8)
+            rec_dev.copy_(torch.from_numpy(raw.copy()))
+            dist.all_gather_into_tensor(rec_all, rec_dev)
+            recs_np = rec_all.cpu().numpy().tobytes()
+            recs = [capi.BestRecord.from_buffer_copy(recs_np[96 * r:96 * (r + 1)]) for r in range(world)]
+            best = capi.best_select(recs)
+        return n, best
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_timing(True)
+    kern_ms, evals, passing, hyps = [], 0, 0, 0
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        n, best = step()
+        tm_ = ctx.last_score_timing()
+        kern_ms.append(tm_["ms"])
+        evals += tm_["evaluations"]
+        passing += tm_["passing"]
+        hyps += n
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    ctx.enable_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        h = torch.tensor([hyps, evals], dtype=torch.float64, device="cuda")
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        hyps_all, evals_all = float(h[0].item()), float(h[1].item())
+    else:
+        hyps_all, evals_all = float(hyps), float(evals)
+
+    value = hyps_all / elapsed
+    # roofline of the dominant kernel (inlier scoring), rank 0's launches:
+    # algorithmic bytes per launch = 40*E + 32*P + 64*H
+    k_ms = float(np.mean(kern_ms))
+    E, P, Hh = evals / args.steps, passing / args.steps, hyps / args.steps
+    alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
+                "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes}
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp,
+                                        DIST_THRES, ACCEPT_PROB)
+
+    if rank == 0:
+        out = {
+            "metric": "scored RANSAC hypotheses/sec (1M-pt scene); inlier-score Gpoints/sec in gpoints_per_s",
+            "value": round(value, 1), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "identity_traits: %d-pt model / %d-pt scene, %d hypotheses/batch, full-scene scoring"
+                       % (args.model_points, args.scene_points, H),
+                       "hypotheses_per_batch_scored": int(hyps / args.steps), "dist_thres": DIST_THRES,
+                       "query_limit": 200, "score_mode": args.mode, "parallelism": "hyp-shard x%d" % world},
+            "gpoints_per_s": round(evals_all / elapsed / 1e9, 2),
+            "best": {"inlier_count": int(best.inlier_count), "hyp_id": int(best.hyp_id)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp, dist_thres,
+                     accept_prob):
+    """Times the oracle's project_ (the CPU restatement of the reference path, kind "port") on a
+    bounded sample of the same hypothesis batch, threads = hardware_concurrency() - 1 as the
+    reference does (include/impl/scene.hpp:146). The voxel table is imported from the GPU build
+    (their equality is what tests/test_gpu_parity.py::test_voxel_grid_bit_exact shows)."""
+    from oracle import tmo
+    threads = max(1, (os.cpu_count() or 2) - 1)
+    om = tmo.Model(model, res)
+    om.set_voxels(gm.voxels())
+    os_ = tmo.Scene(scene["surfels"], scene["tangent_mask"])
+    poses = np.zeros((n_hyp, 16), np.float32)
+    ctx.d2h(poses, d_poses)
+    # calibrate on a few hypotheses, then size the sample for the target time
+    k0 = min(n_hyp, 2 * threads)
+    t0 = time.perf_counter()
+    os_.score_hypotheses(om, poses[:k0], accept_prob, dist_thres, threads=threads)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    k = int(min(n_hyp, max(k0, args.cpu_seconds * k0 / dt)))
+    sel = np.linspace(0, n_hyp - 1, k).astype(np.int64)
+    t0 = time.perf_counter()
+    c_full, _, ev_full = os_.score_hypotheses(om, poses[sel], accept_prob, dist_thres, threads=threads)
+    t_full = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    c_ed, _, ev_ed = os_.score_hypotheses(om, poses[sel], accept_prob, dist_thres, early_drop=True,
+                                          threads=threads)
+    t_ed = time.perf_counter() - t0
+    # checker role of the oracle: the GPU's inlier counts for the sampled hypotheses must be identical
+    counts = np.zeros(n_hyp, np.uint32)
+    ctx.d2h(counts, d_counts)
+    parity = bool(np.array_equal(counts[sel], c_full))
+    if not parity:
+        log("ERROR: GPU inlier counts differ from the oracle on the CPU-baseline sample")
+    return {"value": round(k / t_full, 2), "unit": "hypotheses/s", "cores": threads, "kind": "port",
+            "sample": "%d of the %d hypotheses of one batch, full pass over the %d-pt scene (early drop off), %.1fs"
+                      % (k, n_hyp, scene["surfels"].shape[0], t_full),
+            "gpoints_per_s": round(ev_full / t_full / 1e9, 4),
+            "early_drop_on": {"value": round(k / t_ed, 2), "unit": "hypotheses/s",
+                              "gpoints_per_s": round(ev_ed / t_ed / 1e9, 4), "seconds": round(t_ed, 2)},
+            "max_inliers_in_sample": int(c_full.max()), "gpu_counts_equal_oracle_on_sample": parity}
+
+
+if __name__ == "__main__":
+    main()
