@@ -96,12 +96,24 @@ struct tm_model {
     int extents[3] = {0, 0, 0};
     float to_voxel[16];
     tmx::grid_t grid;
-    /* device SoA */
+    /* device SoA, stored in MORTON order of the positions ("new" indices): neighbouring scene points
+     * gather neighbouring model records. The ABI speaks original indices; new2orig / orig2new map. */
+    std::vector<uint32_t> h_new2orig, h_orig2new;
+    tmx::dbuf<uint32_t> new2orig;
+    tmx::dbuf<float4> vpos; /* xyz (NaN if non-finite), w = bits of the ORIGINAL index (voxel build tie-break) */
     tmx::dbuf<float4> pos;  /* xyz, w = (|tangent| > 0.7) ? 1 : 0 ; non-finite points keep NaN */
     tmx::dbuf<float4> ref;  /* tangent if is_tangent else normal */
     tmx::dbuf<float4> tan4; /* raw tangent xyz (pair build / hypothesis generation) */
-    tmx::dbuf<uint32_t> voxels;
-    uint64_t voxel_count = 0;
+    tmx::dbuf<uint32_t> voxels; /* 4x4x4-bricked: [brick][z&3][y&3][x&3], entries are NEW indices */
+    uint64_t voxel_count = 0;   /* dense count ex*ey*ez (ABI view) */
+    uint64_t voxel_slots = 0;   /* bricks * 64 */
+    /* 4x4x4-voxel bricks: quantised lower bound of the NN distance over the brick's voxel centres.
+     * 1 byte per brick (L2-resident); lets the scoring kernels reject far-from-surface hits without
+     * touching the big voxel table. */
+    tmx::dbuf<uint32_t> brick_min_bits; /* f32 bits of min d2 per brick */
+    tmx::dbuf<unsigned char> brick_code; /* floor(sqrt(min d2) / brick_q), clamped to 255 */
+    int bdim[3] = {0, 0, 0};
+    float brick_q = 0.f;
     /* pair table */
     std::vector<uint32_t> subset;
     float bmin[4], bmax[4];
@@ -128,15 +140,13 @@ struct tm_scene {
     tmx::dbuf<float4> opos;  /* xyz, w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> otan;  /* raw tangent xyz, w = masked ? 1 : 0 */
     tmx::dbuf<float4> oref;  /* tangent if tangent_mask else normal, w = tangent_mask */
-    /* cell-sorted order (scoring) */
-    float cell = 0.f;            /* current grid cell size, 0 = not built */
-    float gmin[3];               /* grid origin */
-    int gdim[3] = {0, 0, 0};
-    tmx::dbuf<float4> spos;       /* sorted xyz (masked / padding -> NaN), w = bits of original index */
+    /* Morton-sorted order (scoring): 64 consecutive points form a tile with a bounding sphere */
+    tmx::dbuf<float4> spos;       /* sorted xyz (masked / padding / non-finite -> NaN in x), w = bits of original index */
     tmx::dbuf<float4> sref;       /* sorted ref (tangent or normal), w = tangent_mask ? 1 : 0 */
-    tmx::dbuf<uint32_t> perm;     /* sorted -> original */
-    tmx::dbuf<uint32_t> cell_start; /* gdim product + 1 */
-    uint32_t n_sorted = 0;       /* finite points */
+    tmx::dbuf<float4> tiles;      /* per tile: centre xyz, radius (negative = empty) */
+    uint32_t n_sorted = 0;        /* padded point count (multiple of the brute-force tile) */
+    uint32_t n_tiles = 0;         /* n_sorted / 64 */
+    float coord_max = 0.f;        /* max |coordinate| over the finite points */
     /* work buffers reused across calls */
     tmx::dbuf<float> w_poses;
     tmx::dbuf<uint32_t> w_counts;

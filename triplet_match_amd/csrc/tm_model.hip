@@ -3,7 +3,7 @@
  * query (a8) and voxel_query (a9). Replaces model<Point>::impl (reference include/impl/model.hpp).
  *
  * HBM layout: pos[n] float4 (xyz, w = 1 if |tangent| > 0.7), ref[n] float4 (tangent or normal),
- * tan4[n] float4 (raw tangent); voxels[ex*ey*ez] u32 (x fastest, reference :83); the pair table as a
+ * tan4[n] float4 (raw tangent), all in Morton order; voxels[bricks*64] u32 (4x4x4-bricked); the pair table as a
  * CSR sorted by key: seg_key[n_keys] (packed key), seg_begin[n_keys+1], entries[] (i,j), plus an
  * open-addressing index keyed by MurmurHash3(key, seed 42) for the device-side probe.
  */
@@ -24,6 +24,16 @@ static inline bool fin3(const float* p) {
     return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
 }
 
+static inline uint64_t spread21(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * a6 — voxel NN grid. One thread owns VPT voxels; the cloud streams through LDS in tiles and every
  * thread scans the tile (broadcast reads), keeping the strict minimum => lowest index on ties.
@@ -32,29 +42,36 @@ static inline bool fin3(const float* p) {
 constexpr int kVoxTile = 2048; /* points per LDS tile: 32 KiB */
 constexpr int kVoxVPT = 4;     /* voxels per thread */
 
+/* Voxels are enumerated (and stored) brick-major: slot = brick*64 + (z&3)*16 + (y&3)*4 + (x&3), so a
+ * wave owns exactly one 4x4x4 brick: coalesced 256-B stores and the brick's minimum distance falls
+ * out of one wave reduction. `pos` is the Morton-ordered cloud with the ORIGINAL index in .w: ties in
+ * d2 go to the lowest original index (what a scan in original order with a strict '<' would keep). */
 __global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos, uint32_t n,
-                                                  grid_t g, uint64_t voxel_count,
-                                                  uint32_t* __restrict__ voxels) {
+                                                  grid_t g, uint64_t voxel_slots, int bx, int by,
+                                                  uint32_t* __restrict__ voxels,
+                                                  uint32_t* __restrict__ brick_min_bits) {
     __shared__ float4 tile[kVoxTile];
     float qx[kVoxVPT], qy[kVoxVPT], qz[kVoxVPT], best[kVoxVPT];
-    uint32_t besti[kVoxVPT];
+    uint32_t besti[kVoxVPT], besto[kVoxVPT];
+    bool live[kVoxVPT];
     const uint64_t base = (uint64_t)blockIdx.x * (256 * kVoxVPT);
     const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
     const float itx = -(g.tx * isx), ity = -(g.ty * isy), itz = -(g.tz * isz);
-    const uint64_t exy = (uint64_t)g.ex * g.ey;
 #pragma unroll
     for (int v = 0; v < kVoxVPT; ++v) {
-        uint64_t lin = base + (uint64_t)v * 256 + threadIdx.x;
-        uint64_t l = lin < voxel_count ? lin : 0;
-        uint32_t k = (uint32_t)(l / exy);
-        uint32_t r = (uint32_t)(l - (uint64_t)k * exy);
-        uint32_t j = r / (uint32_t)g.ex;
-        uint32_t i = r - j * (uint32_t)g.ex;
+        uint64_t slot = base + (uint64_t)v * 256 + threadIdx.x;
+        uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
+        uint32_t bk = brick / (uint32_t)(bx * by);
+        uint32_t br = brick - bk * (uint32_t)(bx * by);
+        uint32_t bj = br / (uint32_t)bx, bi = br - bj * (uint32_t)bx;
+        uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
+        live[v] = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
         qx[v] = isx * (float)i + itx;
         qy[v] = isy * (float)j + ity;
         qz[v] = isz * (float)k + itz;
         best[v] = __builtin_inff();
         besti[v] = 0xFFFFFFFFu;
+        besto[v] = 0xFFFFFFFFu;
     }
     for (uint32_t t0 = 0; t0 < n; t0 += kVoxTile) {
         __syncthreads();
@@ -70,18 +87,51 @@ __global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos
             for (int v = 0; v < kVoxVPT; ++v) {
                 float dx = p.x - qx[v], dy = p.y - qy[v], dz = p.z - qz[v];
                 float d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 < best[v]) { /* NaN (non-finite point) never wins */
-                    best[v] = d2;
-                    besti[v] = t0 + s;
+                if (d2 <= best[v]) { /* NaN (non-finite point) never enters */
+                    uint32_t o = __float_as_uint(p.w);
+                    if (d2 < best[v] || o < besto[v]) {
+                        best[v] = d2;
+                        besti[v] = t0 + s;
+                        besto[v] = o;
+                    }
                 }
             }
         }
     }
 #pragma unroll
     for (int v = 0; v < kVoxVPT; ++v) {
-        uint64_t lin = base + (uint64_t)v * 256 + threadIdx.x;
-        if (lin < voxel_count) voxels[lin] = besti[v];
+        uint64_t slot = base + (uint64_t)v * 256 + threadIdx.x;
+        if (slot < voxel_slots) voxels[slot] = live[v] ? besti[v] : 0u;
+        /* brick minimum over the live voxel centres: d2 >= 0, so f32 bit patterns order like values */
+        uint32_t b = live[v] ? __float_as_uint(best[v]) : 0x7F7F7F7Fu;
+        for (int off = 32; off > 0; off >>= 1) b = min(b, (uint32_t)__shfl_down((int)b, off));
+        if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = b;
     }
+}
+
+/* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
+__global__ void k_unbrick(const uint32_t* __restrict__ bricked, const uint32_t* __restrict__ new2orig,
+                          grid_t g, int bx, int by, uint64_t count, uint32_t* __restrict__ dense) {
+    uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= count) return;
+    const uint64_t exy = (uint64_t)g.ex * g.ey;
+    uint32_t k = (uint32_t)(lin / exy);
+    uint32_t r = (uint32_t)(lin - (uint64_t)k * exy);
+    uint32_t j = r / (uint32_t)g.ex, i = r - j * (uint32_t)g.ex;
+    uint32_t brick = ((k >> 2) * (uint32_t)by + (j >> 2)) * (uint32_t)bx + (i >> 2);
+    uint32_t v = bricked[(uint64_t)brick * 64u + (((k & 3u) << 4) | ((j & 3u) << 2) | (i & 3u))];
+    dense[lin] = v == 0xFFFFFFFFu ? v : new2orig[v];
+}
+
+/* brick code = floor(lower bound of sqrt(min d2) / q), clamped to 255 */
+__global__ void k_brick_codes(const uint32_t* __restrict__ bits, uint32_t n, float q,
+                              unsigned char* __restrict__ code) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float d2 = __uint_as_float(bits[t]);
+    float d = sqrtf(d2) * 0.99999f;
+    float c = floorf(d / q);
+    code[t] = (unsigned char)(c >= 255.f ? 255u : (c > 0.f ? (uint32_t)c : 0u));
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -352,22 +402,62 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
     m->distance_step_count = distance_step_count;
     m->angle_step = angle_step;
     m->h_cloud.assign(surfels, surfels + (size_t)n * 12);
-    std::vector<float4> pos(n), ref(n), tan4(n);
-    for (uint32_t i = 0; i < n; ++i) {
+    /* internal order = Morton curve over the finite bounding box (non-finite points last) */
+    {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* s = surfels + (size_t)i * 12;
+            if (!fin3(s)) continue;
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = std::min(lo[d], (double)s[d]);
+                hi[d] = std::max(hi[d], (double)s[d]);
+            }
+        }
+        double ext = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        double inv = ext > 0.0 ? 2097151.0 / ext : 0.0;
+        std::vector<std::pair<uint64_t, uint32_t>> order(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* s = surfels + (size_t)i * 12;
+            uint64_t code = ~0ull;
+            if (fin3(s))
+                code = spread21((uint64_t)((s[0] - lo[0]) * inv)) | (spread21((uint64_t)((s[1] - lo[1]) * inv)) << 1) |
+                       (spread21((uint64_t)((s[2] - lo[2]) * inv)) << 2);
+            order[i] = {code, i};
+        }
+        std::sort(order.begin(), order.end());
+        m->h_new2orig.resize(n);
+        m->h_orig2new.resize(n);
+        for (uint32_t k = 0; k < n; ++k) {
+            m->h_new2orig[k] = order[k].second;
+            m->h_orig2new[order[k].second] = k;
+        }
+    }
+    std::vector<float4> pos(n), ref(n), tan4(n), vpos(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t i = m->h_new2orig[k];
         const float* s = surfels + (size_t)i * 12;
         f3 t = make3(s[9], s[10], s[11]);
         bool is_t = len(t) > 0.7f; /* reference include/impl/scene.hpp:469-470 */
-        pos[i] = make_float4(s[0], s[1], s[2], is_t ? 1.f : 0.f);
-        if (!fin3(s)) pos[i].x = std::numeric_limits<float>::quiet_NaN();
-        ref[i] = is_t ? make_float4(s[9], s[10], s[11], 0.f) : make_float4(s[4], s[5], s[6], 0.f);
-        tan4[i] = make_float4(s[9], s[10], s[11], 0.f);
+        pos[k] = make_float4(s[0], s[1], s[2], is_t ? 1.f : 0.f);
+        if (!fin3(s)) pos[k].x = std::numeric_limits<float>::quiet_NaN();
+        ref[k] = is_t ? make_float4(s[9], s[10], s[11], 0.f) : make_float4(s[4], s[5], s[6], 0.f);
+        tan4[k] = make_float4(s[9], s[10], s[11], 0.f);
+        float w;
+        memcpy(&w, &i, 4);
+        vpos[k] = make_float4(pos[k].x, s[1], s[2], w);
     }
     int rc;
-    if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n))) {
+    if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n)) ||
+        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n))) {
         tm_model_destroy(m);
         return rc;
     }
     hipError_t e = hipMemcpyAsync(m->pos.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->vpos.p, vpos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->new2orig.p, m->h_new2orig.data(), (size_t)n * 4, hipMemcpyHostToDevice,
+                           ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->ref.p, ref.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
@@ -398,7 +488,11 @@ int tm_model_destroy(tm_model* m) {
     m->pos.release();
     m->ref.release();
     m->tan4.release();
+    m->vpos.release();
+    m->new2orig.release();
     m->voxels.release();
+    m->brick_min_bits.release();
+    m->brick_code.release();
     m->seg_key.release();
     m->seg_begin.release();
     m->entries.release();
@@ -416,13 +510,24 @@ int tm_model_build_voxels(tm_model* m) {
     uint64_t count = (uint64_t)m->extents[0] * m->extents[1] * m->extents[2];
     /* the reference's voxel_count is a uint32_t (include/impl/model.hpp:65) */
     TM_REQUIRE(count <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid exceeds 2^32 cells");
-    TM_FORWARD(m->voxels.alloc(count));
     m->voxel_count = count;
+    for (int d = 0; d < 3; ++d) m->bdim[d] = (m->extents[d] + 3) / 4;
+    const uint64_t n_bricks64 = (uint64_t)m->bdim[0] * m->bdim[1] * m->bdim[2];
+    TM_REQUIRE(n_bricks64 * 64ull <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid exceeds 2^32 slots");
+    const uint32_t n_bricks = (uint32_t)n_bricks64;
+    m->voxel_slots = n_bricks64 * 64ull;
+    TM_FORWARD(m->voxels.alloc(m->voxel_slots));
+    TM_FORWARD(m->brick_min_bits.alloc(n_bricks));
+    TM_FORWARD(m->brick_code.alloc(n_bricks));
+    m->brick_q = 0.25f * m->resolution;
     uint64_t per_block = 256ull * kVoxVPT;
-    uint64_t blocks = (count + per_block - 1) / per_block;
+    uint64_t blocks = (m->voxel_slots + per_block - 1) / per_block;
     TM_REQUIRE(blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
-    hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->pos.p, m->n,
-                       m->grid, count, m->voxels.p);
+    hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->vpos.p, m->n,
+                       m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);
+    TM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_brick_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream,
+                       m->brick_min_bits.p, n_bricks, m->brick_q, m->brick_code.p);
     TM_HIP_CHECK(hipGetLastError());
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     m->voxels_ready = true;
@@ -494,7 +599,9 @@ int tm_model_build_pairs(tm_model* m, const uint32_t* subset, uint32_t n_t,
     TM_TRY(d_subset.alloc(n_t));
     TM_TRY(d_bounds.alloc(8));
     TM_TRY(d_counter.alloc(1));
-    TM_TRY_HIP(hipMemcpyAsync(d_subset.p, subset, (size_t)n_t * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> subset_new(n_t);
+    for (uint32_t i = 0; i < n_t; ++i) subset_new[i] = m->h_orig2new[subset[i]];
+    TM_TRY_HIP(hipMemcpyAsync(d_subset.p, subset_new.data(), (size_t)n_t * 4, hipMemcpyHostToDevice, c->stream));
     uint32_t init_bounds[8];
     for (int d = 0; d < 4; ++d) {
         init_bounds[d] = 0xFFFFFFFFu;
@@ -629,9 +736,20 @@ int tm_model_download_voxels(const tm_model* m, uint32_t* voxels, uint64_t cap, 
     if (!voxels) return TM_OK;
     TM_REQUIRE(cap >= m->voxel_count, TM_ERR_CAPACITY, "voxel buffer too small");
     TM_HIP_CHECK(hipSetDevice(m->ctx->device));
-    TM_HIP_CHECK(hipMemcpyAsync(voxels, m->voxels.p, m->voxel_count * 4, hipMemcpyDeviceToHost,
-                                m->ctx->stream));
-    TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    dbuf<uint32_t> dense;
+    TM_FORWARD(dense.alloc(m->voxel_count));
+    uint64_t blocks = (m->voxel_count + 255) / 256;
+    hipLaunchKernelGGL(k_unbrick, dim3((uint32_t)blocks), dim3(256), 0, m->ctx->stream, m->voxels.p,
+                       m->new2orig.p, m->grid, m->bdim[0], m->bdim[1], m->voxel_count, dense.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(voxels, dense.p, m->voxel_count * 4, hipMemcpyDeviceToHost, m->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->ctx->stream);
+    dense.release();
+    if (e != hipSuccess) {
+        set_error("tm_model_download_voxels: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
     return TM_OK;
 }
 
@@ -674,6 +792,7 @@ int tm_model_download_table(const tm_model* m, uint32_t* keys4, uint32_t* offset
         TM_HIP_CHECK(hipMemcpyAsync(pairs_ij, m->entries.p, m->n_entries * 8, hipMemcpyDeviceToHost,
                                     m->ctx->stream));
         TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        for (uint64_t k = 0; k < 2 * m->n_entries; ++k) pairs_ij[k] = m->h_new2orig[pairs_ij[k]];
     }
     return TM_OK;
 }
@@ -700,6 +819,7 @@ int tm_model_query_key(const tm_model* m, const uint32_t key[4], uint32_t* pairs
         TM_HIP_CHECK(hipMemcpyAsync(pairs_ij, m->entries.p + h_out[0], (size_t)take * 8,
                                     hipMemcpyDeviceToHost, c->stream));
         TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint32_t k = 0; k < 2 * take; ++k) pairs_ij[k] = m->h_new2orig[pairs_ij[k]];
     }
     return TM_OK;
 }
@@ -726,12 +846,14 @@ int tm_model_voxel_query(const tm_model* m, const float pos4[4], uint32_t* index
     float vz = g.sz * pos4[2] + g.tz * pos4[3];
     *found = 0;
     if (!(vx > -1.f && vx < g.fex && vy > -1.f && vy < g.fey && vz > -1.f && vz < g.fez)) return TM_OK;
-    size_t lin = (size_t)(int)vz * g.ex * g.ey + (size_t)(int)vy * g.ex + (size_t)(int)vx;
+    const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
+    const size_t brick = ((size_t)(iz >> 2) * m->bdim[1] + (iy >> 2)) * m->bdim[0] + (ix >> 2);
+    size_t lin = brick * 64 + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
     uint32_t v = 0;
     TM_HIP_CHECK(hipSetDevice(m->ctx->device));
     TM_HIP_CHECK(hipMemcpyAsync(&v, m->voxels.p + lin, 4, hipMemcpyDeviceToHost, m->ctx->stream));
     TM_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
-    *index = v;
+    *index = v < m->n ? m->h_new2orig[v] : v;
     *found = 1;
     return TM_OK;
 }

@@ -7,8 +7,10 @@
  * otan[n] float4 (tangent xyz, w = mask). Cell-sorted order (scoring): spos[n_pad] float4 (xyz,
  * w = bits of the original index; masked / padded / non-finite points carry NaN in x so that they
  * fail the in-grid test), sref[n_pad] float4 (tangent if tangent_mask else normal, w = tangent_mask),
- * cell_start[cells+2]. Points are sorted by uniform-grid cell (x fastest) so that a wave's 64 points
- * are spatial neighbours: the voxel-hit branch is then taken by whole waves or not at all.
+ * tiles[n_pad/64] float4 (bounding sphere of 64 consecutive sorted points). Points are sorted along a
+ * Morton curve so that a wave's 64 points are spatial neighbours: the voxel-hit branch is taken by
+ * whole waves or not at all, and a hypothesis can skip every tile whose sphere misses the model's
+ * voxel box.
  */
 #include <cstring>
 
@@ -67,6 +69,144 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
     if ((threadIdx.x & 63) == 0 && pass_total) atomicAdd(&a.stats[0], pass_total);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Culled scoring: one workgroup per hypothesis. Phase 1 tests every tile's bounding sphere against
+ * the model's voxel box under this pose (conservative margins, so no in-grid point is ever skipped)
+ * and compacts the surviving tile ids into LDS; phase 2 evaluates the surviving tiles, four tiles
+ * per wave iteration with predicated (branch-free) gathers so that four independent
+ * voxel -> model-point gather chains are in flight per lane. No atomics: one store per hypothesis.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kCullChunk = 4096; /* tiles culled per round: 16 KiB of LDS */
+
+struct cull_args {
+    const float4* tiles;
+    uint32_t n_tiles;
+    float coord_max; /* max |coordinate| of the scene, for the rounding margin */
+};
+
+__device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, float rnorm, float abs_eps,
+                                          float4 tb) {
+    f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
+    float rho = tb.w * rnorm * 1.0001f + abs_eps;
+    float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
+    float mx = a.g.sx * rho + 0.05f, my = a.g.sy * rho + 0.05f, mz = a.g.sz * rho + 0.05f;
+    return (tb.w >= 0.f) & (vx + mx > -1.f) & (vx - mx < a.g.fex) & (vy + my > -1.f) & (vy - my < a.g.fey) &
+           (vz + mz > -1.f) & (vz - mz < a.g.fez);
+}
+
+__global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
+    __shared__ uint32_t s_list[kCullChunk];
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_cnt[4], s_pass[4];
+    __shared__ unsigned long long s_fx[4];
+    /* XCD-aware block -> hypothesis map (speed only): blocks b and b+8 share an XCD's L2, and
+     * consecutive hypotheses come from the same scene sample pair, i.e. touch the same scene tiles and
+     * voxels. Give each XCD a contiguous run of hypotheses so those re-reads hit its L2. Bijective. */
+    uint32_t h;
+    {
+        const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        const uint32_t q = a.n_hyp >> 3, r = a.n_hyp & 7u;
+        h = x * q + min(x, r) + i;
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const pose12 T = load_pose(a.poses + (size_t)h * 16);
+    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                              T.r22 * T.r22);
+    const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
+    uint32_t cnt = 0, pass = 0, n_in = 0, n_near = 0;
+    long long fx = 0;
+    unsigned long long tiles_done = 0;
+    for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kCullChunk) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t t1 = min(t0 + (uint32_t)kCullChunk, ca.n_tiles);
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256) {
+            if (tile_hits(a, T, rnorm, abs_eps, ca.tiles[t])) s_list[atomicAdd(&s_n, 1u)] = t;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        tiles_done += n;
+        for (uint32_t i = wave * 4; i < n; i += 16) {
+            /* stage 1: load + transform + in-grid + brick code, 4 tiles */
+            f3 q[4];
+            uint32_t sidx[4], lin[4], m[4];
+            bool near[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool have = i + k < n;
+                sidx[k] = (have ? s_list[i + k] : s_list[i]) * 64u + lane;
+                float4 P = a.spos[sidx[k]];
+                q[k] = xform_point(T, make3(P.x, P.y, P.z));
+                float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
+                bool in = have & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
+                          (vz < a.g.fez);
+                uint32_t ix = in ? (uint32_t)(int)vx : 0u, iy = in ? (uint32_t)(int)vy : 0u,
+                         iz = in ? (uint32_t)(int)vz : 0u;
+                const uint32_t brick = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
+                uint32_t code = a.bcode[brick];
+                near[k] = in & (code <= a.code_max);
+                n_in += in ? 1u : 0u;
+                n_near += near[k] ? 1u : 0u;
+                lin[k] = near[k] ? brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)) : 0u;
+            }
+            /* stage 2: voxel gathers */
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = a.vox[lin[k]];
+            /* stage 3: model point gathers + distance test */
+            bool ok[4];
+            float mw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 mp = a.mpos[m[k]];
+                float dx = q[k].x - mp.x, dy = q[k].y - mp.y, dz = q[k].z - mp.z;
+                float d2 = (dx * dx + dy * dy) + dz * dz;
+                ok[k] = near[k] & (d2 <= a.d2max);
+                mw[k] = mp.w;
+            }
+            /* stage 4: orientation term for the distance-passing points */
+            if (__ballot(ok[0] | ok[1] | ok[2] | ok[3])) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (ok[k]) {
+                        ++pass;
+                        float4 sr = a.sref[sidx[k]];
+                        if (sr.w == mw[k]) {
+                            f3 r = xform_dir(T, make3(sr.x, sr.y, sr.z));
+                            float4 mr = a.mref[m[k]];
+                            float term = fabsf(dot3(r, make3(mr.x, mr.y, mr.z)));
+                            fx += (long long)((double)term * kFx);
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off);
+        pass += __shfl_down(pass, off);
+        fx += __shfl_down(fx, off);
+        n_in += __shfl_down(n_in, off);
+        n_near += __shfl_down(n_near, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&a.stats[2], (unsigned long long)n_in);
+        atomicAdd(&a.stats[3], (unsigned long long)n_near);
+        s_cnt[wave] = cnt;
+        s_pass[wave] = pass;
+        s_fx[wave] = (unsigned long long)fx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.counts[h] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        a.scores_fx[h] = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
+        atomicAdd(&a.stats[0], (unsigned long long)((s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3])));
+        atomicAdd(&a.stats[1], tiles_done * 64ull);
+    }
+}
+
 __global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uint32_t n, double inv_scale,
                                   double model_size, double* __restrict__ out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +244,8 @@ struct gen_args {
     const uint4* ht_key;
     uint32_t cap_mask;
     const uint32_t* seg_begin;
-    const uint2* entries;
+    const uint2* entries;       /* NEW model indices */
+    const uint32_t* new2orig;   /* model: internal -> original index */
     float lower2, upper2; /* squared diameter window, reference include/impl/scene.hpp:117-120 */
     float lo0, hi0;
     uint32_t steps;
@@ -178,7 +319,7 @@ __global__ void k_gen_emit(gen_args g, const uint2* __restrict__ ij, uint32_t n_
         dst[1] = make_float4(T[4], T[5], T[6], T[7]);
         dst[2] = make_float4(T[8], T[9], T[10], T[11]);
         dst[3] = make_float4(T[12], T[13], T[14], T[15]);
-        prov[t] = make_uint4(lo, mm.x, mm.y, e);
+        prov[t] = make_uint4(lo, g.new2orig[mm.x], g.new2orig[mm.y], e);
     }
 }
 
@@ -253,8 +394,20 @@ static inline bool fin3(const float* p) {
     return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
 }
 
-/* sort the scene by uniform-grid cell and upload the scoring arrays */
-static int build_sorted(tm_scene* s, float cell) {
+static inline uint64_t spread21(uint64_t v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+/* Sort the scene along a Morton curve (63-bit code over the finite bounding box) and upload the
+ * scoring arrays. 64 consecutive sorted points form a tile with a bounding sphere used by the
+ * culled kernel; masked and non-finite points carry NaN and never enter a sphere. */
+static int build_sorted(tm_scene* s) {
     tm_ctx* c = s->ctx;
     const uint32_t n = s->n;
     const float big = std::numeric_limits<float>::max();
@@ -267,49 +420,37 @@ static int build_sorted(tm_scene* s, float cell) {
             mx[d] = std::max(mx[d], p[d]);
         }
     }
-    if (mn[0] > mx[0]) {
+    if (mn[0] > mx[0])
         for (int d = 0; d < 3; ++d) mn[d] = mx[d] = 0.f;
-    }
-    float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-    if (!(cell > 0.f)) cell = ext > 0.f ? ext / 128.f : 1.f;
-    uint64_t dims[3];
-    for (;;) {
-        for (int d = 0; d < 3; ++d) dims[d] = (uint64_t)std::floor((mx[d] - mn[d]) / cell) + 1;
-        if (dims[0] * dims[1] * dims[2] <= (1ull << 24)) break;
-        cell *= 1.5f;
-    }
-    const uint32_t cells = (uint32_t)(dims[0] * dims[1] * dims[2]);
-    s->cell = cell;
-    for (int d = 0; d < 3; ++d) {
-        s->gmin[d] = mn[d];
-        s->gdim[d] = (int)dims[d];
-    }
-    std::vector<uint32_t> cid(n), start((size_t)cells + 2, 0u);
+    double ext = std::max(std::max((double)mx[0] - mn[0], (double)mx[1] - mn[1]), (double)mx[2] - mn[2]);
+    double inv = ext > 0.0 ? 2097151.0 / ext : 0.0;
+    float cmax = 0.f;
+    for (int d = 0; d < 3; ++d) cmax = std::max(cmax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
+    s->coord_max = cmax;
+    std::vector<std::pair<uint64_t, uint32_t>> order(n);
     for (uint32_t i = 0; i < n; ++i) {
         const float* p = s->h_cloud.data() + (size_t)i * 12;
-        uint32_t id = cells; /* non-finite points: trailing bucket */
+        uint64_t code = ~0ull; /* non-finite points sort last */
         if (fin3(p)) {
-            uint64_t ix = std::min<uint64_t>((uint64_t)((p[0] - mn[0]) / cell), dims[0] - 1);
-            uint64_t iy = std::min<uint64_t>((uint64_t)((p[1] - mn[1]) / cell), dims[1] - 1);
-            uint64_t iz = std::min<uint64_t>((uint64_t)((p[2] - mn[2]) / cell), dims[2] - 1);
-            id = (uint32_t)((iz * dims[1] + iy) * dims[0] + ix);
+            uint64_t ix = (uint64_t)(((double)p[0] - mn[0]) * inv);
+            uint64_t iy = (uint64_t)(((double)p[1] - mn[1]) * inv);
+            uint64_t iz = (uint64_t)(((double)p[2] - mn[2]) * inv);
+            code = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
         }
-        cid[i] = id;
-        start[(size_t)id + 1]++;
+        order[i] = {code, i};
     }
-    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
-    std::vector<uint32_t> perm(n), cursor(start.begin(), start.end() - 1);
-    for (uint32_t i = 0; i < n; ++i) perm[cursor[cid[i]]++] = i;
+    std::sort(order.begin(), order.end());
     const uint32_t n_pad = ((n + kScoreTile - 1) / kScoreTile) * kScoreTile;
+    const uint32_t n_tiles = n_pad / 64;
     const float nanv = std::numeric_limits<float>::quiet_NaN();
-    std::vector<float4> spos(n_pad), sref(n_pad);
+    std::vector<float4> spos(n_pad), sref(n_pad), tiles(n_tiles);
     for (uint32_t k = 0; k < n_pad; ++k) {
         if (k >= n) {
             spos[k] = make_float4(nanv, 0.f, 0.f, 0.f);
             sref[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
-        uint32_t i = perm[k];
+        uint32_t i = order[k].second;
         const float* p = s->h_cloud.data() + (size_t)i * 12;
         float w;
         memcpy(&w, &i, 4);
@@ -318,17 +459,43 @@ static int build_sorted(tm_scene* s, float cell) {
         bool ut = s->h_tmask[i] != 0;
         sref[k] = ut ? make_float4(p[9], p[10], p[11], 1.f) : make_float4(p[4], p[5], p[6], 0.f);
     }
+    for (uint32_t t = 0; t < n_tiles; ++t) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        int live = 0;
+        for (uint32_t k = t * 64; k < t * 64 + 64; ++k) {
+            if (!(spos[k].x == spos[k].x)) continue;
+            const float q[3] = {spos[k].x, spos[k].y, spos[k].z};
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = std::min(lo[d], (double)q[d]);
+                hi[d] = std::max(hi[d], (double)q[d]);
+            }
+            ++live;
+        }
+        if (!live) {
+            tiles[t] = make_float4(0.f, 0.f, 0.f, -1.f);
+            continue;
+        }
+        float cx = (float)(0.5 * (lo[0] + hi[0])), cy = (float)(0.5 * (lo[1] + hi[1])),
+              cz = (float)(0.5 * (lo[2] + hi[2]));
+        double r2 = 0.0;
+        for (uint32_t k = t * 64; k < t * 64 + 64; ++k) {
+            if (!(spos[k].x == spos[k].x)) continue;
+            double dx = (double)spos[k].x - cx, dy = (double)spos[k].y - cy, dz = (double)spos[k].z - cz;
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        float r = (float)(std::sqrt(r2) * (1.0 + 1e-6));
+        r = std::nextafter(r, std::numeric_limits<float>::infinity());
+        tiles[t] = make_float4(cx, cy, cz, r);
+    }
     TM_FORWARD(s->spos.ensure(n_pad));
     TM_FORWARD(s->sref.ensure(n_pad));
-    TM_FORWARD(s->perm.ensure(n));
-    TM_FORWARD(s->cell_start.ensure(start.size()));
+    TM_FORWARD(s->tiles.ensure(n_tiles));
     TM_HIP_CHECK(hipMemcpyAsync(s->spos.p, spos.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->sref.p, sref.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->perm.p, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->cell_start.p, start.data(), start.size() * 4, hipMemcpyHostToDevice,
-                                c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->tiles.p, tiles.data(), (size_t)n_tiles * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     s->n_sorted = n_pad;
+    s->n_tiles = n_tiles;
     return TM_OK;
 }
 
@@ -387,8 +554,22 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     a.scores_fx = s->w_scores_fx.p;
     a.stats = c->stats.p;
     a.g = m->grid;
-    a.d2max = sq_threshold(dist_thres * m->resolution); /* thres: reference :413 */
+    const float thres = dist_thres * m->resolution; /* reference :413 */
+    a.d2max = sq_threshold(thres);
     a.n_hyp = n_hyp;
+    /* brick filter: a voxel hit can be skipped when every voxel centre of its 4x4x4 brick is farther
+     * than thres + (largest distance from a voxel's centre to a point of its cell = sqrt(3) cells,
+     * the int cast truncates) from the model: then no model point is within thres of the query. */
+    const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
+    const float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
+    const bool culled = (mode != TM_SCORE_BRUTEFORCE) && !d_active;
+    a.bcode = culled ? m->brick_code.p : nullptr;
+    a.bx = m->bdim[0];
+    a.by = m->bdim[1];
+    {
+        float cm = std::floor((thres + slack) / m->brick_q) + 1.f;
+        a.code_max = (thres >= 0.f && cm < 255.f) ? (uint32_t)cm : 255u;
+    }
     const uint32_t tiles = s->n_sorted / kScoreTile;
     /* aim for >= ~8 workgroups per CU; keep chunks long enough to amortise the tile load */
     uint32_t want_chunks = std::max(1u, (256u * 16u + tiles - 1) / tiles);
@@ -397,25 +578,34 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     dim3 grid(tiles, (n_hyp + hpb - 1) / hpb);
     TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
     if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-    if (d_active)
+    if (culled) {
+        cull_args ca;
+        ca.tiles = s->tiles.p;
+        ca.n_tiles = s->n_tiles;
+        ca.coord_max = s->coord_max;
+        hipLaunchKernelGGL(k_score_culled, dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+    } else if (d_active) {
         hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
-    else
+    } else {
         hipLaunchKernelGGL(k_score_brute<false>, grid, dim3(256), 0, c->stream, a);
+    }
     TM_HIP_CHECK(hipGetLastError());
     if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     hipLaunchKernelGGL(k_finalize_scores, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream,
                        s->w_scores_fx.p, n_hyp, 1.0 / kFx, (double)m->n, d_scores);
     TM_HIP_CHECK(hipGetLastError());
     if (c->timing) {
-        unsigned long long h_stats[2] = {0, 0};
-        TM_HIP_CHECK(hipMemcpyAsync(h_stats, c->stats.p, 16, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long h_stats[4] = {0, 0, 0, 0};
+        TM_HIP_CHECK(hipMemcpyAsync(h_stats, c->stats.p, 32, hipMemcpyDeviceToHost, c->stream));
         TM_HIP_CHECK(hipStreamSynchronize(c->stream));
         float ms = 0.f;
         TM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last.ms = ms;
-        c->last.evaluations = (uint64_t)n_hyp * n_active;
+        c->last.evaluations = culled ? (uint64_t)h_stats[1] : (uint64_t)n_hyp * n_active;
         c->last.passing = h_stats[0];
         c->last.hypotheses = n_hyp;
+        if (getenv("TM_DEBUG_STATS"))
+            fprintf(stderr, "[tm] score: evals %llu in_grid %llu near %llu passing %llu ms %.3f\n", (unsigned long long)c->last.evaluations, h_stats[2], h_stats[3], h_stats[0], ms);
     }
     return TM_OK;
 }
@@ -451,6 +641,7 @@ static int generate_device(tm_scene* s, tm_model* m, const uint2* d_ij, uint32_t
     g.cap_mask = m->ht_cap - 1;
     g.seg_begin = m->seg_begin.p;
     g.entries = m->entries.p;
+    g.new2orig = m->new2orig.p;
     float lower = m->diameter * minf, upper = m->diameter * maxf;
     g.lower2 = lower * lower;
     g.upper2 = upper * upper;
@@ -558,7 +749,7 @@ int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t
     s->h_tmask.assign(tangent_mask, tangent_mask + n);
     s->h_mask.assign(n, 0);
     int rc = upload_original(s);
-    if (!rc) rc = build_sorted(s, 0.f);
+    if (!rc) rc = build_sorted(s);
     if (rc) {
         tm_scene_destroy(s);
         return rc;
@@ -576,8 +767,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->oref.release();
     s->spos.release();
     s->sref.release();
-    s->perm.release();
-    s->cell_start.release();
+    s->tiles.release();
     s->w_poses.release();
     s->w_counts.release();
     s->w_scores_fx.release();
@@ -598,7 +788,7 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
     else
         s->h_mask.assign(s->n, 0);
     TM_FORWARD(upload_original(s));
-    return build_sorted(s, s->cell);
+    return build_sorted(s);
 }
 
 uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
@@ -758,6 +948,10 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     a.d2max = sq_threshold(dist_thres * m->resolution);
     a.n_hyp = 1;
     a.hyp_per_block = 1;
+    a.bcode = nullptr; /* no brick filter here; bx/by still address the bricked voxel table */
+    a.bx = m->bdim[0];
+    a.by = m->bdim[1];
+    a.code_max = 255u;
     hipLaunchKernelGGL(k_extract, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_u32a.p);
     TM_HIP_CHECK(hipGetLastError());
@@ -776,7 +970,7 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
         for (uint32_t i = 0; i < s->n; ++i) { /* ascending scene index = reference scan order */
             if (match[i] == 0xFFFFFFFFu) continue;
             if (scene_corrs) scene_corrs[k] = i;
-            if (model_corrs) model_corrs[k] = match[i];
+            if (model_corrs) model_corrs[k] = m->h_new2orig[match[i]];
             ++k;
         }
     }

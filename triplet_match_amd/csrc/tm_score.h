@@ -21,6 +21,9 @@ struct score_args {
     const float4* mref;
     const uint32_t* vox;
     const unsigned char* active; /* per original index, or null */
+    const unsigned char* bcode;  /* brick distance codes, or null (filter off) */
+    int bx, by;                  /* brick grid dims (x, y) */
+    uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
     const float* poses;
     uint32_t* counts;
     unsigned long long* scores_fx;
@@ -43,8 +46,12 @@ __device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12
     bool in = (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez);
     if (in_grid) *in_grid = in;
     if (!in) return 0u;
-    uint32_t lin = ((uint32_t)(int)vz * (uint32_t)a.g.ey + (uint32_t)(int)vy) * (uint32_t)a.g.ex +
-                   (uint32_t)(int)vx;
+    const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
+    const uint32_t brick = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
+    if (a.bcode) { /* exact-safe: every model point is farther than thres from this voxel's cell */
+        if ((uint32_t)a.bcode[brick] > a.code_max) return 0u;
+    }
+    uint32_t lin = brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)); /* bricked layout */
     uint32_t m = a.vox[lin];
     float4 mp = a.mpos[m];
     float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
