@@ -237,6 +237,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
+    a.sc.ablate = 0;
     a.sc.bcode = nullptr; /* bx/by still address the bricked voxel table */
     a.sc.bx = m->bdim[0];
     a.sc.by = m->bdim[1];
@@ -244,7 +245,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.poses = d_poses.p;
     a.sc.counts = d_counts.p;
     a.sc.scores_fx = d_fx.p;
-    a.sc.stats = c->stats.p;
+    a.sc.stat_slots = nullptr;
     a.sc.g = m->grid;
     a.sc.d2max = sq_threshold(dist_thres * m->resolution);
     a.sc.n_hyp = n_hyp;

@@ -144,6 +144,7 @@ struct tm_scene {
     tmx::dbuf<float4> spos;       /* sorted xyz (masked / padding / non-finite -> NaN in x), w = bits of original index */
     tmx::dbuf<float4> sref;       /* sorted ref (tangent or normal), w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> tiles;      /* per tile: centre xyz, radius (negative = empty) */
+    tmx::dbuf<float4> supers;     /* per super-tile (64 tiles = 4096 points): bounding sphere */
     uint32_t n_sorted = 0;        /* padded point count (multiple of the brute-force tile) */
     uint32_t n_tiles = 0;         /* n_sorted / 64 */
     float coord_max = 0.f;        /* max |coordinate| over the finite points */
@@ -153,6 +154,7 @@ struct tm_scene {
     tmx::dbuf<unsigned long long> w_scores_fx;
     tmx::dbuf<double> w_scores;
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
+    tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
 };
 

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
     }
     const uint32_t h0 = blockIdx.y * a.hyp_per_block;
     const uint32_t h1 = min(h0 + a.hyp_per_block, a.n_hyp);
-    unsigned long long pass_total = 0;
+    uint32_t pass_total = 0;
     for (uint32_t h = h0; h < h1; ++h) {
         const pose12 T = load_pose(a.poses + (size_t)h * 16);
         uint32_t cnt = 0, pass = 0;
@@ -66,7 +66,12 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
             }
         }
     }
-    if ((threadIdx.x & 63) == 0 && pass_total) atomicAdd(&a.stats[0], pass_total);
+    __shared__ uint32_t s_pass[4];
+    if ((threadIdx.x & 63) == 0) s_pass[threadIdx.x >> 6] = pass_total;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.stat_slots[blockIdx.y * gridDim.x + blockIdx.x] =
+            make_uint4(0u, (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]), 0u, 0u);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -80,12 +85,36 @@ constexpr int kCullChunk = 4096; /* tiles culled per round: 16 KiB of LDS */
 
 struct cull_args {
     const float4* tiles;
+    const float4* supers; /* bounding spheres of 64-tile groups */
     uint32_t n_tiles;
     float coord_max; /* max |coordinate| of the scene, for the rounding margin */
+    float inv_q;     /* 1 / brick code quantum */
+    float tcode;     /* (thres + slack) / q + 1: a brick code above this is farther than thres */
 };
 
 __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, float rnorm, float abs_eps,
-                                          float4 tb) {
+                                          float ca_tcode, float ca_inv_q, float4 tb) {
+    f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
+    float rho = tb.w * rnorm * 1.0001f + abs_eps;
+    float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
+    float mx = a.g.sx * rho + 0.05f, my = a.g.sy * rho + 0.05f, mz = a.g.sz * rho + 0.05f;
+    bool hit = (tb.w >= 0.f) & (vx + mx > -1.f) & (vx - mx < a.g.fex) & (vy + my > -1.f) & (vy - my < a.g.fey) &
+               (vz + mz > -1.f) & (vz - mz < a.g.fez);
+    if (!hit) return false;
+    /* distance-field test: the NN distance is 1-Lipschitz, so every point x of the tile has
+     * NN(x) >= NN(c') - rho >= code(brick(c'))*q - sqrt(3)*cell - rho. If that exceeds thres no point of
+     * the tile can become a correspondence (slack and the +1 code of safety are inside tcode). */
+    if ((vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez)) {
+        const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
+        const float code = (float)a.bcode[((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2)];
+        if (code > ca_tcode + rho * ca_inv_q * 1.0001f) return false;
+    }
+    return true;
+}
+
+/* sphere vs voxel box only (super-tiles) */
+__device__ __forceinline__ bool sphere_hits_box(const score_args& a, const pose12& T, float rnorm,
+                                                float abs_eps, float4 tb) {
     f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
     float rho = tb.w * rnorm * 1.0001f + abs_eps;
     float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
@@ -97,6 +126,7 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
 __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
     __shared__ uint32_t s_list[kCullChunk];
     __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_smask;
     __shared__ uint32_t s_cnt[4], s_pass[4];
     __shared__ unsigned long long s_fx[4];
     /* XCD-aware block -> hypothesis map (speed only): blocks b and b+8 share an XCD's L2, and
@@ -109,6 +139,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
         h = x * q + min(x, r) + i;
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.ablate == 6) return;
     const pose12 T = load_pose(a.poses + (size_t)h * 16);
     const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
                               ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
@@ -118,41 +149,69 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
     long long fx = 0;
     unsigned long long tiles_done = 0;
     for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kCullChunk) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-        const uint32_t t1 = min(t0 + (uint32_t)kCullChunk, ca.n_tiles);
-        for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256) {
-            if (tile_hits(a, T, rnorm, abs_eps, ca.tiles[t])) s_list[atomicAdd(&s_n, 1u)] = t;
+        /* level 1: the chunk's 64 super-tiles (64 tiles each), one lane each, wave 0 */
+        if (wave == 0) {
+            const uint32_t u = (t0 >> 6) + lane;
+            bool hit = false;
+            if (u * 64u < ca.n_tiles) hit = sphere_hits_box(a, T, rnorm, abs_eps, ca.supers[u]);
+            unsigned long long mask = __ballot(hit);
+            if (lane == 0) {
+                s_smask = mask;
+                s_n = 0;
+            }
         }
         __syncthreads();
-        const uint32_t n = s_n;
+        const unsigned long long smask = s_smask;
+        /* level 2: wave w owns super-tiles w, w+4, ... of the chunk: wave-uniform skip */
+        for (uint32_t r = wave; r < (uint32_t)(kCullChunk / 64); r += 4) {
+            if (a.ablate == 5) break;
+            if (!((smask >> r) & 1ull)) continue;
+            const uint32_t t = t0 + r * 64u + lane;
+            if (t < ca.n_tiles && tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, ca.tiles[t]))
+                s_list[atomicAdd(&s_n, 1u)] = t;
+        }
+        __syncthreads();
+        const uint32_t n = a.ablate == 4 ? 0u : s_n;
         tiles_done += n;
         for (uint32_t i = wave * 4; i < n; i += 16) {
-            /* stage 1: load + transform + in-grid + brick code, 4 tiles */
+            /* stage 1: load 4 tiles' points, then transform + in-grid, then 4 brick-code loads */
             f3 q[4];
-            uint32_t sidx[4], lin[4], m[4];
-            bool near[4];
+            uint32_t sidx[4], lin[4], m[4], brick[4];
+            bool near[4], in[4];
+            float4 P[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bool have = i + k < n;
                 sidx[k] = (have ? s_list[i + k] : s_list[i]) * 64u + lane;
-                float4 P = a.spos[sidx[k]];
-                q[k] = xform_point(T, make3(P.x, P.y, P.z));
-                float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
-                bool in = have & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
-                          (vz < a.g.fez);
-                uint32_t ix = in ? (uint32_t)(int)vx : 0u, iy = in ? (uint32_t)(int)vy : 0u,
-                         iz = in ? (uint32_t)(int)vz : 0u;
-                const uint32_t brick = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
-                uint32_t code = a.bcode[brick];
-                near[k] = in & (code <= a.code_max);
-                n_in += in ? 1u : 0u;
-                n_near += near[k] ? 1u : 0u;
-                lin[k] = near[k] ? brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)) : 0u;
+                P[k] = a.spos[sidx[k]];
+                in[k] = have;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k] = xform_point(T, make3(P[k].x, P[k].y, P[k].z));
+                float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
+                in[k] = in[k] & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
+                        (vz < a.g.fez);
+                uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
+                         iz = in[k] ? (uint32_t)(int)vz : 0u;
+                brick[k] = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
+                lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
+            }
+            uint32_t code[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) code[k] = a.bcode[brick[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                near[k] = in[k] & (code[k] <= a.code_max);
+                n_in += in[k] ? 1u : 0u;
+                n_near += near[k] ? 1u : 0u;
+                lin[k] = near[k] ? lin[k] : 0u;
+            }
+            if (a.ablate == 3) { cnt += near[0] + near[1] + near[2] + near[3]; continue; }
             /* stage 2: voxel gathers */
 #pragma unroll
             for (int k = 0; k < 4; ++k) m[k] = a.vox[lin[k]];
+            if (a.ablate == 2) { cnt += m[0] + m[1] + m[2] + m[3]; continue; }
             /* stage 3: model point gathers + distance test */
             bool ok[4];
             float mw[4];
@@ -164,6 +223,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                 ok[k] = near[k] & (d2 <= a.d2max);
                 mw[k] = mp.w;
             }
+            if (a.ablate == 1) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
             /* stage 4: orientation term for the distance-passing points */
             if (__ballot(ok[0] | ok[1] | ok[2] | ok[3])) {
 #pragma unroll
@@ -191,9 +251,10 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
         n_in += __shfl_down(n_in, off);
         n_near += __shfl_down(n_near, off);
     }
+    __shared__ uint32_t s_in[4], s_near[4];
     if (lane == 0) {
-        atomicAdd(&a.stats[2], (unsigned long long)n_in);
-        atomicAdd(&a.stats[3], (unsigned long long)n_near);
+        s_in[wave] = n_in;
+        s_near[wave] = n_near;
         s_cnt[wave] = cnt;
         s_pass[wave] = pass;
         s_fx[wave] = (unsigned long long)fx;
@@ -202,8 +263,9 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
     if (threadIdx.x == 0) {
         a.counts[h] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
         a.scores_fx[h] = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
-        atomicAdd(&a.stats[0], (unsigned long long)((s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3])));
-        atomicAdd(&a.stats[1], tiles_done * 64ull);
+        a.stat_slots[h] = make_uint4((uint32_t)(tiles_done * 64ull), (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]),
+                                     (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]),
+                                     (s_near[0] + s_near[1]) + (s_near[2] + s_near[3]));
     }
 }
 
@@ -487,9 +549,42 @@ static int build_sorted(tm_scene* s) {
         r = std::nextafter(r, std::numeric_limits<float>::infinity());
         tiles[t] = make_float4(cx, cy, cz, r);
     }
+    /* super-tiles: 64 consecutive tiles (one culling chunk row); sphere over the live points */
+    const uint32_t n_super = (n_tiles + 63) / 64;
+    std::vector<float4> supers(n_super);
+    for (uint32_t u = 0; u < n_super; ++u) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        int live = 0;
+        const uint32_t k0 = u * 4096u, k1 = std::min(k0 + 4096u, n_pad);
+        for (uint32_t k = k0; k < k1; ++k) {
+            if (!(spos[k].x == spos[k].x)) continue;
+            const float q[3] = {spos[k].x, spos[k].y, spos[k].z};
+            for (int d = 0; d < 3; ++d) {
+                lo[d] = std::min(lo[d], (double)q[d]);
+                hi[d] = std::max(hi[d], (double)q[d]);
+            }
+            ++live;
+        }
+        if (!live) {
+            supers[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+            continue;
+        }
+        float cx = (float)(0.5 * (lo[0] + hi[0])), cy = (float)(0.5 * (lo[1] + hi[1])),
+              cz = (float)(0.5 * (lo[2] + hi[2]));
+        double r2 = 0.0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            if (!(spos[k].x == spos[k].x)) continue;
+            double dx = (double)spos[k].x - cx, dy = (double)spos[k].y - cy, dz = (double)spos[k].z - cz;
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        float r = (float)(std::sqrt(r2) * (1.0 + 1e-6));
+        supers[u] = make_float4(cx, cy, cz, std::nextafter(r, std::numeric_limits<float>::infinity()));
+    }
     TM_FORWARD(s->spos.ensure(n_pad));
     TM_FORWARD(s->sref.ensure(n_pad));
     TM_FORWARD(s->tiles.ensure(n_tiles));
+    TM_FORWARD(s->supers.ensure(n_super));
+    TM_HIP_CHECK(hipMemcpyAsync(s->supers.p, supers.data(), (size_t)n_super * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->spos.p, spos.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->sref.p, sref.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->tiles.p, tiles.data(), (size_t)n_tiles * 16, hipMemcpyHostToDevice, c->stream));
@@ -541,7 +636,6 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_FORWARD(s->w_scores_fx.ensure(n_hyp));
     TM_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)n_hyp * 4, c->stream));
     TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, (size_t)n_hyp * 8, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(c->stats.p, 0, 16 * 8, c->stream));
     score_args a;
     a.spos = s->spos.p;
     a.sref = s->sref.p;
@@ -552,11 +646,11 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     a.poses = d_poses;
     a.counts = d_counts;
     a.scores_fx = s->w_scores_fx.p;
-    a.stats = c->stats.p;
     a.g = m->grid;
     const float thres = dist_thres * m->resolution; /* reference :413 */
     a.d2max = sq_threshold(thres);
     a.n_hyp = n_hyp;
+    a.ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
     /* brick filter: a voxel hit can be skipped when every voxel centre of its 4x4x4 brick is farther
      * than thres + (largest distance from a voxel's centre to a point of its cell = sqrt(3) cells,
      * the int cast truncates) from the model: then no model point is within thres of the query. */
@@ -577,12 +671,19 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     a.hyp_per_block = hpb;
     dim3 grid(tiles, (n_hyp + hpb - 1) / hpb);
     TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
+    const size_t n_slots = culled ? (size_t)n_hyp : (size_t)grid.x * grid.y;
+    TM_FORWARD(s->w_stats.ensure(n_slots));
+    a.stat_slots = s->w_stats.p;
     if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     if (culled) {
         cull_args ca;
         ca.tiles = s->tiles.p;
+        ca.supers = s->supers.p;
         ca.n_tiles = s->n_tiles;
         ca.coord_max = s->coord_max;
+        ca.inv_q = 1.f / m->brick_q;
+        ca.tcode = (thres + slack) / m->brick_q + 1.f;
+        if (!(thres >= 0.f)) ca.tcode = 1e30f;
         hipLaunchKernelGGL(k_score_culled, dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
     } else if (d_active) {
         hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
@@ -595,9 +696,17 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                        s->w_scores_fx.p, n_hyp, 1.0 / kFx, (double)m->n, d_scores);
     TM_HIP_CHECK(hipGetLastError());
     if (c->timing) {
-        unsigned long long h_stats[4] = {0, 0, 0, 0};
-        TM_HIP_CHECK(hipMemcpyAsync(h_stats, c->stats.p, 32, hipMemcpyDeviceToHost, c->stream));
+        std::vector<uint4> slots(n_slots);
+        TM_HIP_CHECK(hipMemcpyAsync(slots.data(), s->w_stats.p, n_slots * sizeof(uint4), hipMemcpyDeviceToHost,
+                                    c->stream));
         TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        unsigned long long h_stats[4] = {0, 0, 0, 0};
+        for (const uint4& v : slots) {
+            h_stats[1] += v.x;
+            h_stats[0] += v.y;
+            h_stats[2] += v.z;
+            h_stats[3] += v.w;
+        }
         float ms = 0.f;
         TM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->last.ms = ms;
@@ -768,6 +877,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->spos.release();
     s->sref.release();
     s->tiles.release();
+    s->supers.release();
     s->w_poses.release();
     s->w_counts.release();
     s->w_scores_fx.release();
@@ -775,6 +885,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_u32a.release();
     s->w_u32b.release();
     s->w_u32c.release();
+    s->w_stats.release();
     s->w_pairs.release();
     delete s;
     return TM_OK;
@@ -943,11 +1054,12 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     a.poses = s->w_poses.p;
     a.counts = s->w_counts.p;
     a.scores_fx = s->w_scores_fx.p;
-    a.stats = c->stats.p;
     a.g = m->grid;
     a.d2max = sq_threshold(dist_thres * m->resolution);
     a.n_hyp = 1;
     a.hyp_per_block = 1;
+    a.ablate = 0;
+    a.stat_slots = nullptr;
     a.bcode = nullptr; /* no brick filter here; bx/by still address the bricked voxel table */
     a.bx = m->bdim[0];
     a.by = m->bdim[1];

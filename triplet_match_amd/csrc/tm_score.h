@@ -24,10 +24,12 @@ struct score_args {
     const unsigned char* bcode;  /* brick distance codes, or null (filter off) */
     int bx, by;                  /* brick grid dims (x, y) */
     uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
+    int ablate;                  /* timing experiments only (TM_ABLATE): 0 = full kernel */
     const float* poses;
     uint32_t* counts;
     unsigned long long* scores_fx;
-    unsigned long long* stats; /* [0] = distance-passing evaluations */
+    uint4* stat_slots; /* one slot per workgroup (plain stores, no contention): evaluations, distance-passing,
+                          in-grid, near; summed on the host only when timing is enabled */
     grid_t g;
     float d2max; /* largest f32 whose sqrtf is <= thres: d2 <= d2max <=> !(sqrtf(d2) > thres) */
     uint32_t n_hyp;
