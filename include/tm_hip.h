@@ -139,6 +139,12 @@ int tm_scene_destroy(tm_scene* scene);
 int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);
 uint32_t tm_scene_size(const tm_scene* scene);
 
+/* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
+ * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same
+ * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */
+int tm_pair_is_valid_sample(const tm_scene* scene, const tm_model* model, uint32_t i, uint32_t j,
+                            float min_diameter_factor, float max_diameter_factor);
+
 /* hypothesis generation: inner body of find_in_subset, include/impl/scene.hpp:288-319, for an
  * ordered batch of scene (i,j) sample pairs: filters -> feature -> valid -> query (first
  * query_limit entries) -> base_transform_ -> optional force_up. Output compacted in visit order:

@@ -1,0 +1,237 @@
+/*
+ * triplet_match/scene.hpp — scene<Point> of the drop-in API over the C ABI.
+ * Mirrors include/scene:10-59 / include/impl/scene.hpp: same constructor, find_all_parallel(),
+ * instantiate(), cloud() and match_t. The search orchestration is search.hpp (host logic); descriptor
+ * match, hypothesis generation, inlier scoring and correspondence extraction run as HIP kernels.
+ */
+#ifndef TRIPLET_MATCH_SCENE_HPP_
+#define TRIPLET_MATCH_SCENE_HPP_
+
+#include <unordered_map>
+
+#include "model.hpp"
+#include "search.hpp"
+
+namespace triplet_match {
+
+namespace detail {
+
+/* search.hpp backend over libtm_hip.so */
+template <typename Point>
+struct hip_backend {
+    tm_scene* s;
+    tm_model* m;
+    const pointcloud<Point>* scloud;
+    const pointcloud<Point>* mcloud;
+    uint32_t n_t;
+    float diam;
+    search::params_t p;
+    /* uniform grid for radius_search_inclusive (include/impl/scene.hpp:273): exact membership */
+    float cell = 0.f;
+    float gmin[3];
+    std::unordered_map<uint64_t, std::vector<uint32_t>> grid;
+
+    uint32_t scene_size() const { return (uint32_t)scloud->size(); }
+    uint32_t model_size() const { return (uint32_t)mcloud->size(); }
+    uint32_t model_point_count() const { return n_t; }
+    float model_diameter() const { return diam; }
+    const float* scene_surfel(uint32_t i) const { return scloud->points[i].raw(); }
+    const float* model_surfel(uint32_t i) const { return mcloud->points[i].raw(); }
+    bool pair_is_valid_sample(uint32_t i, uint32_t j) const {
+        return tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor) != 0;
+    }
+    static uint64_t pack(int64_t a, int64_t b, int64_t c) {
+        return ((uint64_t)(a + 1) << 42) ^ ((uint64_t)(b + 1) << 21) ^ (uint64_t)(c + 1);
+    }
+    void build_grid(float radius) {
+        cell = radius;
+        gmin[0] = gmin[1] = gmin[2] = std::numeric_limits<float>::max();
+        for (const auto& q : scloud->points) {
+            if (!q.getVector3fMap().allFinite()) continue;
+            gmin[0] = std::min(gmin[0], q.x);
+            gmin[1] = std::min(gmin[1], q.y);
+            gmin[2] = std::min(gmin[2], q.z);
+        }
+        grid.clear();
+        for (uint32_t i = 0; i < scloud->size(); ++i) {
+            const auto& q = scloud->points[i];
+            if (!q.getVector3fMap().allFinite()) continue;
+            grid[pack((int64_t)std::floor((q.x - gmin[0]) / cell), (int64_t)std::floor((q.y - gmin[1]) / cell),
+                      (int64_t)std::floor((q.z - gmin[2]) / cell))]
+                .push_back(i);
+        }
+    }
+    void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
+        if (cell != radius || grid.empty()) build_grid(radius);
+        out.clear();
+        const auto& c = scloud->points[i];
+        const float r2 = radius * radius;
+        int64_t k[3] = {(int64_t)std::floor((c.x - gmin[0]) / cell), (int64_t)std::floor((c.y - gmin[1]) / cell),
+                        (int64_t)std::floor((c.z - gmin[2]) / cell)};
+        for (int64_t a = k[0] - 1; a <= k[0] + 1; ++a)
+            for (int64_t b = k[1] - 1; b <= k[1] + 1; ++b)
+                for (int64_t d = k[2] - 1; d <= k[2] + 1; ++d) {
+                    auto it = grid.find(pack(a, b, d));
+                    if (it == grid.end()) continue;
+                    for (uint32_t j : it->second) {
+                        const auto& q = scloud->points[j];
+                        float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+                        if ((dx * dx + dy * dy) + dz * dz <= r2) out.push_back((int32_t)j);
+                    }
+                }
+        std::sort(out.begin(), out.end());
+    }
+    void generate(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses) {
+        const uint32_t n_pairs = (uint32_t)(ij.size() / 2);
+        const uint32_t cap = n_pairs * (uint32_t)search::query_limit;
+        poses.resize(cap);
+        std::vector<uint32_t> prov(4 * (size_t)cap);
+        uint32_t count = 0, total = 0;
+        check(tm_generate_hypotheses(s, m, ij.data(), n_pairs, p.min_diameter_factor, p.max_diameter_factor,
+                                     p.force_up ? 1 : 0, search::query_limit, &poses[0].m[0], prov.data(), cap,
+                                     &count, &total),
+              "tm_generate_hypotheses");
+        poses.resize(count);
+    }
+    void score(const std::vector<search::pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
+               std::vector<uint32_t>& counts, std::vector<double>& scores) {
+        const uint32_t n = (uint32_t)poses.size();
+        counts.assign(n, 0u);
+        scores.assign(n, 0.0);
+        if (early_drop) {
+            std::vector<int32_t> dropped(n);
+            std::vector<uint32_t> saved(n);
+            check(tm_score_hypotheses_early_drop(s, m, &poses[0].m[0], n, subset.data(), (uint32_t)subset.size(),
+                                                 p.dist_thres, p.accept_prob, counts.data(), scores.data(),
+                                                 dropped.data(), saved.data()),
+                  "tm_score_hypotheses_early_drop");
+        } else {
+            check(tm_score_hypotheses(s, m, TM_TRAITS_IDENTITY, &poses[0].m[0], n, subset.data(),
+                                      (uint32_t)subset.size(), p.dist_thres, TM_SCORE_AUTO, counts.data(),
+                                      scores.data()),
+                  "tm_score_hypotheses");
+        }
+    }
+    void extract(const search::pose_t& T, float dist_thres, search::candidate_t& out) {
+        const uint32_t cap = (uint32_t)scloud->size();
+        out.transform = T;
+        out.scene_corrs.resize(cap);
+        out.model_corrs.resize(cap);
+        uint32_t count = 0;
+        check(tm_extract_correspondences(s, m, T.m, dist_thres, out.scene_corrs.data(), out.model_corrs.data(), cap,
+                                         &count, &out.signed_score),
+              "tm_extract_correspondences");
+        out.scene_corrs.resize(count);
+        out.model_corrs.resize(count);
+    }
+    void set_mask(const std::vector<int32_t>& mask) { check(tm_scene_set_mask(s, mask.data()), "tm_scene_set_mask"); }
+};
+
+}  // namespace detail
+
+template <typename Point>
+class scene {
+public:
+    typedef std::unique_ptr<scene<Point>> uptr_t;
+    typedef std::shared_ptr<scene<Point>> sptr_t;
+    typedef model<Point> model_t;
+    typedef pointcloud<Point> cloud_t;
+
+    typedef struct match_ { /* include/scene:23-28 */
+        mat4f_t transform;
+        subset_t scene_corrs;
+        subset_t model_corrs;
+        double signed_score;
+    } match_t;
+
+    struct statistics {
+        double rejection_rate;
+    };
+
+    explicit scene(typename cloud_t::Ptr cloud, int device = 0)
+        : cloud_(cloud), ctx_(detail::default_context(device)) {
+        static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
+        if (!cloud_ || cloud_->size() == 0) throw std::runtime_error("scene: empty cloud");
+    }
+    virtual ~scene() { tm_scene_destroy(h_); }
+    scene(const scene&) = delete;
+    scene& operator=(const scene&) = delete;
+
+    /* the curvature-ratio half of tangent_mask_ (include/impl/scene.hpp:50) is a "next" row; supply one
+     * flag per point to apply it */
+    void set_curvature_ok(const std::vector<uint8_t>& ok) { curvature_ok_ = ok; }
+    void set_workers(uint32_t w) { workers_ = w; }
+
+    /* include/impl/scene.hpp:39-98 */
+    std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
+                                           float early_out_factor, const sample_parameters& sample_params,
+                                           uint32_t max_icp_iterations) {
+        const uint32_t n = (uint32_t)cloud_->size();
+        std::vector<int32_t> tangent_mask(n, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
+            if (t && !curvature_ok_.empty() && !curvature_ok_[i]) t = false;
+            tangent_mask[i] = t ? 1 : 0;
+        }
+        if (h_) tm_scene_destroy(h_);
+        h_ = nullptr;
+        detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
+                      "tm_scene_create");
+        detail::hip_backend<Point> be;
+        be.s = h_;
+        be.m = m.handle();
+        be.scloud = cloud_.get();
+        be.mcloud = m.cloud().get();
+        be.n_t = m.point_count();
+        be.diam = m.diameter();
+        be.p.dist_thres = dist_thres;
+        be.p.accept_prob = model_match_factor;
+        be.p.early_out_factor = early_out_factor;
+        be.p.min_diameter_factor = sample_params.min_diameter_factor;
+        be.p.max_diameter_factor = sample_params.max_diameter_factor;
+        be.p.force_up = sample_params.force_up;
+        be.p.max_icp_iterations = max_icp_iterations;
+        be.p.workers = workers_;
+        auto found = search::find_all(be, tangent_mask, be.p);
+        std::vector<match_t> results;
+        for (auto& c : found) {
+            match_t r;
+            memcpy(r.transform.m, c.transform.m, 64);
+            r.transform = r.transform.inverse(); /* :92: model -> scene */
+            r.scene_corrs = std::move(c.scene_corrs);
+            r.model_corrs = std::move(c.model_corrs);
+            r.signed_score = c.signed_score;
+            results.push_back(std::move(r));
+        }
+        return results;
+    }
+
+    /* include/impl/scene.hpp:512-531 (instantiate_all == false returns an empty cloud there too) */
+    typename cloud_t::Ptr instantiate(model<Point>& m, const match_t& match, bool instantiate_all = false) {
+        typename cloud_t::Ptr inst = cloud_t::empty();
+        if (!instantiate_all) return inst;
+        for (const auto& mp : m.cloud()->points) {
+            vec4f_t q = match.transform * homogeneous(mp.getVector3fMap());
+            Point o;
+            o.x = q[0];
+            o.y = q[1];
+            o.z = q[2];
+            inst->push_back(o);
+        }
+        return inst;
+    }
+
+    typename cloud_t::ConstPtr cloud() const { return cloud_; }
+    tm_scene* handle() const { return h_; }
+
+protected:
+    typename cloud_t::Ptr cloud_;
+    std::shared_ptr<detail::context_holder> ctx_;
+    tm_scene* h_ = nullptr;
+    std::vector<uint8_t> curvature_ok_;
+    uint32_t workers_ = 7;
+};
+
+}  // namespace triplet_match
+
+#endif

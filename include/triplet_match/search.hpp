@@ -1,0 +1,340 @@
+/*
+ * triplet_match/search.hpp — backend-agnostic host orchestration of the RANSAC search.
+ *
+ * Restates scene<Point>::impl::find_all_parallel / find_parallel / find_in_subset / icp_ of the
+ * reference (include/impl/scene.hpp:39-98, 108-240, 242-367, 369-404). All heavy work goes through a
+ * Backend (query + hypothesis generation, batched scoring, correspondence extraction); the product
+ * backend is the HIP C ABI (scene.hpp), tests also run this code over the CPU oracle to check the host
+ * logic without a GPU.
+ *
+ * Where the reference is non-deterministic or third-party-defined this file fixes a definition
+ * (SURVEY.md Appendix A, Q10):
+ *   - RNG: std::mt19937 seeded with 13 (the reference's `deterministic` branch, :123,245); draws are
+ *     `rng() % k` in a partial Fisher-Yates shuffle (range-v3's view::sample / action::shuffle are
+ *     unpinned);
+ *   - workers: the reference splits the outer sample over hardware_concurrency()-1 threads and each
+ *     returns its own first sufficient hypothesis; `workers` is an explicit parameter here (default 7);
+ *   - radius_search_inclusive(diameter, p1): membership d2 <= r*r, ascending index order.
+ */
+#ifndef TRIPLET_MATCH_SEARCH_HPP_
+#define TRIPLET_MATCH_SEARCH_HPP_
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <set>
+#include <vector>
+
+namespace triplet_match {
+namespace search {
+
+constexpr double match_probability = 0.999;   /* include/impl/scene.hpp:14 */
+constexpr uint64_t min_sample_count = 10ull;  /* :15 */
+constexpr int query_limit = 200;              /* :19 */
+
+struct pose_t {
+    float m[16];
+};
+
+struct candidate_t { /* match_t with the scene->model transform (inverted once at :92) */
+    pose_t transform;
+    std::vector<uint32_t> scene_corrs, model_corrs;
+    double signed_score = 0.0;
+};
+
+struct params_t {
+    float dist_thres = 3.f;
+    float accept_prob = 0.5f; /* model_match_factor */
+    float early_out_factor = 0.9f;
+    float min_diameter_factor = 0.2f, max_diameter_factor = 1.0f;
+    bool force_up = false;
+    uint32_t max_icp_iterations = 0;
+    uint32_t workers = 7;
+    uint64_t seed = 13;
+    bool early_drop = true; /* detail::early_drop, :25 */
+};
+
+/*
+ * Backend concept:
+ *   uint32_t scene_size(); uint32_t model_size(); uint32_t model_point_count(); float model_diameter();
+ *   const float* scene_surfel(uint32_t i);            // 12 floats
+ *   bool pair_is_valid_sample(uint32_t i, uint32_t j);// filters :290-297 + feature/valid :299-302
+ *   void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out);
+ *   void generate(const std::vector<uint32_t>& ij, std::vector<pose_t>& poses);   // visit order
+ *   void score(const std::vector<pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
+ *              std::vector<uint32_t>& counts, std::vector<double>& scores);       // project_ per pose
+ *   void extract(const pose_t& T, float dist_thres, candidate_t& out);            // finish_find
+ *   void set_mask(const std::vector<int32_t>& mask);
+ */
+
+namespace detail {
+
+/* Horn's closed form (unit quaternion = dominant eigenvector of the 4x4 N matrix, Jacobi sweeps in
+ * double): rigid T minimising sum |mdl - T*scn|^2, the no-scale case of Eigen::umeyama (:393) */
+inline pose_t rigid_fit(const std::vector<double>& scn, const std::vector<double>& mdl) {
+    const size_t n = scn.size() / 3;
+    double cs[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) {
+            cs[d] += scn[3 * i + d];
+            cm[d] += mdl[3 * i + d];
+        }
+    for (int d = 0; d < 3; ++d) {
+        cs[d] /= (double)n;
+        cm[d] /= (double)n;
+    }
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (size_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) S[a][b] += (scn[3 * i + a] - cs[a]) * (mdl[3 * i + b] - cm[b]);
+    double N[4][4] = {
+        {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+        {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+        {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+        {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) off += N[p][q] * N[p][q];
+        if (off < 1e-30) break;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (std::fabs(N[p][q]) < 1e-300) continue;
+                double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    double a = N[k][p], b = N[k][q];
+                    N[k][p] = c * a - s * b;
+                    N[k][q] = s * a + c * b;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    double a = N[p][k], b = N[q][k];
+                    N[p][k] = c * a - s * b;
+                    N[q][k] = s * a + c * b;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    double a = V[k][p], b = V[k][q];
+                    V[k][p] = c * a - s * b;
+                    V[k][q] = s * a + c * b;
+                }
+            }
+    }
+    int best = 0;
+    for (int k = 1; k < 4; ++k)
+        if (N[k][k] > N[best][best]) best = k;
+    double q0 = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
+    double nq = std::sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
+    q0 /= nq, qx /= nq, qy /= nq, qz /= nq;
+    double R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * q0), 2 * (qx * qz + qy * q0)},
+                      {2 * (qx * qy + qz * q0), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * q0)},
+                      {2 * (qx * qz - qy * q0), 2 * (qy * qz + qx * q0), 1 - 2 * (qx * qx + qy * qy)}};
+    pose_t T;
+    for (int i = 0; i < 16; ++i) T.m[i] = 0.f;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T.m[c * 4 + r] = (float)R[r][c];
+        T.m[12 + r] = (float)(cm[r] - (R[r][0] * cs[0] + R[r][1] * cs[1] + R[r][2] * cs[2]));
+    }
+    T.m[15] = 1.f;
+    return T;
+}
+
+/* first `count` elements become a uniform sample in random order (sample + shuffle, :143-144) */
+template <typename T>
+inline void partial_shuffle(std::vector<T>& v, size_t count, std::mt19937& rng) {
+    const size_t n = v.size();
+    for (size_t k = 0; k < count && k + 1 < n; ++k) {
+        size_t j = k + (size_t)(rng() % (uint32_t)(n - k));
+        std::swap(v[k], v[j]);
+    }
+}
+
+}  // namespace detail
+
+/* find_in_subset, include/impl/scene.hpp:242-367 */
+template <class Backend>
+inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
+    Backend& be, const std::vector<uint32_t>& firsts, const std::vector<int32_t>& mask,
+    const std::vector<int32_t>& fp_mask, const std::vector<int32_t>& tangent_mask, const params_t& p) {
+    std::mt19937 rng;
+    rng.seed((uint32_t)p.seed);
+    std::vector<pose_t> best_ts;
+    uint32_t cons = 0;
+    const uint32_t n_model_all = be.model_size();
+    const float sufficient = p.accept_prob * (float)n_model_all; /* :331, size_t > float in float */
+    std::vector<int32_t> nn;
+    std::vector<uint32_t> ij;
+    std::vector<pose_t> poses;
+    std::vector<uint32_t> counts;
+    std::vector<double> scores;
+    for (uint32_t i : firsts) {
+        if (fp_mask[i] || mask[i]) continue; /* :268 */
+        ++cons;
+        be.radius_subset(i, be.model_diameter(), nn); /* :273 */
+        if (nn.empty()) continue;
+        double prob = (double)n_model_all / (double)nn.size();
+        uint64_t inner_bound = (uint64_t)(-std::log(1.0 - match_probability) / prob); /* :277 */
+        inner_bound = std::max(inner_bound, min_sample_count);
+        inner_bound = std::min<uint64_t>(inner_bound, nn.size());
+        std::vector<int32_t> inner0(nn.begin(), nn.end());
+        detail::partial_shuffle(inner0, inner0.size(), rng); /* :285 */
+        if (!best_ts.empty()) continue; /* the reference keeps looping without effect once a candidate
+                                           exists (best_ts.empty() gates :331; early-out is unreachable,
+                                           SURVEY Q8): skip the dead work, keep `cons` and the rng stream */
+        /* the valid samples of this first point, up to inner_bound + 1 (:305, :350) */
+        ij.clear();
+        uint32_t valid_samples = 0;
+        for (int32_t j : inner0) {
+            if (!tangent_mask[j] || mask[j] || i == (uint32_t)j) continue; /* :290 */
+            if (!be.pair_is_valid_sample(i, (uint32_t)j)) continue;         /* :293-302 */
+            ij.push_back(i);
+            ij.push_back((uint32_t)j);
+            ++valid_samples;
+            if (valid_samples > inner_bound) break; /* :350 */
+        }
+        if (ij.empty()) continue;
+        be.generate(ij, poses); /* :304-319, visit order */
+        if (poses.empty()) continue;
+        be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
+        for (size_t h = 0; h < poses.size(); ++h) {
+            /* :330-338: score > best_score(=0) and #corrs > accept_prob * |model cloud| */
+            if (scores[h] > 0.0 && (float)counts[h] > sufficient) {
+                best_ts.push_back(poses[h]);
+                break;
+            }
+        }
+    }
+    std::vector<candidate_t> matches;
+    for (size_t k = 0; k < best_ts.size() && matches.size() < 5; ++k) { /* :361-364 */
+        candidate_t c;
+        be.extract(best_ts[k], p.dist_thres, c);
+        matches.push_back(std::move(c));
+    }
+    return {matches, cons};
+}
+
+/* icp_, include/impl/scene.hpp:369-404 (note the doubled distance threshold, :373,395) */
+template <class Backend>
+inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p) {
+    if (p.max_icp_iterations == 0) return match;
+    candidate_t best;
+    be.extract(match.transform, 2.f * p.dist_thres, best);
+    uint32_t iter = 0;
+    for (;;) {
+        if (best.scene_corrs.size() < 3) return best;
+        std::vector<double> scn(3 * best.scene_corrs.size()), mdl(3 * best.scene_corrs.size());
+        for (size_t k = 0; k < best.scene_corrs.size(); ++k) {
+            const float* s = be.scene_surfel(best.scene_corrs[k]);
+            const float* m = be.model_surfel(best.model_corrs[k]);
+            for (int d = 0; d < 3; ++d) {
+                scn[3 * k + d] = s[d];
+                mdl[3 * k + d] = m[d];
+            }
+        }
+        pose_t trans = detail::rigid_fit(scn, mdl); /* :393 */
+        candidate_t proj;
+        be.extract(trans, 2.f * p.dist_thres, proj);
+        if (proj.scene_corrs.size() < best.scene_corrs.size()) return best; /* :396 */
+        best = std::move(proj);
+        if (++iter == p.max_icp_iterations) return best;
+    }
+}
+
+/* find_parallel, include/impl/scene.hpp:108-240 */
+template <class Backend>
+inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uint32_t>& tangent_indices,
+                                              uint32_t n_scene, std::vector<int32_t>& mask,
+                                              std::vector<int32_t>& fp_mask,
+                                              const std::vector<int32_t>& tangent_mask, const params_t& p) {
+    const uint32_t n_model = be.model_point_count();
+    const uint32_t n_model_all = be.model_size();
+    const uint32_t min_points = (uint32_t)((1.f * p.accept_prob) * (float)n_model);      /* :114 */
+    const uint32_t min_points_all = (uint32_t)(p.accept_prob * (float)n_model_all);      /* :115 */
+    std::mt19937 rng;
+    rng.seed((uint32_t)p.seed);
+    std::vector<uint32_t> left;
+    for (uint32_t idx : tangent_indices)
+        if (!fp_mask[idx] && !mask[idx]) left.push_back(idx); /* :131 */
+    if (left.empty()) return {};
+    double outer_prob = (double)n_model / (double)left.size();
+    uint64_t outer_bound;
+    if (outer_prob >= 1.0)
+        outer_bound = 0; /* log(1 - p) is undefined; the clamp below takes over */
+    else
+        outer_bound = (uint64_t)(std::log(1.0 - match_probability) / std::log(1.0 - outer_prob)); /* :134 */
+    outer_bound = std::max(outer_bound, min_sample_count);
+    outer_bound = std::min<uint64_t>(outer_bound, n_scene);
+    outer_bound = std::min<uint64_t>(outer_bound, left.size());
+    detail::partial_shuffle(left, (size_t)outer_bound, rng); /* sample + shuffle, :143-144 */
+    std::vector<uint32_t> outer(left.begin(), left.begin() + (size_t)outer_bound);
+    const uint32_t concurrency = std::max(1u, p.workers); /* :146 */
+    uint64_t batch = outer_bound / concurrency;
+    if (outer_bound % concurrency > 0) ++batch;
+    std::vector<candidate_t> cands;
+    for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) { /* chunks, :156-166 (run one after another) */
+        std::vector<uint32_t> chunk(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
+        auto res = find_in_subset(be, chunk, mask, fp_mask, tangent_mask, p);
+        uint32_t cons = res.second;
+        for (uint32_t k = 0, seen = 0; k < chunk.size() && seen < cons; ++k, ++seen) fp_mask[chunk[k]] = 1; /* :160-162 */
+        for (auto& mt : res.first) cands.push_back(icp(be, mt, p)); /* :169-171 */
+    }
+    std::stable_sort(cands.begin(), cands.end(), [](const candidate_t& a, const candidate_t& b) {
+        return a.scene_corrs.size() > b.scene_corrs.size(); /* :193-195 */
+    });
+    std::vector<candidate_t> result;
+    std::set<uint32_t> used;
+    for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
+        candidate_t out;
+        out.transform = cand.transform;
+        out.signed_score = cand.signed_score;
+        std::set<uint32_t> used_copy = used;
+        for (size_t k = 0; k < cand.scene_corrs.size(); ++k) {
+            if (used.find(cand.scene_corrs[k]) == used.end()) {
+                out.scene_corrs.push_back(cand.scene_corrs[k]);
+                out.model_corrs.push_back(cand.model_corrs[k]);
+            }
+            used.insert(cand.scene_corrs[k]);
+        }
+        uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
+        for (uint32_t idx : out.scene_corrs)
+            if (tangent_mask[idx]) ++score;
+        if (score < min_points || score_all < min_points_all) { /* :227 */
+            used = used_copy;
+            continue;
+        }
+        result.push_back(std::move(out));
+    }
+    return result;
+}
+
+/* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
+ * inverts them (:92). */
+template <class Backend>
+inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>& tangent_mask,
+                                         const params_t& p) {
+    const uint32_t n = be.scene_size();
+    std::vector<int32_t> mask(n, 0), fp_mask(n, 0);
+    std::vector<uint32_t> tangent_indices;
+    for (uint32_t i = 0; i < n; ++i)
+        if (tangent_mask[i]) tangent_indices.push_back(i);
+    const uint32_t n_scene = (uint32_t)tangent_indices.size();
+    be.set_mask(mask);
+    std::vector<candidate_t> results;
+    for (;;) {
+        auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p);
+        if (matches.empty()) break;
+        for (auto& mt : matches) {
+            for (uint32_t idx : mt.scene_corrs) mask[idx] = 1; /* :88-90 */
+            results.push_back(std::move(mt));
+        }
+        be.set_mask(mask);
+    }
+    return results;
+}
+
+}  // namespace search
+}  // namespace triplet_match
+
+#endif

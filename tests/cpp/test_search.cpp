@@ -1,0 +1,205 @@
+/*
+ * test_search.cpp — runs the host orchestration (include/triplet_match/search.hpp) over the CPU oracle
+ * backend (mode "oracle": host-logic test, no GPU) and, in mode "both", also over the HIP backend and
+ * requires identical results (same candidates, same correspondences, bit-identical transforms).
+ * TEST CODE: the only place that links the oracle next to the product library.
+ */
+#include <cstdio>
+#include <fstream>
+
+#include "../../oracle/tm_oracle.h"
+#include "triplet_match/scene.hpp"
+
+using namespace triplet_match;
+typedef PointSurfel P;
+
+struct oracle_backend {
+    tmo_scene* s;
+    tmo_model* m;
+    const pointcloud<P>* scloud;
+    const pointcloud<P>* mcloud;
+    uint32_t n_t;
+    search::params_t p;
+    std::vector<int32_t> mask, tmask;
+
+    uint32_t scene_size() const { return (uint32_t)scloud->size(); }
+    uint32_t model_size() const { return (uint32_t)mcloud->size(); }
+    uint32_t model_point_count() const { return n_t; }
+    float model_diameter() const { return tmo_model_diameter(m); }
+    const float* scene_surfel(uint32_t i) const { return scloud->points[i].raw(); }
+    const float* model_surfel(uint32_t i) const { return mcloud->points[i].raw(); }
+    bool pair_is_valid_sample(uint32_t i, uint32_t j) const {
+        /* one pair through the oracle's generator path: valid <=> it survives the filters and valid();
+         * query_limit 0 entries would hide validity, so restate the filter with the oracle's scalars */
+        if (i == j || mask[i] || !tmask[j] || mask[j]) return false;
+        const float* a = scloud->points[i].raw();
+        const float* b = scloud->points[j].raw();
+        float lower = tmo_model_diameter(m) * p.min_diameter_factor, upper = tmo_model_diameter(m) * p.max_diameter_factor;
+        lower *= lower;
+        upper *= upper;
+        float d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        float sq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+        if (sq > 0.f) {
+            float n = sqrtf(sq);
+            d[0] /= n, d[1] /= n, d[2] /= n;
+        }
+        if (sq < lower || sq > upper) return false;
+        if (1.f - fabsf((d[0] * a[9] + d[1] * a[10]) + d[2] * a[11]) < 0.01f) return false;
+        float f[4], bmin[4], bmax[4];
+        tmo_feature(a, b, f);
+        tmo_model_get_feature_bounds(m, bmin, bmax);
+        return tmo_valid(f, bmin, bmax) != 0;
+    }
+    void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
+        uint32_t n = tmo_scene_radius_subset(s, i, radius, nullptr, 0);
+        out.resize(n);
+        tmo_scene_radius_subset(s, i, radius, out.data(), n);
+    }
+    void generate(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses) {
+        uint32_t n_pairs = (uint32_t)(ij.size() / 2), count = 0;
+        tmo_generate_hypotheses(s, m, ij.data(), n_pairs, p.min_diameter_factor, p.max_diameter_factor,
+                                p.force_up ? 1 : 0, search::query_limit, nullptr, nullptr, 0, &count);
+        poses.resize(count);
+        if (count)
+            tmo_generate_hypotheses(s, m, ij.data(), n_pairs, p.min_diameter_factor, p.max_diameter_factor,
+                                    p.force_up ? 1 : 0, search::query_limit, &poses[0].m[0], nullptr, count, &count);
+    }
+    void score(const std::vector<search::pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
+               std::vector<uint32_t>& counts, std::vector<double>& scores) {
+        counts.resize(poses.size());
+        scores.resize(poses.size());
+        tmo_score_hypotheses(s, m, &poses[0].m[0], (uint32_t)poses.size(), subset.data(), (uint32_t)subset.size(),
+                             p.accept_prob, p.dist_thres, early_drop ? 1 : 0, 4, counts.data(), scores.data(), nullptr);
+    }
+    void extract(const search::pose_t& T, float dist_thres, search::candidate_t& out) {
+        out.transform = T;
+        out.scene_corrs.resize(scloud->size());
+        out.model_corrs.resize(scloud->size());
+        uint32_t saved = 0;
+        uint32_t n = tmo_project(s, m, nullptr, 0, T.m, p.accept_prob, dist_thres, 0, out.scene_corrs.data(),
+                                 out.model_corrs.data(), &out.signed_score, &saved);
+        out.scene_corrs.resize(n);
+        out.model_corrs.resize(n);
+    }
+    void set_mask(const std::vector<int32_t>& mk) {
+        mask = mk;
+        tmo_scene_set_mask(s, mk.data());
+    }
+};
+
+static pointcloud<P>::Ptr read_cloud(std::ifstream& in) {
+    uint32_t n = 0;
+    in.read((char*)&n, 4);
+    auto c = pointcloud<P>::empty();
+    c->points.resize(n);
+    in.read((char*)c->points.data(), (std::streamsize)n * 48);
+    return c;
+}
+
+static void dump(const char* tag, const std::vector<search::candidate_t>& r) {
+    printf("%s: %zu candidates\n", tag, r.size());
+    for (const auto& c : r)
+        printf("   corrs %zu score %.9f t = (%.6f %.6f %.6f)\n", c.scene_corrs.size(), c.signed_score, c.transform.m[12],
+               c.transform.m[13], c.transform.m[14]);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    const bool both = std::string(argv[2]) == "both";
+    std::ifstream in(argv[1], std::ios::binary);
+    auto mcloud = read_cloud(in);
+    auto scloud = read_cloud(in);
+    float res = 0.f;
+    in.read((char*)&res, 4);
+    uint32_t n_truth = 0;
+    in.read((char*)&n_truth, 4);
+    std::vector<mat4f_t> truth(n_truth);
+    for (auto& t : truth) in.read((char*)t.m, 64);
+    if (!in.good()) return 3;
+
+    const float angle_step = 10.f * (float)M_PI / 180.f;
+    std::vector<uint32_t> subset;
+    for (uint32_t i = 0; i < mcloud->size(); ++i)
+        if (tangent(mcloud->points[i]).norm() > 0.7f) subset.push_back(i);
+    std::vector<int32_t> tmask(scloud->size());
+    for (uint32_t i = 0; i < scloud->size(); ++i) tmask[i] = tangent(scloud->points[i]).norm() > 0.7f ? 1 : 0;
+
+    search::params_t p;
+    p.dist_thres = 3.f;
+    p.accept_prob = 0.5f;
+    p.max_icp_iterations = 2;
+    p.workers = 4;
+
+    oracle_backend ob;
+    ob.m = tmo_model_create(mcloud->points[0].raw(), (uint32_t)mcloud->size(), res, 20.f, angle_step);
+    if (tmo_model_build_voxels(ob.m, 8) || tmo_model_build_pairs(ob.m, subset.data(), (uint32_t)subset.size(), 0.2f, 1.0f))
+        return 4;
+    ob.s = tmo_scene_create(scloud->points[0].raw(), (uint32_t)scloud->size(), tmask.data());
+    ob.scloud = scloud.get();
+    ob.mcloud = mcloud.get();
+    ob.n_t = (uint32_t)subset.size();
+    ob.p = p;
+    ob.tmask = tmask;
+    auto ro = search::find_all(ob, tmask, p);
+    dump("oracle backend", ro);
+    int failures = 0;
+    if (ro.empty()) {
+        printf("FAIL no candidate found by the host logic over the oracle\n");
+        ++failures;
+    }
+    for (const auto& c : ro) { /* each accepted candidate must sit on a planted pose */
+        double best = 1e30;
+        for (const auto& t : truth) {
+            double err = 0;
+            for (size_t k = 0; k < c.scene_corrs.size(); k += 7) { /* over the matched instance's points */
+                mat4f_t T;
+                memcpy(T.m, c.transform.m, 64);
+                const auto& q = scloud->points[c.scene_corrs[k]];
+                vec4f_t a = T * homogeneous(q.getVector3fMap());
+                vec4f_t b = t * homogeneous(q.getVector3fMap());
+                err = std::max(err, (double)(a.head3() - b.head3()).norm());
+            }
+            best = std::min(best, err);
+        }
+        printf("   alignment error vs nearest planted pose: %.6f (resolution %.6f)\n", best, res);
+        if (!(best < 6.0 * res)) { /* within the ICP correspondence distance 2 x dist_thres x resolution */
+            printf("FAIL candidate is not a planted pose\n");
+            ++failures;
+        }
+    }
+    if (both) {
+        discretization_params dp;
+        dp.distance_step_count = 20.f;
+        dp.angle_step = angle_step;
+        mcloud->set_resolution(res);
+        model<P> gm(mcloud, dp);
+        sample_parameters sp;
+        gm.init(sp);
+        tm_scene* gs = nullptr;
+        detail::check(tm_scene_create(gm.context(), scloud->points[0].raw(), (uint32_t)scloud->size(), tmask.data(), &gs),
+                      "tm_scene_create");
+        detail::hip_backend<P> hb;
+        hb.s = gs;
+        hb.m = gm.handle();
+        hb.scloud = scloud.get();
+        hb.mcloud = mcloud.get();
+        hb.n_t = gm.point_count();
+        hb.diam = gm.diameter();
+        hb.p = p;
+        auto rg = search::find_all(hb, tmask, p);
+        dump("hip backend", rg);
+        bool same = rg.size() == ro.size();
+        for (size_t k = 0; same && k < rg.size(); ++k) {
+            same = same && memcmp(rg[k].transform.m, ro[k].transform.m, 64) == 0;
+            same = same && rg[k].scene_corrs == ro[k].scene_corrs && rg[k].model_corrs == ro[k].model_corrs;
+            same = same && std::fabs(rg[k].signed_score - ro[k].signed_score) <= 1e-9 * std::fabs(ro[k].signed_score);
+        }
+        printf("%s hip backend == oracle backend (candidates, correspondences, transforms)\n", same ? "ok  " : "FAIL");
+        if (!same) ++failures;
+        tm_scene_destroy(gs);
+    }
+    tmo_scene_destroy(ob.s);
+    tmo_model_destroy(ob.m);
+    printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,83 @@
+"""The drop-in C++ template API (include/triplet_match/*.hpp over libtm_hip.so).
+
+CPU: the headers compile with a plain host compiler against the C ABI, and the host orchestration
+(search.hpp) finds the planted poses when run over the CPU oracle backend.
+GPU: the same orchestration over the HIP backend gives identical results, and the full
+model<Point>/scene<Point>/traits walk-through passes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from triplet_match_amd import build as tm_build
+from triplet_match_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "cpp", "_build")
+
+
+def _compile(name, extra=()):
+    os.makedirs(BUILD, exist_ok=True)
+    tm_build.build()
+    from oracle import tmo
+    tmo.build()
+    out = os.path.join(BUILD, name)
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wno-comment", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+           "-L" + os.path.join(ROOT, "triplet_match_amd"), "-ltm_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "triplet_match_amd")] + list(extra)
+    subprocess.check_call(cmd)
+    return out
+
+
+def _fixture(path, model_n=1500, scene_n=12000, copies=2):
+    model, _ = synth.synth_model(model_n, seed=1)
+    res = synth.resolution(model)
+    scene = synth.synth_scene(scene_n, model_n, seed=2, copies=copies, model_resolution=res)
+    with open(path, "wb") as f:
+        f.write(np.uint32(model.shape[0]).tobytes())
+        f.write(model.tobytes())
+        f.write(np.uint32(scene["surfels"].shape[0]).tobytes())
+        f.write(scene["surfels"].tobytes())
+        f.write(np.float32(res).tobytes())
+        f.write(np.uint32(copies).tobytes())
+        for T in scene["poses_scene_to_model"]:
+            f.write(synth.pose_colmajor(T).tobytes())
+    return path
+
+
+def _oracle_link():
+    return ["-L" + os.path.join(ROOT, "oracle"), "-ltm_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+            "-pthread"]
+
+
+def test_dropin_headers_compile_with_host_compiler():
+    _compile("test_dropin")
+    _compile("test_search", _oracle_link())
+
+
+def test_host_orchestration_over_oracle_backend(tmp_path):
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "case.bin"))
+    r = subprocess.run([exe, fx, "oracle"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_orchestration_hip_equals_oracle(tmp_path):
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "case.bin"))
+    r = subprocess.run([exe, fx, "both"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
+
+
+@pytest.mark.gpu
+def test_dropin_walkthrough(tmp_path):
+    exe = _compile("test_dropin")
+    fx = _fixture(str(tmp_path / "case.bin"))
+    r = subprocess.run([exe, fx], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASSED" in r.stdout and "FAIL" not in r.stdout

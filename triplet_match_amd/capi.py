@@ -77,6 +77,7 @@ SIGNATURES = {
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
+    "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
     "tm_generate_hypotheses_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_int,

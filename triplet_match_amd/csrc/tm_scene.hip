@@ -904,6 +904,26 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
 
 uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
 
+int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, uint32_t j, float minf,
+                            float maxf) {
+    if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
+    if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
+    const float* a = s->h_cloud.data() + (size_t)i * 12;
+    const float* b = s->h_cloud.data() + (size_t)j * 12;
+    f3 p1 = make3(a[0], a[1], a[2]), p2 = make3(b[0], b[1], b[2]);
+    f3 t1 = make3(a[9], a[10], a[11]), t2 = make3(b[9], b[10], b[11]);
+    float lower = m->diameter * minf, upper = m->diameter * maxf;
+    lower *= lower;
+    upper *= upper;
+    f3 d = p2 - p1;
+    float sq = len2(d);
+    d = unit(d);
+    if (sq < lower || sq > upper) return 0;
+    if (1.f - fabsf(dot3(d, t1)) < 0.01f) return 0;
+    feat4 f = pair_feature(p1, t1, p2, t2);
+    return feature_valid(f, m->bmin[0], m->bmax[0]) ? 1 : 0;
+}
+
 int tm_generate_hypotheses_dev(tm_scene* s, tm_model* m, const uint32_t* d_ij_pairs, uint32_t n_pairs,
                                float min_diameter_factor, float max_diameter_factor, int force_up,
                                int query_limit, float* d_poses16, uint32_t* d_provenance4, uint32_t cap,

@@ -4,8 +4,9 @@ The reference ships no data; every generator parameter here is ours. Surfel layo
 pcl::PointSurfel image used by the reference (include/common:62-70): 12 float32 per point,
 [x y z 1 | nx ny nz 0 | rgba tx ty tz]; the tangent lives in the radius/confidence/curvature slots.
 
-Model:  L-step prism (asymmetric, so its pose is unique under SE(3)); 4 % of the points lie on the
-        straight creases and carry the unit crease direction as tangent, all others a zero tangent.
+Model:  L-step prism (asymmetric, so its pose is unique under SE(3)), sampled area-uniformly; the
+        points inside a thin band along the straight creases (~4 % of the area, never thinner than
+        ~1.5 point spacings) carry the unit crease direction as tangent, all others a zero tangent.
 Scene:  K planted rigid copies (independent resamplings of the same surface) + planar clutter
         (floor, two walls, with their own crease lines) + uniform outliers + Gaussian position noise.
 """
@@ -66,31 +67,42 @@ def _sample_rects(rng, rects, n):
     return O + u[:, None] * A + v[:, None] * B, Nn
 
 
-def _sample_creases(rng, creases, n):
-    lens = np.array([np.linalg.norm(c[1] - c[0]) for c in creases])
-    which = rng.choice(len(creases), size=n, p=lens / lens.sum())
-    u = rng.random(n)
-    P0 = np.stack([c[0] for c in creases])[which]
-    P1 = np.stack([c[1] for c in creases])[which]
-    Nn = np.stack([c[2] for c in creases])[which]
-    d = P1 - P0
-    t = d / np.linalg.norm(d, axis=1, keepdims=True)
-    return P0 + u[:, None] * d, Nn, t
+def _crease_tangents(pos, creases, width):
+    """Tangent of every point lying within `width` of a crease segment: the unit direction of the
+    nearest crease (an edge detector marks a band of points, not a line); zero elsewhere."""
+    n = pos.shape[0]
+    best = np.full(n, np.inf)
+    tgt = np.zeros((n, 3))
+    for (p0, p1, _) in creases:
+        d = p1 - p0
+        L = np.linalg.norm(d)
+        u = d / L
+        t = np.clip((pos - p0) @ u, 0.0, L)
+        dist = np.linalg.norm(pos - (p0 + t[:, None] * u), axis=1)
+        closer = dist < best
+        best = np.where(closer, dist, best)
+        tgt[closer] = u
+    tgt[best > width] = 0.0
+    return tgt
+
+
+def _band_width(rects, creases, edge_fraction, n, min_res_factor=1.5):
+    """Band half-width giving ~edge_fraction of the area, but never thinner than ~1.5 x the expected
+    point spacing (otherwise a band point's nearest model point is usually outside the band)."""
+    area = sum(np.linalg.norm(np.cross(a, b)) for (_, a, b, _) in rects)
+    length = sum(np.linalg.norm(c[1] - c[0]) for c in creases)
+    w_area = edge_fraction * area / (2.0 * length)
+    expected_res = 0.5 / np.sqrt(n / area)
+    return max(w_area, min_res_factor * expected_res)
 
 
 def synth_model(n, seed=1, edge_fraction=EDGE_FRACTION):
     """n-point L-step model. Returns (surfels[n,12] f32, tangent_subset u32 ascending)."""
     rng = np.random.default_rng(seed)
     rects, creases = _rects_and_creases()
-    n_edge = int(round(n * edge_fraction))
-    n_face = n - n_edge
-    pf, nf = _sample_rects(rng, rects, n_face)
-    pe, ne, te = _sample_creases(rng, creases, n_edge)
-    pos = np.concatenate([pf, pe])
-    nrm = np.concatenate([nf, ne])
-    tgt = np.concatenate([np.zeros_like(pf), te])
-    perm = rng.permutation(n)
-    s = _pack(pos[perm], nrm[perm], tgt[perm])
+    pos, nrm = _sample_rects(rng, rects, n)
+    tgt = _crease_tangents(pos, creases, _band_width(rects, creases, edge_fraction, n))
+    s = _pack(pos, nrm, tgt)
     subset = np.nonzero(np.linalg.norm(s[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
     return s, subset
 
@@ -139,13 +151,10 @@ def synth_scene(n, model_n, seed=2, copies=4, outlier_fraction=0.05, noise_sigma
         raise ValueError("scene too small for the requested copies")
     pos_l, nrm_l, tgt_l, inst_l = [], [], [], []
     m2s, s2m = [], []
+    width = _band_width(rects, creases, edge_fraction, model_n)
     for k in range(copies):
-        n_edge = int(round(model_n * edge_fraction))
-        pf, nf = _sample_rects(rng, rects, model_n - n_edge)
-        pe, ne, te = _sample_creases(rng, creases, n_edge)
-        p = np.concatenate([pf, pe])
-        nn = np.concatenate([nf, ne])
-        tt = np.concatenate([np.zeros_like(pf), te])
+        p, nn = _sample_rects(rng, rects, model_n)
+        tt = _crease_tangents(p, creases, width)
         R = random_rotation(rng, upright)
         t = rng.random(3) * (room - diam) + 0.5 * diam * np.array([1, 1, 0.3])
         pos_l.append(p @ R.T + t)
@@ -180,12 +189,10 @@ def synth_scene(n, model_n, seed=2, copies=4, outlier_fraction=0.05, noise_sigma
         d[2 if rng.random() < 0.5 else (0 if a[0] != 0.0 else 1)] = (0.5 + rng.random()) * diam
         nrm = np.array([0, 1.0, 0]) if a[1] == 0.0 else np.array([1.0, 0, 0])
         c_creases.append((a, a + d, nrm))
-    n_cedge = int(round(n_clutter * edge_fraction))
-    pf, nf = _sample_rects(rng, c_rects, n_clutter - n_cedge)
-    pe, ne, te = _sample_creases(rng, c_creases, n_cedge)
-    pos_l += [pf, pe]
-    nrm_l += [nf, ne]
-    tgt_l += [np.zeros_like(pf), te]
+    pf, nf = _sample_rects(rng, c_rects, n_clutter)
+    pos_l.append(pf)
+    nrm_l.append(nf)
+    tgt_l.append(_crease_tangents(pf, c_creases, _band_width(c_rects, c_creases, edge_fraction, max(n_clutter, 1))))
     inst_l.append(np.full(n_clutter, -1, np.int32))
     # outliers
     po = rng.random((n_out, 3)) * room
