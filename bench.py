@@ -66,6 +66,7 @@ def main():
     if world > 1:
         dist.barrier()
     from triplet_match_amd import capi, synth
+    from triplet_match_amd import dist as tmd
 
     mode = {"auto": capi.SCORE_AUTO, "brute": capi.SCORE_BRUTEFORCE, "culled": capi.SCORE_CULLED}[args.mode]
     DIST_THRES, ACCEPT_PROB = 3.0, 0.5
@@ -99,7 +100,7 @@ def main():
     H = args.hyp_per_batch
     n_first = max(64, H // 400)
     pairs_all = synth.sample_scene_pairs(scene, gm.diameter, n_first * world, 24, seed=13)
-    pairs = np.ascontiguousarray(pairs_all[rank::world])
+    pairs = tmd.shard_pairs(pairs_all, rank, world)
     d_ij = ctx.alloc(max(pairs.nbytes, 8))
     ctx.h2d(d_ij, pairs)
     d_poses = ctx.alloc(H * 64)
@@ -111,23 +112,14 @@ def main():
     if n_hyp < H:
         log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (n_hyp, H))
 
-    if world > 1:
-        rec_dev = torch.zeros(96, dtype=torch.uint8, device="cuda")
-        rec_all = torch.zeros(96 * world, dtype=torch.uint8, device="cuda")
-
-    import ctypes as C
+    cuda_dev = torch.device("cuda", local_rank)
 
     def step():
         n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
         gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
         best = ctx.best_of_batch(d_counts, d_scores, d_poses, n, id_offset=rank, id_stride=world)
-        if world > 1:
-            raw = np.frombuffer(bytes(best), dtype=np.uint8)
-            rec_dev.copy_(torch.from_numpy(raw.copy()))
-            dist.all_gather_into_tensor(rec_all, rec_dev)
-            recs_np = rec_all.cpu().numpy().tobytes()
-            recs = [capi.BestRecord.from_buffer_copy(recs_np[96 * r:96 * (r + 1)]) for r in range(world)]
-            best = capi.best_select(recs)
+        if world > 1:  # one 96-byte-per-rank RCCL all-gather + deterministic argmax (tm_best_select)
+            best = tmd.allgather_best(best, device=cuda_dev)
         return n, best
 
     def sync_all():
