@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <outdir> <bench args...>   — separate, small PMC passes over the same bench command
+# usage: tools/pmc_passes.sh <outdir> <bench args...>   — separate, small PMC passes over the same bench command
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $out
