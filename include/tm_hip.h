@@ -105,6 +105,11 @@ int tm_model_build_voxels(tm_model* model);
  * filter (:96-99). Builds feature bounds and the key -> (i,j) table. */
 int tm_model_build_pairs(tm_model* model, const uint32_t* subset, uint32_t n_subset,
                          float min_diameter_factor, float max_diameter_factor);
+/* Declares the model to be a projector's uvw cloud (built from tm_traits_project_cloud output): the
+ * query <-> model-point distance of the scoring kernels becomes that traits' intrinsic_distance
+ * (plane2: 2-D; cylinder: wrap-around in u with `radius`); remnant of the reference's
+ * model<Proj,Point>::voxel_distance (include/impl/model.hpp:194-201). Default: identity (3-D L2). */
+int tm_model_set_metric(tm_model* model, int traits_kind, float radius);
 int tm_model_get_info(const tm_model* model, float* diameter, uint32_t* cloud_size,
                       uint32_t* point_count /* tangent-subset size, model.hpp:219-221 */,
                       float* resolution);

@@ -388,6 +388,8 @@ struct tmo_model {
     uint64_t valid_count = 0;
     hash_map_t map;
     std::vector<uint8_t> is_tangent; /* |tangent| > 0.7 per model point, ref: scene.hpp:469-470 */
+    int metric_kind = 0;      /* traits whose intrinsic_distance measures query <-> model point */
+    float metric_radius = 0.f; /* cylinder radius for the wrap-around */
 };
 
 namespace {
@@ -611,6 +613,10 @@ int tmo_model_build_pairs(tmo_model* m, const uint32_t* subset, uint32_t n_subse
 }
 
 float tmo_model_diameter(const tmo_model* m) { return m->diameter; }
+void tmo_model_set_metric(tmo_model* m, int kind, float radius) {
+    m->metric_kind = kind;
+    m->metric_radius = radius;
+}
 uint32_t tmo_model_size(const tmo_model* m) { return m->n; }
 uint32_t tmo_model_point_count(const tmo_model* m) { return (uint32_t)m->subset.size(); }
 void tmo_model_get_grid(const tmo_model* m, int extents[3], float to_voxel16[16]) {
@@ -749,7 +755,16 @@ uint32_t tmo_project(const tmo_scene* s, const tmo_model* m, const int32_t* subs
                 at_tail = true;
                 ref = mat3_mul(T, ref);                       /* :461 */
                 const float* mp = mc + (size_t)mi * 12;
-                float dist = norm(sub(v3{pos[0], pos[1], pos[2]}, s_pos(mp))); /* :464 */
+                /* :464; for a model living in a projector's uvw space the distance is that traits'
+                 * intrinsic_distance (remnant: include/impl/model.hpp:194-201 voxel_distance) */
+                float dist;
+                if (m->metric_kind == TMO_TRAITS_IDENTITY) {
+                    dist = norm(sub(v3{pos[0], pos[1], pos[2]}, s_pos(mp)));
+                } else {
+                    float st[TMO_STATE_FLOATS] = {0};
+                    st[0] = m->metric_radius;
+                    dist = tmo_traits_intrinsic_distance(m->metric_kind, st, pos, mp);
+                }
                 if (!(dist > thres)) {                        /* :465 */
                     bool is_tangent = m->is_tangent[mi] != 0; /* :469-470 */
                     if (use_tangent == is_tangent) {          /* :472 */

@@ -63,6 +63,8 @@ int      tmo_model_set_voxels(tmo_model* m, const uint32_t* voxels, uint64_t cou
 int      tmo_model_build_pairs(tmo_model* m, const uint32_t* subset, uint32_t n_subset,
                                float min_diameter_factor, float max_diameter_factor);
 float    tmo_model_diameter(const tmo_model* m);
+/* the model is a projector's uvw cloud: distances use that traits' intrinsic_distance */
+void     tmo_model_set_metric(tmo_model* m, int traits_kind, float radius);
 uint32_t tmo_model_size(const tmo_model* m);
 uint32_t tmo_model_point_count(const tmo_model* m); /* tangent-subset size */
 void     tmo_model_get_grid(const tmo_model* m, int extents[3], float to_voxel16[16]);

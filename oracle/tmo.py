@@ -73,6 +73,7 @@ def lib():
         L.tmo_model_build_pairs.argtypes = [C.c_void_p, u32p, C.c_uint32, C.c_float, C.c_float]
         L.tmo_model_diameter.restype = C.c_float
         L.tmo_model_diameter.argtypes = [C.c_void_p]
+        L.tmo_model_set_metric.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.tmo_model_size.restype = C.c_uint32
         L.tmo_model_size.argtypes = [C.c_void_p]
         L.tmo_model_point_count.restype = C.c_uint32
@@ -247,6 +248,9 @@ class Model:
     @property
     def diameter(self):
         return float(lib().tmo_model_diameter(self.h))
+
+    def set_metric(self, kind, radius=0.0):
+        lib().tmo_model_set_metric(self.h, kind, radius)
 
     def grid(self):
         ext = np.zeros(3, np.int32)

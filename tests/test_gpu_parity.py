@@ -334,3 +334,142 @@ def test_traits_project_cloud_bit_exact(gpu_ctx):
                 assert np.array_equal(bits(out[i, 9:12]), bits(tmo.traits_tangent(kind, st, s[i])))
                 assert np.array_equal(bits(out[i, 4:7]), bits(tmo.traits_normal(kind, st, s[i])))
         assert 0 < valid.sum() <= n
+
+
+def _cylinder_case(rng, n_model=1500, n_scene=6000):
+    """pipe section (radius 0.5, height 2) with seam/flange tangents; scene = rigid copy + clutter"""
+    def pipe(n, r=0.5):
+        theta = rng.random(n) * 2 * np.pi
+        h = rng.random(n) * 2.0
+        nrm = np.stack([np.cos(theta), np.sin(theta), np.zeros(n)], 1)
+        s = np.zeros((n, 12), np.float32)
+        s[:, 0:3] = r * nrm + np.stack([0 * h, 0 * h, h], 1)
+        s[:, 3] = 1
+        s[:, 4:7] = -nrm
+        seam = (np.abs(theta - 1.0) < 0.08) | (np.abs(theta - 4.0) < 0.08)      # two axial seams
+        flange = (np.abs(h - 0.6) < 0.03) | (np.abs(h - 1.5) < 0.03)             # two rings
+        s[seam, 9:12] = [0, 0, 1]
+        tang = np.stack([-np.sin(theta), np.cos(theta), np.zeros(n)], 1)
+        s[flange & ~seam, 9:12] = tang[flange & ~seam]
+        return s
+    model = pipe(n_model)
+    inst = pipe(n_model)
+    R = synth.random_rotation(rng)
+    t = np.array([3.0, -2.0, 1.0])
+    inst[:, 0:3] = inst[:, 0:3] @ R.T + t
+    inst[:, 4:7] = inst[:, 4:7] @ R.T
+    inst[:, 9:12] = inst[:, 9:12] @ R.T
+    clutter = np.zeros((n_scene - n_model, 12), np.float32)
+    clutter[:, 0:3] = rng.random((n_scene - n_model, 3)) * 6 - np.array([0, 5, 2])
+    clutter[:, 3] = 1
+    clutter[:, 6] = 1
+    scene = np.concatenate([inst, clutter]).astype(np.float32)
+    return model, scene, R, t
+
+
+def _project_cloud_oracle(kind, state, surfels):
+    out = np.zeros_like(surfels)
+    valid = np.zeros(len(surfels), np.int32)
+    for i, s in enumerate(surfels):
+        uvw = tmo.traits_project(kind, state, s[0:3])
+        if uvw is None:
+            continue
+        valid[i] = 1
+        out[i, 0:3] = uvw
+        out[i, 3] = 1
+        if np.linalg.norm(s[9:12]) > 0:
+            out[i, 9:12] = tmo.traits_tangent(kind, state, s)
+            out[i, 4:7] = tmo.traits_normal(kind, state, s)
+        else:
+            st = np.asarray(state)
+            g = st[5:21].reshape(4, 4).T[:3, :3]
+            v = g.astype(np.float32) @ s[4:7]
+            out[i, 4:7] = v
+    return out, valid
+
+
+@pytest.mark.parametrize("kind", ["cylinder", "plane2"])
+def test_projected_traits_pipeline(gpu_ctx, kind):
+    """configs 3/4 wiring: project model and scene into the projector's uvw space, then the same
+    kernels run there with that traits' intrinsic_distance (cylinder: wrap-around, plane2: 2-D)."""
+    rng = np.random.default_rng(12)
+    K = capi.CYLINDER if kind == "cylinder" else capi.PLANE2
+    ms = np.zeros(capi.STATE_FLOATS, np.float32)
+    if kind == "cylinder":
+        model, scene, R, t = _cylinder_case(rng)
+        ms[1] = 0.05
+        # model projector: known axis (MSAC fit is out of scope); scene projector: from two samples
+        mstate = capi.traits_init_from_samples(K, ms, np.concatenate([model[0], model[11]]))
+        sstate = capi.traits_init_from_samples(K, ms, np.concatenate([scene[0], scene[11]]))
+        radius = float(mstate[0])
+    else:
+        n = 1500
+        model = np.zeros((n, 12), np.float32)
+        model[:, 0:2] = rng.random((n, 2)) * [2.0, 1.0]
+        model[:, 2] = rng.normal(size=n) * 0.002
+        model[:, 3] = 1
+        model[:, 6] = 1
+        edge = (model[:, 0] < 0.04) | (model[:, 1] < 0.03) | (np.abs(model[:, 0] - 1.2) < 0.02)
+        model[edge & (model[:, 1] >= 0.03), 9:12] = [0, 1, 0]
+        model[model[:, 1] < 0.03, 9:12] = [1, 0, 0]
+        inst = model.copy()
+        inst[:, 0:2] = rng.random((n, 2)) * [2.0, 1.0]
+        inst[:, 2] = rng.normal(size=n) * 0.002
+        inst[:, 9:12] = 0
+        e2 = (inst[:, 0] < 0.04) | (np.abs(inst[:, 0] - 1.2) < 0.02)
+        inst[e2 & (inst[:, 1] >= 0.03), 9:12] = [0, 1, 0]
+        inst[inst[:, 1] < 0.03, 9:12] = [1, 0, 0]
+        R = synth.random_rotation(rng)
+        t = np.array([1.0, 2.0, -1.0])
+        inst[:, 0:3] = inst[:, 0:3] @ R.T + t
+        inst[:, 4:7] = inst[:, 4:7] @ R.T
+        inst[:, 9:12] = inst[:, 9:12] @ R.T
+        clutter = np.zeros((3000, 12), np.float32)
+        clutter[:, 0:3] = rng.random((3000, 3)) * 5
+        clutter[:, 3] = 1
+        clutter[:, 4] = 1
+        scene = np.concatenate([inst, clutter]).astype(np.float32)
+        mstate = capi.traits_init_from_samples(K, ms, np.concatenate([model[0], model[700], model[1400]]))
+        sstate = capi.traits_init_from_samples(K, ms, np.concatenate([scene[0], scene[700], scene[1400]]))
+        radius = 0.0
+    assert mstate is not None and sstate is not None
+    # GPU projection == oracle projection (bit-exact), then build both sides from the GPU output
+    mu, mv = gpu_ctx.traits_project_cloud(K, mstate, model)
+    su, sv = gpu_ctx.traits_project_cloud(K, sstate, scene)
+    mo, mvo = _project_cloud_oracle(K, mstate, model)
+    assert np.array_equal(mv, mvo) and np.array_equal(bits(mu[:, 0:3]), bits(mo[:, 0:3]))
+    assert mv.sum() > 0.9 * len(model) and sv.sum() >= 0.2 * len(scene)
+    mu, su = mu[mv == 1], su.copy()
+    su[sv == 0, 0] = np.nan  # projected-away scene points never take part
+    res = synth.resolution(mu)
+    subset = np.nonzero(np.linalg.norm(mu[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+    tmask = ((np.linalg.norm(su[:, 9:12], axis=1) > 0.7) & (sv == 1)).astype(np.int32)
+    gm = capi.Model(gpu_ctx, mu, res)
+    gm.set_metric(K, radius)
+    gm.build_voxels()
+    gm.build_pairs(subset)
+    gs = capi.Scene(gpu_ctx, su, tmask)
+    om = tmo.Model(mu, res)
+    om.set_metric(K, radius)
+    om.build_voxels(threads=4)
+    assert om.build_pairs(subset) == 0
+    os_ = tmo.Scene(su, tmask)
+    assert np.array_equal(gm.voxels(), om.voxels())
+    tidx = np.nonzero(tmask)[0]
+    pairs = rng.choice(tidx, size=(300, 2)).astype(np.uint32)
+    pg, vg, total = gs.generate_hypotheses(gm, pairs)
+    po, vo = os_.generate_hypotheses(om, pairs)
+    assert total == len(po) and np.array_equal(vg, vo) and np.array_equal(bits(pg), bits(po))
+    poses = np.concatenate([po[:600], np.eye(4, dtype=np.float32).reshape(1, 16)])
+    co, so, _ = os_.score_hypotheses(om, poses, 0.5, DT, threads=4)
+    cg, sg = gs.score_hypotheses(gm, poses, DT, traits=K)
+    assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    assert co.max() > 0
+    with pytest.raises(capi.TmError):  # the metric is part of the model: a mismatching kind is refused
+        gs.score_hypotheses(gm, poses, DT, traits=capi.IDENTITY)
+    if kind == "cylinder":
+        # wrap-around: a query at u ~ 0 matches a model point at u ~ 2*pi*r only under the cylinder metric
+        gm2 = capi.Model(gpu_ctx, mu, res)
+        gm2.build_voxels()
+        c_l2, _ = gs.score_hypotheses(gm2, poses, DT)
+        assert (cg >= c_l2).all()

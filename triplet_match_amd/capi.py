@@ -64,6 +64,7 @@ SIGNATURES = {
     "tm_model_destroy": (C.c_int, [vp]),
     "tm_model_build_voxels": (C.c_int, [vp]),
     "tm_model_build_pairs": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_float]),
+    "tm_model_set_metric": (C.c_int, [vp, C.c_int, C.c_float]),
     "tm_model_get_info": (C.c_int, [vp, f32p, u32p, u32p, f32p]),
     "tm_model_get_grid": (C.c_int, [vp, i32p, f32p]),
     "tm_model_download_voxels": (C.c_int, [vp, u32p, C.c_uint64, u64p]),
@@ -329,6 +330,9 @@ class Model:
         s, p = _u(subset)
         _check(lib().tm_model_build_pairs(self.h, p, s.size, min_diameter_factor,
                                           max_diameter_factor))
+
+    def set_metric(self, kind, radius=0.0):
+        _check(lib().tm_model_set_metric(self.h, kind, radius))
 
     def info(self):
         d, r = C.c_float(0), C.c_float(0)

@@ -238,6 +238,9 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
     a.sc.ablate = 0;
+    a.sc.kind = m->metric_kind;
+    a.sc.radius = m->metric_radius;
+    a.sc.dmax = dist_thres * m->resolution;
     a.sc.bcode = nullptr; /* bx/by still address the bricked voxel table */
     a.sc.bx = m->bdim[0];
     a.sc.by = m->bdim[1];

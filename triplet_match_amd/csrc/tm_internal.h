@@ -88,6 +88,8 @@ struct tm_model {
     uint32_t n = 0;
     float resolution = 0.f;
     float distance_step_count = 0.f, angle_step = 0.f;
+    int metric_kind = 0;       /* TM_TRAITS_*: which intrinsic_distance the scoring kernels use */
+    float metric_radius = 0.f;
     std::vector<float> h_cloud; /* n*12 host copy (host-side query helpers) */
     /* geometry */
     bool grid_ready = false, voxels_ready = false, pairs_ready = false;

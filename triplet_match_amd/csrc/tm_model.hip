@@ -710,6 +710,16 @@ int tm_model_build_pairs(tm_model* m, const uint32_t* subset, uint32_t n_t,
     return TM_OK;
 }
 
+int tm_model_set_metric(tm_model* m, int traits_kind, float radius) {
+    TM_REQUIRE(m, TM_ERR_INVALID, "null model");
+    TM_REQUIRE(traits_kind >= TM_TRAITS_IDENTITY && traits_kind <= TM_TRAITS_CYLINDER, TM_ERR_INVALID,
+               "bad traits kind");
+    TM_REQUIRE(traits_kind != TM_TRAITS_CYLINDER || radius > 0.f, TM_ERR_INVALID, "cylinder metric needs a radius");
+    m->metric_kind = traits_kind;
+    m->metric_radius = radius;
+    return TM_OK;
+}
+
 int tm_model_get_info(const tm_model* m, float* diameter, uint32_t* cloud_size, uint32_t* point_count,
                       float* resolution) {
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");

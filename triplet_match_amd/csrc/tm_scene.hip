@@ -625,8 +625,8 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                         const unsigned char* d_active, uint64_t n_active, float dist_thres, int mode,
                         uint32_t* d_counts, double* d_scores) {
     TM_FORWARD(check_pair(s, m));
-    TM_REQUIRE(traits_kind == TM_TRAITS_IDENTITY, TM_ERR_UNSUPPORTED,
-               "projected traits are scored through a model/scene built from tm_traits_project_cloud");
+    TM_REQUIRE(traits_kind == m->metric_kind, TM_ERR_INVALID,
+               "traits_kind differs from the model's metric (tm_model_set_metric)");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
     TM_REQUIRE(mode == TM_SCORE_AUTO || mode == TM_SCORE_BRUTEFORCE || mode == TM_SCORE_CULLED,
                TM_ERR_INVALID, "bad scoring mode");
@@ -651,12 +651,16 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     a.d2max = sq_threshold(thres);
     a.n_hyp = n_hyp;
     a.ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
+    a.kind = m->metric_kind;
+    a.radius = m->metric_radius;
+    a.dmax = thres;
     /* brick filter: a voxel hit can be skipped when every voxel centre of its 4x4x4 brick is farther
      * than thres + (largest distance from a voxel's centre to a point of its cell = sqrt(3) cells,
      * the int cast truncates) from the model: then no model point is within thres of the query. */
     const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
     const float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
-    const bool culled = (mode != TM_SCORE_BRUTEFORCE) && !d_active;
+    /* tile culling and the brick filter reason with 3-D Euclidean distances: L2 metrics only */
+    const bool culled = (mode != TM_SCORE_BRUTEFORCE) && !d_active && m->metric_kind <= TM_TRAITS_PLANE;
     a.bcode = culled ? m->brick_code.p : nullptr;
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
@@ -1079,6 +1083,9 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     a.n_hyp = 1;
     a.hyp_per_block = 1;
     a.ablate = 0;
+    a.kind = m->metric_kind;
+    a.radius = m->metric_radius;
+    a.dmax = dist_thres * m->resolution;
     a.stat_slots = nullptr;
     a.bcode = nullptr; /* no brick filter here; bx/by still address the bricked voxel table */
     a.bx = m->bdim[0];

@@ -7,6 +7,7 @@
 #include <limits>
 
 #include "tm_internal.h"
+#include "tm_traits_math.h"
 
 namespace tmx {
 
@@ -25,6 +26,9 @@ struct score_args {
     int bx, by;                  /* brick grid dims (x, y) */
     uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
     int ablate;                  /* timing experiments only (TM_ABLATE): 0 = full kernel */
+    int kind;                    /* traits whose intrinsic_distance applies (0 = 3-D L2) */
+    float radius;                /* cylinder radius (wrap-around in u) */
+    float dmax;                  /* thres itself, for the non-Euclidean metrics */
     const float* poses;
     uint32_t* counts;
     unsigned long long* scores_fx;
@@ -56,9 +60,14 @@ __device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12
     uint32_t lin = brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)); /* bricked layout */
     uint32_t m = a.vox[lin];
     float4 mp = a.mpos[m];
-    float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
-    float d2 = (dx * dx + dy * dy) + dz * dz;
-    if (!(d2 <= a.d2max)) return 0u;
+    if (a.kind == 0 || a.kind == 1) { /* identity / plane: 3-D L2 */
+        float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
+        float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (!(d2 <= a.d2max)) return 0u;
+    } else { /* plane2 (2-D) / cylinder (wrap-around): the traits' intrinsic_distance */
+        float dist = traits_distance(a.kind, a.radius, make3(q.x, q.y, q.z), make3(mp.x, mp.y, mp.z));
+        if (dist > a.dmax) return 0u;
+    }
     ++pass;
     float4 sr = a.sref[sorted_idx];
     if (sr.w != mp.w) return 0u; /* use_tangent != is_tangent, reference :472 */
