@@ -221,6 +221,23 @@ float tm_traits_intrinsic_distance(int kind, const float* state, const float p0[
 int tm_traits_project_cloud(tm_ctx* ctx, int kind, const float* state, const float* surfels,
                             uint32_t n, float* uvw_surfels, int32_t* valid);
 
+/* ---- HIP equivalents of the reference's orphaned OpenCL kernels (opencl/icp.cl, cylinder.cl) ----
+ * icp_projection (opencl/icp.cl:1-53, with uv_project opencl/cylinder.cl:1-25 and mat44_multiply
+ * opencl/util.cl:1-9): per scene point align -> cylinder unroll -> normalise -> pixel lookup in the
+ * model's uv image -> correspondence within max_corr_dist. Outputs exactly as the OpenCL kernel:
+ * out_positions4[i] = uv_nrm (or (0,0,0,dist) / zeros), model_indices[i] = pixel index or -1,
+ * scene_indices[i] = i or -1. *n_corr = number of correspondences (wave-ballot count). */
+int tm_cl_icp_projection(tm_ctx* ctx, const float* pnts4, int n, const float* image4, const int img_size[2],
+                         const int img_margin[2], const float* mat_align16, const float* mat_uvw16,
+                         const float* mat_proj16, const float* mat_norm16, float max_corr_dist,
+                         float* out_positions4, int* model_indices, int* scene_indices, uint32_t* n_corr);
+/* icp_correlation (opencl/icp.cl:55-86) fused with the sum the reference never shipped: returns the
+ * 3x3 cross-covariance sum_i (scene[is_i]-cs)(model[im_i]-cm)^T / (n-1), row-major in cov9
+ * (cov9[3*r+c] = scene component c x model component r, the s0..s8 order of the OpenCL kernel). */
+int tm_cl_icp_correlation(tm_ctx* ctx, const float* scene4, uint32_t n_scene, const float* model4,
+                          uint32_t n_model, const int* indices_scene, const int* indices_model, int n,
+                          const float centroid_scene[4], const float centroid_model[4], double cov9[9]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -473,3 +473,50 @@ def test_projected_traits_pipeline(gpu_ctx, kind):
         gm2.build_voxels()
         c_l2, _ = gs.score_hypotheses(gm2, poses, DT)
         assert (cg >= c_l2).all()
+
+
+def test_opencl_kernel_equivalents(gpu_ctx):
+    """HIP twins of the reference's orphaned OpenCL kernels: icp_projection (opencl/icp.cl:1-53 +
+    cylinder.cl uv_project) bit-exact against the oracle's transcription, icp_correlation (:55-86)
+    summed to the 3x3 cross-covariance against a float64 numpy evaluation."""
+    from oracle import tmo as o
+    rng = np.random.default_rng(9)
+    n, W, H = 5000, 96, 64
+    theta = rng.random(n) * 2 * np.pi
+    pts = np.stack([np.cos(theta) * (1 + rng.normal(size=n) * 0.01), np.sin(theta) * (1 + rng.normal(size=n) * 0.01),
+                    rng.random(n), np.ones(n)], 1).astype(np.float32)
+    image = np.zeros((W * H, 4), np.float32)
+    image[:, 0] = np.tile((np.arange(W) + 0.5) / W, H)
+    image[:, 1] = np.repeat((np.arange(H) + 0.5) / H, W)
+    eye = np.eye(4, dtype=np.float32).T.reshape(16)
+    al = np.eye(4, dtype=np.float32)
+    al[:3, :3] = synth.random_rotation(rng, upright=True)
+    al = np.ascontiguousarray(al.T.reshape(16))
+    size = np.array([W, H], np.int32)
+    margin = np.array([2, 3], np.int32)
+    out, mi, si, cnt = capi.cl_icp_projection(gpu_ctx, pts, image, size, margin, al, eye, eye, eye, 0.02)
+    exp_out = np.zeros_like(out)
+    exp_mi = np.zeros(n, np.int32)
+    exp_si = np.zeros(n, np.int32)
+    L = o.lib()
+    import ctypes as C
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    L.tmo_cl_icp_projection(fp(pts), n, fp(image), ip(size), ip(margin), fp(al), fp(eye), fp(eye), fp(eye),
+                            C.c_float(0.02), fp(exp_out), ip(exp_mi), ip(exp_si))
+    assert np.array_equal(mi, exp_mi) and np.array_equal(si, exp_si)
+    assert np.array_equal(bits(out), bits(exp_out))
+    assert cnt == int((exp_mi >= 0).sum()) and 0 < cnt < n
+    # correlation
+    scene4 = rng.normal(size=(4000, 4)).astype(np.float32)
+    model4 = rng.normal(size=(3000, 4)).astype(np.float32)
+    k = 2500
+    ia = rng.integers(0, 4000, k).astype(np.int32)
+    ib = rng.integers(0, 3000, k).astype(np.int32)
+    cs = scene4[ia].mean(0).astype(np.float32)
+    cm = model4[ib].mean(0).astype(np.float32)
+    cov = capi.cl_icp_correlation(gpu_ctx, scene4, model4, ia, ib, cs, cm)
+    S = (scene4[ia, :3].astype(np.float32) - cs[:3]).astype(np.float64)
+    M = (model4[ib, :3].astype(np.float32) - cm[:3]).astype(np.float64)
+    ref = (M.T @ S) / (k - 1)  # cov9[3*r + c] = model r x scene c
+    assert np.allclose(cov.reshape(3, 3), ref, rtol=1e-5, atol=1e-7)  # fp32 products, tolerance 1e-5

@@ -101,6 +101,10 @@ SIGNATURES = {
     "tm_traits_normal": (None, [C.c_int, f32p, f32p, f32p]),
     "tm_traits_intrinsic_distance": (C.c_float, [C.c_int, f32p, f32p, f32p]),
     "tm_traits_project_cloud": (C.c_int, [vp, C.c_int, f32p, f32p, C.c_uint32, f32p, i32p]),
+    "tm_cl_icp_projection": (C.c_int, [vp, f32p, C.c_int, f32p, i32p, i32p, f32p, f32p, f32p, f32p, C.c_float,
+                                       f32p, i32p, i32p, u32p]),
+    "tm_cl_icp_correlation": (C.c_int, [vp, f32p, C.c_uint32, f32p, C.c_uint32, i32p, i32p, C.c_int, f32p, f32p,
+                                        f64p]),
 }
 
 _lib = None
@@ -292,6 +296,37 @@ class Context:
         _check(lib().tm_traits_project_cloud(self.h, kind, pst, ps, s.shape[0],
                                              out.ctypes.data_as(f32p), valid_.ctypes.data_as(i32p)))
         return out, valid_
+
+
+def cl_icp_projection(ctx, pnts4, image4, img_size, img_margin, mat_align, mat_uvw, mat_proj, mat_norm,
+                      max_corr_dist):
+    p, pp = _f(np.asarray(pnts4).reshape(-1, 4))
+    im, pim = _f(np.asarray(image4).reshape(-1, 4))
+    sz, psz = _i(img_size)
+    mg, pmg = _i(img_margin)
+    mats = [_f(m) for m in (mat_align, mat_uvw, mat_proj, mat_norm)]
+    n = p.shape[0]
+    out = np.zeros((n, 4), np.float32)
+    mi = np.zeros(n, np.int32)
+    si = np.zeros(n, np.int32)
+    cnt = C.c_uint32(0)
+    _check(lib().tm_cl_icp_projection(ctx.h, pp, n, pim, psz, pmg, mats[0][1], mats[1][1], mats[2][1], mats[3][1],
+                                      max_corr_dist, out.ctypes.data_as(f32p), mi.ctypes.data_as(i32p),
+                                      si.ctypes.data_as(i32p), C.byref(cnt)))
+    return out, mi, si, cnt.value
+
+
+def cl_icp_correlation(ctx, scene4, model4, idx_scene, idx_model, centroid_scene, centroid_model):
+    s, ps = _f(np.asarray(scene4).reshape(-1, 4))
+    m, pm = _f(np.asarray(model4).reshape(-1, 4))
+    a, pa = _i(idx_scene)
+    b, pb = _i(idx_model)
+    cs, pcs = _f(centroid_scene)
+    cm, pcm = _f(centroid_model)
+    cov = np.zeros(9, np.float64)
+    _check(lib().tm_cl_icp_correlation(ctx.h, ps, s.shape[0], pm, m.shape[0], pa, pb, a.size, pcs, pcm,
+                                       cov.ctypes.data_as(f64p)))
+    return cov
 
 
 def best_select(records):

@@ -39,6 +39,91 @@ __global__ void k_project_cloud(int kind, const float* __restrict__ state, const
     valid[t] = 1;
 }
 
+/* column-major 4x4 * float4, left-to-right sum like opencl/util.cl:4-7 */
+__device__ __forceinline__ float4 cl_mat44(float4 p, const float* __restrict__ m) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * p.w,
+                       m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * p.w,
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * p.w,
+                       m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15] * p.w);
+}
+
+/* opencl/cylinder.cl:1-25 */
+__device__ __forceinline__ float4 cl_uv_project(float4 loc, const float* __restrict__ cyl2ncoord) {
+    float4 nc = cl_mat44(loc, cyl2ncoord);
+    float u = atan2_def(nc.y, nc.x) / 3.14159265358979323846f; /* atan2pi */
+    if (u < 0.f) u += 2.f;
+    u /= 2.f;
+    return make_float4(u, nc.z, sqrtf(nc.x * nc.x + nc.y * nc.y) - 1.0f, 1.f);
+}
+
+/* opencl/icp.cl:1-53: one thread per scene point, float4 coalesced load, one image gather */
+__global__ void k_icp_projection(const float4* __restrict__ pnts, int n, const float4* __restrict__ image,
+                                 int2 img_size, int2 img_margin, const float* __restrict__ mats /* 4 x 16 */,
+                                 float max_corr_dist, float4* __restrict__ out_positions,
+                                 int* __restrict__ model_indices, int* __restrict__ scene_indices,
+                                 unsigned int* __restrict__ n_corr) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    bool corr = false;
+    if (index < n) {
+        const float* mat_align = mats;
+        const float* mat_uvw = mats + 16;
+        const float* mat_proj = mats + 32;
+        const float* mat_norm = mats + 48;
+        float4 loc = cl_mat44(pnts[index], mat_align);
+        float4 uv = cl_uv_project(loc, mat_proj);
+        float4 uvn = cl_mat44(cl_mat44(uv, mat_norm), mat_uvw);
+        float extx = (float)(img_size.x - 2 * img_margin.x - 1), exty = (float)(img_size.y - 2 * img_margin.y - 1);
+        int px = (int)(uvn.x * extx) + img_margin.x;
+        int py = (int)(uvn.y * exty) + img_margin.y;
+        if (py == img_size.y) py = img_size.y - 1;
+        int mi = -1, si = -1;
+        float4 outp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (px >= 0 && px < img_size.x && py >= 0 && py < img_size.y) {
+            int idx = py * img_size.x + px;
+            float4 im = image[idx];
+            float dx = im.x - uvn.x, dy = im.y - uvn.y;
+            float dist = sqrtf(dx * dx + dy * dy);
+            outp.w = dist;
+            if (dist < max_corr_dist) {
+                mi = idx;
+                si = index;
+                outp = uvn;
+                corr = true;
+            }
+        }
+        model_indices[index] = mi;
+        scene_indices[index] = si;
+        out_positions[index] = outp;
+    }
+    unsigned long long b = __ballot(corr);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_corr, (unsigned int)__popcll(b));
+}
+
+/* opencl/icp.cl:55-86 fused with its missing reduction: per-thread products in f64, wave shuffle,
+ * one atomic per wave and matrix entry */
+__global__ void k_icp_correlation(const float4* __restrict__ scene, const float4* __restrict__ model,
+                                  const int* __restrict__ is, const int* __restrict__ im, int n, float4 cs,
+                                  float4 cm, double* __restrict__ cov9) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    if (index < n) {
+        float4 s = scene[is[index]], m = model[im[index]];
+        float sx = s.x - cs.x, sy = s.y - cs.y, sz = s.z - cs.z;
+        float mx = m.x - cm.x, my = m.y - cm.y, mz = m.z - cm.z;
+        float norm = 1.f / (float)(n - 1);
+        acc[0] = sx * mx * norm; acc[1] = sy * mx * norm; acc[2] = sz * mx * norm;
+        acc[3] = sx * my * norm; acc[4] = sy * my * norm; acc[5] = sz * my * norm;
+        acc[6] = sx * mz * norm; acc[7] = sy * mz * norm; acc[8] = sz * mz * norm;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        if ((threadIdx.x & 63) == 0 && acc[k] != 0.0) atomicAdd(&cov9[k], acc[k]);
+    }
+}
+
 }  // namespace tmx
 
 using namespace tmx;
@@ -139,6 +224,105 @@ int tm_traits_project_cloud(tm_ctx* c, int kind, const float* state, const float
     cleanup();
     if (e != hipSuccess) {
         set_error("tm_traits_project_cloud: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
+int tm_cl_icp_projection(tm_ctx* c, const float* pnts4, int n, const float* image4, const int img_size[2],
+                         const int img_margin[2], const float* mat_align16, const float* mat_uvw16,
+                         const float* mat_proj16, const float* mat_norm16, float max_corr_dist,
+                         float* out_positions4, int* model_indices, int* scene_indices, uint32_t* n_corr) {
+    TM_REQUIRE(c && pnts4 && image4 && img_size && img_margin && mat_align16 && mat_uvw16 && mat_proj16 &&
+                   mat_norm16 && out_positions4 && model_indices && scene_indices,
+               TM_ERR_INVALID, "tm_cl_icp_projection: null argument");
+    TM_REQUIRE(n >= 0 && img_size[0] > 0 && img_size[1] > 0, TM_ERR_INVALID, "tm_cl_icp_projection: bad sizes");
+    if (n_corr) *n_corr = 0;
+    if (n == 0) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const size_t npix = (size_t)img_size[0] * img_size[1];
+    dbuf<float4> d_p, d_img, d_out;
+    dbuf<float> d_m;
+    dbuf<int> d_mi, d_si;
+    dbuf<unsigned int> d_n;
+    auto cleanup = [&]() {
+        d_p.release(); d_img.release(); d_out.release(); d_m.release(); d_mi.release(); d_si.release(); d_n.release();
+    };
+    int rc;
+    if ((rc = d_p.alloc(n)) || (rc = d_img.alloc(npix)) || (rc = d_out.alloc(n)) || (rc = d_m.alloc(64)) ||
+        (rc = d_mi.alloc(n)) || (rc = d_si.alloc(n)) || (rc = d_n.alloc(1))) {
+        cleanup();
+        return rc;
+    }
+    float mats[64];
+    memcpy(mats, mat_align16, 64);
+    memcpy(mats + 16, mat_uvw16, 64);
+    memcpy(mats + 32, mat_proj16, 64);
+    memcpy(mats + 48, mat_norm16, 64);
+    hipError_t e = hipMemcpyAsync(d_p.p, pnts4, (size_t)n * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_img.p, image4, npix * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m.p, mats, sizeof(mats), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_n.p, 0, 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_icp_projection, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_p.p, n, d_img.p,
+                           make_int2(img_size[0], img_size[1]), make_int2(img_margin[0], img_margin[1]), d_m.p,
+                           max_corr_dist, d_out.p, d_mi.p, d_si.p, d_n.p);
+        e = hipGetLastError();
+    }
+    unsigned int h_n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(out_positions4, d_out.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(model_indices, d_mi.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(scene_indices, d_si.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_n, d_n.p, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_cl_icp_projection: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    if (n_corr) *n_corr = h_n;
+    return TM_OK;
+}
+
+int tm_cl_icp_correlation(tm_ctx* c, const float* scene4, uint32_t n_scene, const float* model4, uint32_t n_model,
+                          const int* indices_scene, const int* indices_model, int n, const float centroid_scene[4],
+                          const float centroid_model[4], double cov9[9]) {
+    TM_REQUIRE(c && scene4 && model4 && indices_scene && indices_model && centroid_scene && centroid_model && cov9,
+               TM_ERR_INVALID, "tm_cl_icp_correlation: null argument");
+    TM_REQUIRE(n >= 2, TM_ERR_INVALID, "tm_cl_icp_correlation: needs at least two correspondences");
+    for (int i = 0; i < n; ++i)
+        TM_REQUIRE(indices_scene[i] >= 0 && (uint32_t)indices_scene[i] < n_scene && indices_model[i] >= 0 &&
+                       (uint32_t)indices_model[i] < n_model,
+                   TM_ERR_INVALID, "tm_cl_icp_correlation: index out of range");
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    dbuf<float4> d_s, d_m;
+    dbuf<int> d_is, d_im;
+    dbuf<double> d_cov;
+    auto cleanup = [&]() { d_s.release(); d_m.release(); d_is.release(); d_im.release(); d_cov.release(); };
+    int rc;
+    if ((rc = d_s.alloc(n_scene)) || (rc = d_m.alloc(n_model)) || (rc = d_is.alloc(n)) || (rc = d_im.alloc(n)) ||
+        (rc = d_cov.alloc(9))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_s.p, scene4, (size_t)n_scene * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m.p, model4, (size_t)n_model * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_is.p, indices_scene, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_im.p, indices_model, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cov.p, 0, 72, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_icp_correlation, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_s.p, d_m.p, d_is.p,
+                           d_im.p, n,
+                           make_float4(centroid_scene[0], centroid_scene[1], centroid_scene[2], centroid_scene[3]),
+                           make_float4(centroid_model[0], centroid_model[1], centroid_model[2], centroid_model[3]),
+                           d_cov.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cov9, d_cov.p, 72, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_cl_icp_correlation: %s", hipGetErrorString(e));
         return TM_ERR_HIP;
     }
     return TM_OK;
