@@ -162,8 +162,9 @@ def main():
     E, P, Hh = evals / args.steps, passing / args.steps, hyps / args.steps
     alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = measured_traffic(args)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
                 "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes}
 
@@ -192,6 +193,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args):
+    """HBM bytes per scoring launch from the committed PMC passes (profiles/r01/traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied);
+    null when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = t.get("workload", {})
+    if (w.get("model_points") == args.model_points and w.get("scene_points") == args.scene_points
+            and w.get("hyp_per_batch") == args.hyp_per_batch and w.get("mode") == args.mode):
+        return t.get("traffic_bytes_per_launch")
+    return None
 
 
 def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp, dist_thres,
