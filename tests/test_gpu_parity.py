@@ -520,3 +520,29 @@ def test_opencl_kernel_equivalents(gpu_ctx):
     M = (model4[ib, :3].astype(np.float32) - cm[:3]).astype(np.float64)
     ref = (M.T @ S) / (k - 1)  # cov9[3*r + c] = model r x scene c
     assert np.allclose(cov.reshape(3, 3), ref, rtol=1e-5, atol=1e-7)  # fp32 products, tolerance 1e-5
+
+
+def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
+    """the default kd-tree voxel build and the LDS-tiled exhaustive kernel give the same table
+    (20k-point model, ~5e6 voxels), including duplicated points (ties -> lowest original index)."""
+    import os
+    model, _ = synth.synth_model(20000, seed=4)
+    model[15000:15500, 0:3] = model[100:600, 0:3]  # exact duplicates at higher indices
+    res = synth.resolution(model)
+    a = capi.Model(gpu_ctx, model, res)
+    a.build_voxels()
+    va = a.voxels()
+    os.environ["TM_VOXEL_BRUTEFORCE"] = "1"
+    try:
+        b = capi.Model(gpu_ctx, model, res)
+        b.build_voxels()
+        vb = b.voxels()
+    finally:
+        del os.environ["TM_VOXEL_BRUTEFORCE"]
+    assert va.size > 4_000_000 and np.array_equal(va, vb)
+    assert not np.isin(va, np.arange(15000, 15500)).any()  # duplicates never win over their originals
+    poses = np.eye(4, dtype=np.float32).reshape(1, 16)
+    s = capi.Scene(gpu_ctx, model, (np.linalg.norm(model[:, 9:12], axis=1) > 0.7).astype(np.int32))
+    ca, _ = s.score_hypotheses(a, poses, DT)
+    cb, _ = s.score_hypotheses(b, poses, DT)
+    assert np.array_equal(ca, cb) and ca[0] > 19000  # brick codes agree as well

@@ -109,6 +109,78 @@ __global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos
     }
 }
 
+/* Exact NN per voxel by kd-tree descent (same answer as the brute-force scan: a far subtree is skipped
+ * only when its split distance squared EXCEEDS the best d2 — rounding is monotone, so fl(diff^2) <= fl(d2)
+ * for every point behind the split — and equal d2 goes to the lowest original index). A wave owns one
+ * 4x4x4 brick, so its 64 lanes walk nearly the same path. Stack of (node, bound) pairs in LDS. */
+constexpr int kKdStack = 24;
+
+__global__ __launch_bounds__(256) void k_voxel_nn_kd(const int4* __restrict__ nodes,
+                                                     const float4* __restrict__ pts,
+                                                     const uint32_t* __restrict__ new2orig, grid_t g,
+                                                     uint64_t voxel_slots, int bx, int by,
+                                                     uint32_t* __restrict__ voxels,
+                                                     uint32_t* __restrict__ brick_min_bits) {
+    __shared__ uint32_t st_node[kKdStack][256];
+    __shared__ float st_bound[kKdStack][256];
+    const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
+    const uint32_t bk = brick / (uint32_t)(bx * by);
+    const uint32_t br = brick - bk * (uint32_t)(bx * by);
+    const uint32_t bj = br / (uint32_t)bx, bi = br - bj * (uint32_t)bx;
+    const uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
+    const bool live = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
+    const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
+    float q[3];
+    q[0] = isx * (float)i + (-(g.tx * isx));
+    q[1] = isy * (float)j + (-(g.ty * isy));
+    q[2] = isz * (float)k + (-(g.tz * isz));
+    float best = __builtin_inff();
+    uint32_t besti = 0xFFFFFFFFu, besto = 0xFFFFFFFFu;
+    if (live) {
+        int sp = 0;
+        st_node[0][threadIdx.x] = 0u;
+        st_bound[0][threadIdx.x] = 0.f;
+        sp = 1;
+        while (sp > 0) {
+            --sp;
+            uint32_t node = st_node[sp][threadIdx.x];
+            if (st_bound[sp][threadIdx.x] > best) continue;
+            int4 nd = nodes[node];
+            while (nd.y != 3) {
+                float diff = q[nd.y] - __int_as_float(nd.x);
+                uint32_t nearc = diff < 0.f ? (uint32_t)nd.z : (uint32_t)nd.w;
+                uint32_t farc = diff < 0.f ? (uint32_t)nd.w : (uint32_t)nd.z;
+                if (sp < kKdStack) {
+                    st_node[sp][threadIdx.x] = farc;
+                    st_bound[sp][threadIdx.x] = diff * diff;
+                    ++sp;
+                }
+                node = nearc;
+                nd = nodes[node];
+            }
+            for (int p = nd.z; p < nd.w; ++p) {
+                float4 P = pts[p];
+                float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                float d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 <= best) {
+                    uint32_t ni = __float_as_uint(P.w);
+                    uint32_t o = new2orig[ni];
+                    if (d2 < best || o < besto) {
+                        best = d2;
+                        besti = ni;
+                        besto = o;
+                    }
+                }
+            }
+        }
+    }
+    if (slot < voxel_slots) voxels[slot] = live ? besti : 0u;
+    uint32_t b = live ? __float_as_uint(best) : 0x7F7F7F7Fu;
+    for (int off = 32; off > 0; off >>= 1) b = min(b, (uint32_t)__shfl_down((int)b, off));
+    if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = b;
+}
+
 /* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
 __global__ void k_unbrick(const uint32_t* __restrict__ bricked, const uint32_t* __restrict__ new2orig,
                           grid_t g, int bx, int by, uint64_t count, uint32_t* __restrict__ dense) {
@@ -326,6 +398,42 @@ __global__ void k_query_one(const uint32_t* __restrict__ ht_slot, const uint4* _
     }
 }
 
+/* host: median-split kd-tree over the finite points (Morton-ordered arrays, `idx` = new indices) */
+struct kd_builder {
+    const std::vector<float4>* pos;
+    std::vector<int4> nodes;
+    std::vector<uint32_t> order;
+    int build(int b, int e, int depth) {
+        int id = (int)nodes.size();
+        nodes.push_back(make_int4(0, 3, b, e));
+        if (e - b <= 8 || depth >= kKdStack - 2) return id;
+        float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int i = b; i < e; ++i) {
+            const float4& p = (*pos)[order[i]];
+            const float c[3] = {p.x, p.y, p.z};
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = std::min(mn[d], c[d]);
+                mx[d] = std::max(mx[d], c[d]);
+            }
+        }
+        int dim = 0;
+        if (mx[1] - mn[1] > mx[dim] - mn[dim]) dim = 1;
+        if (mx[2] - mn[2] > mx[dim] - mn[dim]) dim = 2;
+        if (!(mx[dim] - mn[dim] > 0.f)) return id;
+        int mid = (b + e) / 2;
+        auto coord = [&](uint32_t i) { const float4& p = (*pos)[i]; return dim == 0 ? p.x : (dim == 1 ? p.y : p.z); };
+        std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e,
+                         [&](uint32_t a, uint32_t c) { return coord(a) < coord(c); });
+        float split = coord(order[mid]);
+        int l = build(b, mid, depth + 1);
+        int r = build(mid, e, depth + 1);
+        int sb;
+        memcpy(&sb, &split, 4);
+        nodes[id] = make_int4(sb, dim, l, r);
+        return id;
+    }
+};
+
 /* host: bbox / diameter / to_voxel, reference include/impl/model.hpp:24-61 */
 static int setup_grid(tm_model* m) {
     const float big = std::numeric_limits<float>::max();
@@ -446,13 +554,35 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
         memcpy(&w, &i, 4);
         vpos[k] = make_float4(pos[k].x, s[1], s[2], w);
     }
+    /* kd-tree for the voxel build */
+    std::vector<float4> kd_pts;
+    kd_builder kb;
+    kb.pos = &pos;
+    for (uint32_t k = 0; k < n; ++k)
+        if (pos[k].x == pos[k].x) kb.order.push_back(k);
+    if (!kb.order.empty()) kb.build(0, (int)kb.order.size(), 0);
+    kd_pts.resize(kb.order.size());
+    for (size_t k = 0; k < kb.order.size(); ++k) {
+        const float4& p = pos[kb.order[k]];
+        float w;
+        uint32_t ni = kb.order[k];
+        memcpy(&w, &ni, 4);
+        kd_pts[k] = make_float4(p.x, p.y, p.z, w);
+    }
+    m->kd_n_nodes = (uint32_t)kb.nodes.size();
+    m->kd_n_pts = (uint32_t)kd_pts.size();
     int rc;
     if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n)) ||
-        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n))) {
+        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->kd_nodes.alloc(kb.nodes.size())) ||
+        (rc = m->kd_pts.alloc(kd_pts.size()))) {
         tm_model_destroy(m);
         return rc;
     }
     hipError_t e = hipMemcpyAsync(m->pos.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !kb.nodes.empty())
+        e = hipMemcpyAsync(m->kd_nodes.p, kb.nodes.data(), kb.nodes.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !kd_pts.empty())
+        e = hipMemcpyAsync(m->kd_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->vpos.p, vpos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
@@ -489,6 +619,8 @@ int tm_model_destroy(tm_model* m) {
     m->ref.release();
     m->tan4.release();
     m->vpos.release();
+    m->kd_nodes.release();
+    m->kd_pts.release();
     m->new2orig.release();
     m->voxels.release();
     m->brick_min_bits.release();
@@ -523,8 +655,19 @@ int tm_model_build_voxels(tm_model* m) {
     uint64_t per_block = 256ull * kVoxVPT;
     uint64_t blocks = (m->voxel_slots + per_block - 1) / per_block;
     TM_REQUIRE(blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
-    hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->vpos.p, m->n,
-                       m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);
+    /* default: kd-tree descent per voxel; TM_VOXEL_BRUTEFORCE=1 selects the LDS-tiled exhaustive scan
+     * (same table, kept as the cross-check and for degenerate clouds without a tree) */
+    const bool brute = getenv("TM_VOXEL_BRUTEFORCE") != nullptr || m->kd_n_nodes == 0;
+    if (brute) {
+        hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->vpos.p, m->n,
+                           m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);
+    } else {
+        uint64_t kd_blocks = (m->voxel_slots + 255) / 256;
+        TM_REQUIRE(kd_blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
+        hipLaunchKernelGGL(k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_nodes.p,
+                           m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1],
+                           m->voxels.p, m->brick_min_bits.p);
+    }
     TM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_brick_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream,
                        m->brick_min_bits.p, n_bricks, m->brick_q, m->brick_code.p);
