@@ -179,6 +179,18 @@ int tm_score_hypotheses(tm_scene* scene, tm_model* model, int traits_kind, const
 int tm_score_hypotheses_dev(tm_scene* scene, tm_model* model, int traits_kind,
                             const float* d_poses16, uint32_t n_hyp, float dist_thres, int mode,
                             uint32_t* d_counts, double* d_scores);
+/* Neighbourhood-restricted scoring for a batch (find_in_subset scores every hypothesis on
+ * nn = radius_search_inclusive(m.diameter(), p1), include/impl/scene.hpp:273,326): hypothesis h is scored
+ * on the scene points whose squared distance to scene point centers[h] is <= radius*radius (same set as
+ * that radius search; masked points excluded), full pass. One launch for the whole batch: the ball test
+ * runs inside the culled kernel (tile level conservatively, point level exactly). */
+int tm_score_hypotheses_ball(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n_hyp,
+                             const uint32_t* centers, float radius, float dist_thres, uint32_t* counts,
+                             double* scores);
+int tm_score_hypotheses_ball_dev(tm_scene* scene, tm_model* model, const float* d_poses16, uint32_t n_hyp,
+                                 const uint32_t* d_centers, float radius, float dist_thres,
+                                 uint32_t* d_counts, double* d_scores);
+
 /* early-drop rule of project_ (include/impl/scene.hpp:422-426,492-506) evaluated exactly for a
  * batch: dropped_at[h] = checkpoint index (0..17) or -1, counts/scores/saved as project_ returns */
 int tm_score_hypotheses_early_drop(tm_scene* scene, tm_model* model, const float* poses16,

@@ -93,6 +93,30 @@ struct hip_backend {
               "tm_generate_hypotheses");
         poses.resize(count);
     }
+    bool supports_batched() const { return true; }
+    void generate_with_pairs(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses,
+                             std::vector<uint32_t>& pair_of_hyp) {
+        const uint32_t n_pairs = (uint32_t)(ij.size() / 2);
+        const uint32_t cap = n_pairs * (uint32_t)search::query_limit;
+        poses.resize(cap);
+        std::vector<uint32_t> prov(4 * (size_t)cap);
+        uint32_t count = 0, total = 0;
+        check(tm_generate_hypotheses(s, m, ij.data(), n_pairs, p.min_diameter_factor, p.max_diameter_factor,
+                                     p.force_up ? 1 : 0, search::query_limit, &poses[0].m[0], prov.data(), cap,
+                                     &count, &total),
+              "tm_generate_hypotheses");
+        poses.resize(count);
+        pair_of_hyp.resize(count);
+        for (uint32_t h = 0; h < count; ++h) pair_of_hyp[h] = prov[4 * (size_t)h];
+    }
+    void score_ball(const std::vector<search::pose_t>& poses, const std::vector<uint32_t>& centers, float radius,
+                    std::vector<uint32_t>& counts, std::vector<double>& scores) {
+        counts.assign(poses.size(), 0u);
+        scores.assign(poses.size(), 0.0);
+        check(tm_score_hypotheses_ball(s, m, &poses[0].m[0], (uint32_t)poses.size(), centers.data(), radius,
+                                       p.dist_thres, counts.data(), scores.data()),
+              "tm_score_hypotheses_ball");
+    }
     void score(const std::vector<search::pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
                std::vector<uint32_t>& counts, std::vector<double>& scores) {
         const uint32_t n = (uint32_t)poses.size();
@@ -161,6 +185,9 @@ public:
      * flag per point to apply it */
     void set_curvature_ok(const std::vector<uint8_t>& ok) { curvature_ok_ = ok; }
     void set_workers(uint32_t w) { workers_ = w; }
+    /* detail::early_drop of the reference (include/impl/scene.hpp:25) is true; switching it off scores
+     * every hypothesis to the end and enables the batched GPU path (16 first points per launch) */
+    void set_early_drop(bool on) { early_drop_ = on; }
 
     /* include/impl/scene.hpp:39-98 */
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
@@ -192,6 +219,7 @@ public:
         be.p.force_up = sample_params.force_up;
         be.p.max_icp_iterations = max_icp_iterations;
         be.p.workers = workers_;
+        be.p.early_drop = early_drop_;
         auto found = search::find_all(be, tangent_mask, be.p);
         std::vector<match_t> results;
         for (auto& c : found) {
@@ -230,6 +258,7 @@ protected:
     tm_scene* h_ = nullptr;
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
+    bool early_drop_ = true;
 };
 
 }  // namespace triplet_match

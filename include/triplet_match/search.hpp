@@ -64,6 +64,9 @@ struct params_t {
  *   void generate(const std::vector<uint32_t>& ij, std::vector<pose_t>& poses);   // visit order
  *   void score(const std::vector<pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
  *              std::vector<uint32_t>& counts, std::vector<double>& scores);       // project_ per pose
+ *   bool supports_batched();                          // optional fast path for early_drop == false:
+ *   void generate_with_pairs(ij, poses, pair_of_hyp); //   hypotheses + the sample pair each came from
+ *   void score_ball(poses, centers, radius, counts, scores); // each pose on the ball around its first point
  *   void extract(const pose_t& T, float dist_thres, candidate_t& out);            // finish_find
  *   void set_mask(const std::vector<int32_t>& mask);
  */
@@ -169,6 +172,30 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     std::vector<pose_t> poses;
     std::vector<uint32_t> counts;
     std::vector<double> scores;
+    /* Batched path (early_drop off): the valid samples of up to 16 first points go through one
+     * generate + one ball-restricted scoring launch; scanning the results in visit order gives the same
+     * first sufficient hypothesis as the one-first-point-at-a-time loop below. */
+    const bool batched = !p.early_drop && be.supports_batched();
+    std::vector<uint32_t> batch_ij, pair_of_hyp, centers;
+    auto flush_batch = [&]() {
+        if (batch_ij.empty() || !best_ts.empty()) {
+            batch_ij.clear();
+            return;
+        }
+        be.generate_with_pairs(batch_ij, poses, pair_of_hyp);
+        if (!poses.empty()) {
+            centers.resize(poses.size());
+            for (size_t h = 0; h < poses.size(); ++h) centers[h] = batch_ij[2 * (size_t)pair_of_hyp[h]];
+            be.score_ball(poses, centers, be.model_diameter(), counts, scores);
+            for (size_t h = 0; h < poses.size(); ++h)
+                if (scores[h] > 0.0 && (float)counts[h] > sufficient) {
+                    best_ts.push_back(poses[h]);
+                    break;
+                }
+        }
+        batch_ij.clear();
+    };
+    uint32_t firsts_in_batch = 0;
     for (uint32_t i : firsts) {
         if (fp_mask[i] || mask[i]) continue; /* :268 */
         ++cons;
@@ -195,6 +222,14 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             if (valid_samples > inner_bound) break; /* :350 */
         }
         if (ij.empty()) continue;
+        if (batched) {
+            batch_ij.insert(batch_ij.end(), ij.begin(), ij.end());
+            if (++firsts_in_batch == 16) {
+                flush_batch();
+                firsts_in_batch = 0;
+            }
+            continue;
+        }
         be.generate(ij, poses); /* :304-319, visit order */
         if (poses.empty()) continue;
         be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
@@ -206,6 +241,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             }
         }
     }
+    if (batched) flush_batch();
     std::vector<candidate_t> matches;
     for (size_t k = 0; k < best_ts.size() && matches.size() < 5; ++k) { /* :361-364 */
         candidate_t c;

@@ -50,6 +50,10 @@ struct oracle_backend {
         tmo_model_get_feature_bounds(m, bmin, bmax);
         return tmo_valid(f, bmin, bmax) != 0;
     }
+    bool supports_batched() const { return false; } /* the oracle always takes the one-at-a-time loop */
+    void generate_with_pairs(const std::vector<uint32_t>&, std::vector<search::pose_t>&, std::vector<uint32_t>&) {}
+    void score_ball(const std::vector<search::pose_t>&, const std::vector<uint32_t>&, float, std::vector<uint32_t>&,
+                    std::vector<double>&) {}
     void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
         uint32_t n = tmo_scene_radius_subset(s, i, radius, nullptr, 0);
         out.resize(n);
@@ -105,7 +109,8 @@ static void dump(const char* tag, const std::vector<search::candidate_t>& r) {
 
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
-    const bool both = std::string(argv[2]) == "both";
+    const bool both = std::string(argv[2]) == "both" || std::string(argv[2]) == "both_noearlydrop";
+    const bool no_early_drop = std::string(argv[2]) == "both_noearlydrop" || std::string(argv[2]) == "oracle_noearlydrop";
     std::ifstream in(argv[1], std::ios::binary);
     auto mcloud = read_cloud(in);
     auto scloud = read_cloud(in);
@@ -129,6 +134,7 @@ int main(int argc, char** argv) {
     p.accept_prob = 0.5f;
     p.max_icp_iterations = 2;
     p.workers = 4;
+    p.early_drop = !no_early_drop;
 
     oracle_backend ob;
     ob.m = tmo_model_create(mcloud->points[0].raw(), (uint32_t)mcloud->size(), res, 20.f, angle_step);

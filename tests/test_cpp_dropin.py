@@ -31,10 +31,11 @@ def _compile(name, extra=()):
     return out
 
 
-def _fixture(path, model_n=1500, scene_n=12000, copies=2):
+def _fixture(path, model_n=1500, scene_n=12000, copies=2, instance_points=None):
     model, _ = synth.synth_model(model_n, seed=1)
     res = synth.resolution(model)
-    scene = synth.synth_scene(scene_n, model_n, seed=2, copies=copies, model_resolution=res)
+    scene = synth.synth_scene(scene_n, model_n, seed=2, copies=copies, model_resolution=res,
+                              instance_points=instance_points)
     with open(path, "wb") as f:
         f.write(np.uint32(model.shape[0]).tobytes())
         f.write(model.tobytes())
@@ -81,3 +82,33 @@ def test_dropin_walkthrough(tmp_path):
     r = subprocess.run([exe, fx], capture_output=True, text=True, timeout=900)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASSED" in r.stdout and "FAIL" not in r.stdout
+
+
+def test_config1_5k_model_5k_scene_on_cpu_path(tmp_path):
+    """BASELINE.json configs[0]: identity traits, 5k-pt model vs 5k-pt scene, CPU path only (plumbing):
+    the host orchestration over the oracle finds the planted instance."""
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "c1.bin"), model_n=5000, scene_n=5000, copies=1, instance_points=3800)
+    r = subprocess.run([exe, fx, "oracle"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_config1_5k_model_5k_scene_hip_equals_oracle(tmp_path):
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "c1.bin"), model_n=5000, scene_n=5000, copies=1, instance_points=3800)
+    r = subprocess.run([exe, fx, "both"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batched_search_equals_one_at_a_time(tmp_path):
+    """early-drop off: the HIP backend takes the batched path (16 first points per generate + ball-scored
+    launch), the oracle backend the reference's one-first-point-at-a-time loop: identical results."""
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "case.bin"))
+    r = subprocess.run([exe, fx, "both_noearlydrop"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout

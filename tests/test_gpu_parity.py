@@ -546,3 +546,32 @@ def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
     ca, _ = s.score_hypotheses(a, poses, DT)
     cb, _ = s.score_hypotheses(b, poses, DT)
     assert np.array_equal(ca, cb) and ca[0] > 19000  # brick codes agree as well
+
+
+def test_ball_restricted_batch_scoring(gpu_small, oracle_small, small_case):
+    """one launch scores every hypothesis on radius_search_inclusive(diameter, p1) of ITS first sample
+    point — the set find_in_subset hands to project_ (include/impl/scene.hpp:273,326)."""
+    om, os_ = oracle_small["model"], oracle_small["scene"]
+    pairs = sample_pairs(small_case, om, n_first=12, per_first=4)
+    poses, prov = os_.generate_hypotheses(om, pairs)
+    poses, prov = poses[:1500], prov[:1500]
+    centers = pairs[prov[:, 0], 0].astype(np.uint32)
+    radius = om.diameter
+    cg, sg = gpu_small["scene"].score_hypotheses_ball(gpu_small["model"], poses, centers, radius, DT)
+    co = np.zeros(len(poses), np.uint32)
+    so = np.zeros(len(poses), np.float64)
+    for c in np.unique(centers):
+        sel = np.nonzero(centers == c)[0]
+        sub = os_.radius_subset(int(c), radius)
+        cc, ss, _ = os_.score_hypotheses(om, poses[sel], 0.5, DT, subset=sub, threads=4)
+        co[sel], so[sel] = cc, ss
+    assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    full, _ = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+    assert (cg <= full).all() and co.max() > 1000  # with r = diameter the ball rarely cuts an in-grid point
+    # a small radius really restricts
+    c2, _ = gpu_small["scene"].score_hypotheses_ball(gpu_small["model"], poses[:50], centers[:50], 0.1 * radius, DT)
+    sub_small = {int(c): os_.radius_subset(int(c), 0.1 * radius) for c in np.unique(centers[:50])}
+    for h in range(50):
+        cc, _, _ = os_.score_hypotheses(om, poses[h:h + 1], 0.5, DT, subset=sub_small[int(centers[h])])
+        assert c2[h] == cc[0]
+    assert (c2 < full[:50]).any()

@@ -87,6 +87,8 @@ SIGNATURES = {
                                       C.c_float, C.c_int, u32p, f64p]),
     "tm_score_hypotheses_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, C.c_float, C.c_int, vp,
                                           vp]),
+    "tm_score_hypotheses_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, u32p, f64p]),
+    "tm_score_hypotheses_ball_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_float, C.c_float, vp, vp]),
     "tm_score_hypotheses_early_drop": (C.c_int, [vp, vp, f32p, C.c_uint32, i32p, C.c_uint32,
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
@@ -512,6 +514,16 @@ class Scene:
                              mode=SCORE_AUTO, traits=IDENTITY):
         _check(lib().tm_score_hypotheses_dev(self.h, model.h, traits, d_poses, n_hyp, dist_thres,
                                              mode, d_counts, d_scores))
+
+    def score_hypotheses_ball(self, model, poses16, centers, radius, dist_thres):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        c, pc = _u(centers)
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        _check(lib().tm_score_hypotheses_ball(self.h, model.h, pP, n, pc, radius, dist_thres,
+                                              counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p)))
+        return counts, scores
 
     def score_hypotheses_early_drop(self, model, poses16, dist_thres, accept_prob, subset=None):
         P, pP = _f(np.asarray(poses16).reshape(-1, 16))

@@ -90,6 +90,9 @@ struct cull_args {
     float coord_max; /* max |coordinate| of the scene, for the rounding margin */
     float inv_q;     /* 1 / brick code quantum */
     float tcode;     /* (thres + slack) / q + 1: a brick code above this is farther than thres */
+    const uint32_t* centers; /* per hypothesis: scene (original) index of the ball centre, or null */
+    const float4* opos;      /* scene positions in original order (ball centres) */
+    float ball_r, ball_r2;   /* radius and radius*radius of the neighbourhood restriction */
 };
 
 __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, float rnorm, float abs_eps,
@@ -148,12 +151,24 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
     uint32_t cnt = 0, pass = 0, n_in = 0, n_near = 0;
     long long fx = 0;
     unsigned long long tiles_done = 0;
+    /* optional neighbourhood restriction: ball around the hypothesis' first sample point */
+    const bool ball = ca.centers != nullptr;
+    f3 bc = make3(0.f, 0.f, 0.f);
+    if (ball) {
+        float4 C = ca.opos[ca.centers[h]];
+        bc = make3(C.x, C.y, C.z);
+    }
+    const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
     for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kCullChunk) {
         /* level 1: the chunk's 64 super-tiles (64 tiles each), one lane each, wave 0 */
         if (wave == 0) {
             const uint32_t u = (t0 >> 6) + lane;
             bool hit = false;
-            if (u * 64u < ca.n_tiles) hit = sphere_hits_box(a, T, rnorm, abs_eps, ca.supers[u]);
+            if (u * 64u < ca.n_tiles) {
+                float4 sb = ca.supers[u];
+                hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
+                if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > ca.ball_r + sb.w * 1.00001f + ball_margin);
+            }
             unsigned long long mask = __ballot(hit);
             if (lane == 0) {
                 s_smask = mask;
@@ -167,8 +182,12 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             if (a.ablate == 5) break;
             if (!((smask >> r) & 1ull)) continue;
             const uint32_t t = t0 + r * 64u + lane;
-            if (t < ca.n_tiles && tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, ca.tiles[t]))
-                s_list[atomicAdd(&s_n, 1u)] = t;
+            if (t < ca.n_tiles) {
+                float4 tb = ca.tiles[t];
+                bool hit = tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb);
+                if (ball) hit = hit && !(len(make3(tb.x, tb.y, tb.z) - bc) > ca.ball_r + tb.w * 1.00001f + ball_margin);
+                if (hit) s_list[atomicAdd(&s_n, 1u)] = t;
+            }
         }
         __syncthreads();
         const uint32_t n = a.ablate == 4 ? 0u : s_n;
@@ -185,6 +204,10 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                 sidx[k] = (have ? s_list[i + k] : s_list[i]) * 64u + lane;
                 P[k] = a.spos[sidx[k]];
                 in[k] = have;
+                if (ball) { /* exact membership: (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point */
+                    f3 d = make3(P[k].x, P[k].y, P[k].z) - bc;
+                    in[k] = in[k] & (len2(d) <= ca.ball_r2);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -623,7 +646,8 @@ static int check_pair(const tm_scene* s, const tm_model* m) {
 /* launches the scoring kernels for poses already on the device; results stay on the device */
 static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* d_poses, uint32_t n_hyp,
                         const unsigned char* d_active, uint64_t n_active, float dist_thres, int mode,
-                        uint32_t* d_counts, double* d_scores) {
+                        uint32_t* d_counts, double* d_scores, const uint32_t* d_centers = nullptr,
+                        float ball_radius = 0.f) {
     TM_FORWARD(check_pair(s, m));
     TM_REQUIRE(traits_kind == m->metric_kind, TM_ERR_INVALID,
                "traits_kind differs from the model's metric (tm_model_set_metric)");
@@ -686,6 +710,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         ca.n_tiles = s->n_tiles;
         ca.coord_max = s->coord_max;
         ca.inv_q = 1.f / m->brick_q;
+        ca.centers = d_centers;
+        ca.opos = s->opos.p;
+        ca.ball_r = ball_radius;
+        ca.ball_r2 = ball_radius * ball_radius;
         ca.tcode = (thres + slack) / m->brick_q + 1.f;
         if (!(thres >= 0.f)) ca.tcode = 1e30f;
         hipLaunchKernelGGL(k_score_culled, dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
@@ -1049,6 +1077,44 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
         set_error("tm_score_hypotheses: %s", hipGetErrorString(e != hipSuccess ? e : e2));
         return TM_ERR_HIP;
     }
+    return TM_OK;
+}
+
+int tm_score_hypotheses_ball_dev(tm_scene* s, tm_model* m, const float* d_poses16, uint32_t n_hyp,
+                                 const uint32_t* d_centers, float radius, float dist_thres, uint32_t* d_counts,
+                                 double* d_scores) {
+    TM_REQUIRE(d_poses16 && d_centers && d_counts && d_scores, TM_ERR_INVALID,
+               "tm_score_hypotheses_ball_dev: null argument");
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(m->metric_kind <= TM_TRAITS_PLANE && m->voxels_ready, TM_ERR_UNSUPPORTED,
+               "ball-restricted scoring needs a built model with a 3-D L2 metric");
+    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+    return score_device(s, m, m->metric_kind, d_poses16, n_hyp, nullptr, count_active(s), dist_thres,
+                        TM_SCORE_CULLED, d_counts, d_scores, d_centers, radius);
+}
+
+int tm_score_hypotheses_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
+                             const uint32_t* centers, float radius, float dist_thres, uint32_t* counts,
+                             double* scores) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(counts && scores, TM_ERR_INVALID, "tm_score_hypotheses_ball: null outputs");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(poses16 && centers, TM_ERR_INVALID, "tm_score_hypotheses_ball: null inputs");
+    for (uint32_t h = 0; h < n_hyp; ++h)
+        TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "tm_score_hypotheses_ball: centre index out of range");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure((size_t)n_hyp * 16));
+    TM_FORWARD(s->w_counts.ensure(n_hyp));
+    TM_FORWARD(s->w_scores.ensure(n_hyp));
+    TM_FORWARD(s->w_u32a.ensure(n_hyp));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_u32a.p, centers, (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
+    TM_FORWARD(tm_score_hypotheses_ball_dev(s, m, s->w_poses.p, n_hyp, s->w_u32a.p, radius, dist_thres,
+                                            s->w_counts.p, s->w_scores.p));
+    TM_HIP_CHECK(hipMemcpyAsync(counts, s->w_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(scores, s->w_scores.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return TM_OK;
 }
 
