@@ -188,6 +188,7 @@ public:
     /* detail::early_drop of the reference (include/impl/scene.hpp:25) is true; switching it off scores
      * every hypothesis to the end and enables the batched GPU path (16 first points per launch) */
     void set_early_drop(bool on) { early_drop_ = on; }
+    void set_verbose(bool on) { verbose_ = on; }
 
     /* include/impl/scene.hpp:39-98 */
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
@@ -220,6 +221,7 @@ public:
         be.p.max_icp_iterations = max_icp_iterations;
         be.p.workers = workers_;
         be.p.early_drop = early_drop_;
+        be.p.verbose = verbose_;
         auto found = search::find_all(be, tangent_mask, be.p);
         std::vector<match_t> results;
         for (auto& c : found) {
@@ -259,6 +261,7 @@ protected:
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
     bool early_drop_ = true;
+    bool verbose_ = false;
 };
 
 }  // namespace triplet_match

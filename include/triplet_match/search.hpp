@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <random>
 #include <set>
 #include <vector>
@@ -53,6 +54,7 @@ struct params_t {
     uint32_t workers = 7;
     uint64_t seed = 13;
     bool early_drop = true; /* detail::early_drop, :25 */
+    bool verbose = false;   /* progress lines on stderr (the reference prints pdebug lines) */
 };
 
 /*
@@ -303,6 +305,9 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     outer_bound = std::max(outer_bound, min_sample_count);
     outer_bound = std::min<uint64_t>(outer_bound, n_scene);
     outer_bound = std::min<uint64_t>(outer_bound, left.size());
+    if (p.verbose)
+        fprintf(stderr, "[search] outer bound: %llu of %zu unmasked tangent points\n", (unsigned long long)outer_bound,
+                left.size()); /* the reference's pdebug("outer bound"), :152 */
     detail::partial_shuffle(left, (size_t)outer_bound, rng); /* sample + shuffle, :143-144 */
     std::vector<uint32_t> outer(left.begin(), left.begin() + (size_t)outer_bound);
     const uint32_t concurrency = std::max(1u, p.workers); /* :146 */
@@ -313,6 +318,9 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         std::vector<uint32_t> chunk(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
         auto res = find_in_subset(be, chunk, mask, fp_mask, tangent_mask, p);
         uint32_t cons = res.second;
+        if (p.verbose)
+            fprintf(stderr, "[search] chunk of %zu firsts: %u considered, %zu candidate(s)%s\n", chunk.size(), cons,
+                    res.first.size(), res.first.empty() ? "" : " found");
         for (uint32_t k = 0, seen = 0; k < chunk.size() && seen < cons; ++k, ++seen) fp_mask[chunk[k]] = 1; /* :160-162 */
         for (auto& mt : res.first) cands.push_back(icp(be, mt, p)); /* :169-171 */
     }
@@ -336,6 +344,9 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
         for (uint32_t idx : out.scene_corrs)
             if (tangent_mask[idx]) ++score;
+        if (p.verbose)
+            fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
+                    cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
         if (score < min_points || score_all < min_points_all) { /* :227 */
             used = used_copy;
             continue;

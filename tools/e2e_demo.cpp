@@ -1,0 +1,69 @@
+/* e2e_demo.cpp — times the drop-in scene<Point>::find_all_parallel on a fixture written by
+ * tests/test_cpp_dropin.py::_fixture (model, scene, resolution, ground-truth poses).
+ * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] */
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+
+#include "triplet_match/scene.hpp"
+
+using namespace triplet_match;
+typedef PointSurfel P;
+
+static pointcloud<P>::Ptr read_cloud(std::ifstream& in) {
+    uint32_t n = 0;
+    in.read((char*)&n, 4);
+    auto c = pointcloud<P>::empty();
+    c->points.resize(n);
+    in.read((char*)c->points.data(), (std::streamsize)n * 48);
+    return c;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    const bool early_drop = argc > 2 ? atoi(argv[2]) != 0 : true;
+    const uint32_t icp = argc > 3 ? (uint32_t)atoi(argv[3]) : 2u;
+    std::ifstream in(argv[1], std::ios::binary);
+    auto mcloud = read_cloud(in);
+    auto scloud = read_cloud(in);
+    float res = 0.f;
+    in.read((char*)&res, 4);
+    uint32_t n_truth = 0;
+    in.read((char*)&n_truth, 4);
+    std::vector<mat4f_t> truth(n_truth);
+    for (auto& t : truth) in.read((char*)t.m, 64);
+    mcloud->set_resolution(res);
+    auto t0 = std::chrono::steady_clock::now();
+    discretization_params dp;
+    dp.distance_step_count = 20.f;
+    dp.angle_step = 10.f * (float)M_PI / 180.f;
+    model<P> m(mcloud, dp);
+    sample_parameters sp;
+    m.init(sp);
+    auto t1 = std::chrono::steady_clock::now();
+    scene<P> s(scloud);
+    s.set_early_drop(early_drop);
+    s.set_verbose(getenv("TM_SEARCH_VERBOSE") != nullptr);
+    auto matches = s.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
+    auto t2 = std::chrono::steady_clock::now();
+    printf("model %zu pts (tangent %u), scene %zu pts, planted %u\n", mcloud->size(), m.point_count(), scloud->size(), n_truth);
+    printf("model init %.3f s; find_all_parallel(early_drop=%d, icp=%u) %.3f s -> %zu matches\n",
+           std::chrono::duration<double>(t1 - t0).count(), (int)early_drop, icp,
+           std::chrono::duration<double>(t2 - t1).count(), matches.size());
+    for (const auto& mt : matches) {
+        double best = 1e30;
+        for (const auto& t : truth) {
+            mat4f_t m2s = t.inverse();
+            double err = 0;
+            for (size_t k = 0; k < mcloud->size(); k += 97) {
+                vec4f_t a = mt.transform * homogeneous(mcloud->points[k].getVector3fMap());
+                vec4f_t b = m2s * homogeneous(mcloud->points[k].getVector3fMap());
+                err = std::max(err, (double)(a.head3() - b.head3()).norm());
+            }
+            best = std::min(best, err);
+        }
+        printf("   match: %zu correspondences, score %.4f, max alignment error %.5f (= %.2f x resolution)\n",
+               mt.scene_corrs.size(), mt.signed_score, best, best / res);
+    }
+    return 0;
+}
