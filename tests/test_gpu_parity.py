@@ -575,3 +575,51 @@ def test_ball_restricted_batch_scoring(gpu_small, oracle_small, small_case):
         cc, _, _ = os_.score_hypotheses(om, poses[h:h + 1], 0.5, DT, subset=sub_small[int(centers[h])])
         assert c2[h] == cc[0]
     assert (c2 < full[:50]).any()
+
+
+def test_multi_model_one_scene(gpu_ctx):
+    """config-5 shape of work: several models against one scene, each with its own best record.
+    Two differently stretched models; the scene holds two instances of A and one of B."""
+    A, subA = synth.synth_model(1500, seed=1)
+    B, subB = synth.synth_model(1500, seed=7, scale=(0.7, 1.3, 1.1))
+    resA, resB = synth.resolution(A), synth.resolution(B)
+    sc = synth.synth_scene(12000, 1500, seed=2, copies=2, model_resolution=resA)
+    rng = np.random.default_rng(3)
+    instB, _ = synth.synth_model(1500, seed=8, scale=(0.7, 1.3, 1.1))
+    R = synth.random_rotation(rng)
+    t = np.array([4.0, 3.0, 1.5])
+    instB[:, 0:3] = instB[:, 0:3] @ R.T + t
+    instB[:, 4:7] = instB[:, 4:7] @ R.T
+    instB[:, 9:12] = instB[:, 9:12] @ R.T
+    surf = np.concatenate([sc["surfels"], instB]).astype(np.float32)
+    tmask = (np.linalg.norm(surf[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    TB = np.eye(4)
+    TB[:3, :3] = R
+    TB[:3, 3] = t
+    truthA = [synth.pose_colmajor(T) for T in sc["poses_scene_to_model"]]
+    truthB = [synth.pose_colmajor(np.linalg.inv(TB))]
+    poses = np.array(truthA + truthB, np.float32)
+    gs = capi.Scene(gpu_ctx, surf, tmask)
+    os_ = tmo.Scene(surf, tmask)
+    best = {}
+    for name, M, sub, res in (("A", A, subA, resA), ("B", B, subB, resB)):
+        gm = capi.Model(gpu_ctx, M, res)
+        gm.build_voxels()
+        gm.build_pairs(sub)
+        om = tmo.Model(M, res)
+        om.build_voxels(threads=4)
+        assert om.build_pairs(sub) == 0
+        cg, sg = gs.score_hypotheses(gm, poses, DT)
+        co, so, _ = os_.score_hypotheses(om, poses, 0.5, DT)
+        assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+        best[name] = cg
+    # each model recognises its own instances only
+    assert best["A"][:2].min() > 1100 and best["A"][2] < 0.8 * best["A"][:2].min()
+    assert best["B"][2] > 1100 and best["B"][:2].max() < 0.8 * best["B"][2]
+    recs = []
+    for k, name in enumerate(("A", "B")):
+        i = int(np.argmax(best[name]))
+        r = capi.BestRecord()
+        r.inlier_count, r.hyp_id, r.score = int(best[name][i]), i, 0.0
+        recs.append(r)
+    assert recs[0].hyp_id in (0, 1) and recs[1].hyp_id == 2  # per-model best records

@@ -96,10 +96,22 @@ def _band_width(rects, creases, edge_fraction, n, min_res_factor=1.5):
     return max(w_area, min_res_factor * expected_res)
 
 
-def synth_model(n, seed=1, edge_fraction=EDGE_FRACTION):
-    """n-point L-step model. Returns (surfels[n,12] f32, tangent_subset u32 ascending)."""
+def _scaled(rects, creases, scale):
+    sc = np.asarray(scale, dtype=np.float64)
+    if np.all(sc == 1.0):
+        return rects, creases
+    def nrm(v):
+        w = v / sc
+        return w / np.linalg.norm(w)
+    return ([(o * sc, a * sc, b * sc, nrm(n)) for (o, a, b, n) in rects],
+            [(p0 * sc, p1 * sc, nrm(n)) for (p0, p1, n) in creases])
+
+
+def synth_model(n, seed=1, edge_fraction=EDGE_FRACTION, scale=(1.0, 1.0, 1.0)):
+    """n-point L-step model (optionally stretched per axis: a different model for multi-model
+    searches). Returns (surfels[n,12] f32, tangent_subset u32 ascending)."""
     rng = np.random.default_rng(seed)
-    rects, creases = _rects_and_creases()
+    rects, creases = _scaled(*_rects_and_creases(), scale)
     pos, nrm = _sample_rects(rng, rects, n)
     tgt = _crease_tangents(pos, creases, _band_width(rects, creases, edge_fraction, n))
     s = _pack(pos, nrm, tgt)
