@@ -143,6 +143,7 @@ struct tm_scene {
     uint32_t n = 0;
     std::vector<float> h_cloud;
     std::vector<int32_t> h_tmask, h_mask;
+    std::vector<uint32_t> h_order; /* Morton order of the points (independent of the mask): sorted -> original */
     /* original order (hypothesis generation addresses points by original index) */
     tmx::dbuf<float4> opos;  /* xyz, w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> otan;  /* raw tangent xyz, w = masked ? 1 : 0 */

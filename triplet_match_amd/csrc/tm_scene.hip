@@ -512,19 +512,23 @@ static int build_sorted(tm_scene* s) {
     float cmax = 0.f;
     for (int d = 0; d < 3; ++d) cmax = std::max(cmax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
     s->coord_max = cmax;
-    std::vector<std::pair<uint64_t, uint32_t>> order(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* p = s->h_cloud.data() + (size_t)i * 12;
-        uint64_t code = ~0ull; /* non-finite points sort last */
-        if (fin3(p)) {
-            uint64_t ix = (uint64_t)(((double)p[0] - mn[0]) * inv);
-            uint64_t iy = (uint64_t)(((double)p[1] - mn[1]) * inv);
-            uint64_t iz = (uint64_t)(((double)p[2] - mn[2]) * inv);
-            code = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+    if (s->h_order.size() != n) { /* the order does not depend on the mask: sort once per scene */
+        std::vector<std::pair<uint64_t, uint32_t>> order(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* p = s->h_cloud.data() + (size_t)i * 12;
+            uint64_t code = ~0ull; /* non-finite points sort last */
+            if (fin3(p)) {
+                uint64_t ix = (uint64_t)(((double)p[0] - mn[0]) * inv);
+                uint64_t iy = (uint64_t)(((double)p[1] - mn[1]) * inv);
+                uint64_t iz = (uint64_t)(((double)p[2] - mn[2]) * inv);
+                code = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
+            }
+            order[i] = {code, i};
         }
-        order[i] = {code, i};
+        std::sort(order.begin(), order.end());
+        s->h_order.resize(n);
+        for (uint32_t k = 0; k < n; ++k) s->h_order[k] = order[k].second;
     }
-    std::sort(order.begin(), order.end());
     const uint32_t n_pad = ((n + kScoreTile - 1) / kScoreTile) * kScoreTile;
     const uint32_t n_tiles = n_pad / 64;
     const float nanv = std::numeric_limits<float>::quiet_NaN();
@@ -535,7 +539,7 @@ static int build_sorted(tm_scene* s) {
             sref[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
-        uint32_t i = order[k].second;
+        uint32_t i = s->h_order[k];
         const float* p = s->h_cloud.data() + (size_t)i * 12;
         float w;
         memcpy(&w, &i, 4);
