@@ -103,9 +103,10 @@ struct tm_model {
     std::vector<uint32_t> h_new2orig, h_orig2new;
     tmx::dbuf<uint32_t> new2orig;
     tmx::dbuf<float4> vpos; /* xyz (NaN if non-finite), w = bits of the ORIGINAL index (voxel build tie-break) */
-    /* kd-tree over the finite points for the voxel NN build: node = (split bits, dim or 3 = leaf,
-     * left | begin, right | end); kd_pts = leaf-ordered (xyz, NEW index bits) */
-    tmx::dbuf<int4> kd_nodes;
+    /* kd-tree over the finite points for the voxel NN build. Node i = bounding box + links:
+     * kd_lo[i] = (lo.xyz, bits a), kd_hi[i] = (hi.xyz, bits b); internal: a = left, b = right;
+     * leaf: a = begin | 0x80000000, b = end. kd_pts = leaf-ordered (xyz, NEW index bits) */
+    tmx::dbuf<float4> kd_lo, kd_hi;
     tmx::dbuf<float4> kd_pts;
     uint32_t kd_n_nodes = 0, kd_n_pts = 0;
     tmx::dbuf<float4> pos;  /* xyz, w = (|tangent| > 0.7) ? 1 : 0 ; non-finite points keep NaN */

@@ -109,13 +109,22 @@ __global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos
     }
 }
 
-/* Exact NN per voxel by kd-tree descent (same answer as the brute-force scan: a far subtree is skipped
- * only when its split distance squared EXCEEDS the best d2 — rounding is monotone, so fl(diff^2) <= fl(d2)
- * for every point behind the split — and equal d2 goes to the lowest original index). A wave owns one
- * 4x4x4 brick, so its 64 lanes walk nearly the same path. Stack of (node, bound) pairs in LDS. */
+/* Exact NN per voxel by kd-tree descent with bounding-box pruning. A subtree is skipped only when the
+ * squared distance from the query to its box EXCEEDS the best d2; per axis the box distance is
+ * max(0, lo - q, q - hi), and rounding is monotone, so fl(box d2) <= fl(d2) for every point inside: an
+ * equal-distance lower index is never lost. Equal d2 goes to the lowest original index. A wave owns one
+ * 4x4x4 brick, so its 64 lanes walk nearly the same path. (node, bound) stack in LDS. */
 constexpr int kKdStack = 24;
 
-__global__ __launch_bounds__(256) void k_voxel_nn_kd(const int4* __restrict__ nodes,
+__device__ __forceinline__ float box_d2(const float q[3], float4 lo, float4 hi) {
+    float dx = fmaxf(fmaxf(lo.x - q[0], q[0] - hi.x), 0.f);
+    float dy = fmaxf(fmaxf(lo.y - q[1], q[1] - hi.y), 0.f);
+    float dz = fmaxf(fmaxf(lo.z - q[2], q[2] - hi.z), 0.f);
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_nn_kd(const float4* __restrict__ kd_lo,
+                                                     const float4* __restrict__ kd_hi,
                                                      const float4* __restrict__ pts,
                                                      const uint32_t* __restrict__ new2orig, grid_t g,
                                                      uint64_t voxel_slots, int bx, int by,
@@ -138,47 +147,51 @@ __global__ __launch_bounds__(256) void k_voxel_nn_kd(const int4* __restrict__ no
     float best = __builtin_inff();
     uint32_t besti = 0xFFFFFFFFu, besto = 0xFFFFFFFFu;
     if (live) {
-        int sp = 0;
+        int sp = 1;
         st_node[0][threadIdx.x] = 0u;
         st_bound[0][threadIdx.x] = 0.f;
-        sp = 1;
         while (sp > 0) {
             --sp;
             uint32_t node = st_node[sp][threadIdx.x];
             if (st_bound[sp][threadIdx.x] > best) continue;
-            int4 nd = nodes[node];
-            while (nd.y != 3) {
-                float diff = q[nd.y] - __int_as_float(nd.x);
-                uint32_t nearc = diff < 0.f ? (uint32_t)nd.z : (uint32_t)nd.w;
-                uint32_t farc = diff < 0.f ? (uint32_t)nd.w : (uint32_t)nd.z;
-                if (sp < kKdStack) {
+            for (;;) {
+                const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
+                if (a & 0x80000000u) { /* leaf: points [begin, end) */
+                    for (uint32_t p = a & 0x7FFFFFFFu; p < b; ++p) {
+                        float4 P = pts[p];
+                        float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                        float d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (d2 <= best) {
+                            uint32_t ni = __float_as_uint(P.w);
+                            uint32_t o = new2orig[ni];
+                            if (d2 < best || o < besto) {
+                                best = d2;
+                                besti = ni;
+                                besto = o;
+                            }
+                        }
+                    }
+                    break;
+                }
+                /* internal: a = left child, b = right child; go to the nearer box, keep the other */
+                float dl = box_d2(q, kd_lo[a], kd_hi[a]);
+                float dr = box_d2(q, kd_lo[b], kd_hi[b]);
+                uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
+                float dn = fminf(dl, dr), df = fmaxf(dl, dr);
+                if (!(df > best) && sp < kKdStack) {
                     st_node[sp][threadIdx.x] = farc;
-                    st_bound[sp][threadIdx.x] = diff * diff;
+                    st_bound[sp][threadIdx.x] = df;
                     ++sp;
                 }
+                if (dn > best) break;
                 node = nearc;
-                nd = nodes[node];
-            }
-            for (int p = nd.z; p < nd.w; ++p) {
-                float4 P = pts[p];
-                float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
-                float d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 <= best) {
-                    uint32_t ni = __float_as_uint(P.w);
-                    uint32_t o = new2orig[ni];
-                    if (d2 < best || o < besto) {
-                        best = d2;
-                        besti = ni;
-                        besto = o;
-                    }
-                }
             }
         }
     }
     if (slot < voxel_slots) voxels[slot] = live ? besti : 0u;
-    uint32_t b = live ? __float_as_uint(best) : 0x7F7F7F7Fu;
-    for (int off = 32; off > 0; off >>= 1) b = min(b, (uint32_t)__shfl_down((int)b, off));
-    if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = b;
+    uint32_t bmin = live ? __float_as_uint(best) : 0x7F7F7F7Fu;
+    for (int off = 32; off > 0; off >>= 1) bmin = min(bmin, (uint32_t)__shfl_down((int)bmin, off));
+    if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = bmin;
 }
 
 /* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
@@ -398,15 +411,19 @@ __global__ void k_query_one(const uint32_t* __restrict__ ht_slot, const uint4* _
     }
 }
 
-/* host: median-split kd-tree over the finite points (Morton-ordered arrays, `idx` = new indices) */
+/* host: median-split kd-tree over the finite points (Morton-ordered arrays, `order` = new indices);
+ * every node carries the bounding box of its points */
 struct kd_builder {
     const std::vector<float4>* pos;
-    std::vector<int4> nodes;
+    std::vector<float4> lo, hi;
     std::vector<uint32_t> order;
+    static float u2f(uint32_t u) {
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
     int build(int b, int e, int depth) {
-        int id = (int)nodes.size();
-        nodes.push_back(make_int4(0, 3, b, e));
-        if (e - b <= 8 || depth >= kKdStack - 2) return id;
+        int id = (int)lo.size();
         float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
         for (int i = b; i < e; ++i) {
             const float4& p = (*pos)[order[i]];
@@ -416,6 +433,9 @@ struct kd_builder {
                 mx[d] = std::max(mx[d], c[d]);
             }
         }
+        lo.push_back(make_float4(mn[0], mn[1], mn[2], u2f((uint32_t)b | 0x80000000u)));
+        hi.push_back(make_float4(mx[0], mx[1], mx[2], u2f((uint32_t)e)));
+        if (e - b <= 8 || depth >= kKdStack - 2) return id;
         int dim = 0;
         if (mx[1] - mn[1] > mx[dim] - mn[dim]) dim = 1;
         if (mx[2] - mn[2] > mx[dim] - mn[dim]) dim = 2;
@@ -424,12 +444,10 @@ struct kd_builder {
         auto coord = [&](uint32_t i) { const float4& p = (*pos)[i]; return dim == 0 ? p.x : (dim == 1 ? p.y : p.z); };
         std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e,
                          [&](uint32_t a, uint32_t c) { return coord(a) < coord(c); });
-        float split = coord(order[mid]);
         int l = build(b, mid, depth + 1);
         int r = build(mid, e, depth + 1);
-        int sb;
-        memcpy(&sb, &split, 4);
-        nodes[id] = make_int4(sb, dim, l, r);
+        lo[id].w = u2f((uint32_t)l);
+        hi[id].w = u2f((uint32_t)r);
         return id;
     }
 };
@@ -569,18 +587,20 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
         memcpy(&w, &ni, 4);
         kd_pts[k] = make_float4(p.x, p.y, p.z, w);
     }
-    m->kd_n_nodes = (uint32_t)kb.nodes.size();
+    m->kd_n_nodes = (uint32_t)kb.lo.size();
     m->kd_n_pts = (uint32_t)kd_pts.size();
     int rc;
     if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n)) ||
-        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->kd_nodes.alloc(kb.nodes.size())) ||
+        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->kd_lo.alloc(kb.lo.size())) || (rc = m->kd_hi.alloc(kb.hi.size())) ||
         (rc = m->kd_pts.alloc(kd_pts.size()))) {
         tm_model_destroy(m);
         return rc;
     }
     hipError_t e = hipMemcpyAsync(m->pos.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && !kb.nodes.empty())
-        e = hipMemcpyAsync(m->kd_nodes.p, kb.nodes.data(), kb.nodes.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !kb.lo.empty())
+        e = hipMemcpyAsync(m->kd_lo.p, kb.lo.data(), kb.lo.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !kb.hi.empty())
+        e = hipMemcpyAsync(m->kd_hi.p, kb.hi.data(), kb.hi.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && !kd_pts.empty())
         e = hipMemcpyAsync(m->kd_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
@@ -619,7 +639,8 @@ int tm_model_destroy(tm_model* m) {
     m->ref.release();
     m->tan4.release();
     m->vpos.release();
-    m->kd_nodes.release();
+    m->kd_lo.release();
+    m->kd_hi.release();
     m->kd_pts.release();
     m->new2orig.release();
     m->voxels.release();
@@ -664,7 +685,7 @@ int tm_model_build_voxels(tm_model* m) {
     } else {
         uint64_t kd_blocks = (m->voxel_slots + 255) / 256;
         TM_REQUIRE(kd_blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
-        hipLaunchKernelGGL(k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_nodes.p,
+        hipLaunchKernelGGL(k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_lo.p, m->kd_hi.p,
                            m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1],
                            m->voxels.p, m->brick_min_bits.p);
     }
