@@ -623,3 +623,55 @@ def test_multi_model_one_scene(gpu_ctx):
         r.inlier_count, r.hyp_id, r.score = int(best[name][i]), i, 0.0
         recs.append(r)
     assert recs[0].hyp_id in (0, 1) and recs[1].hyp_id == 2  # per-model best records
+
+
+def test_edge_cases(gpu_ctx, gpu_small, oracle_small, small_case):
+    gm, gs = gpu_small["model"], gpu_small["scene"]
+    om, os_ = oracle_small["model"], oracle_small["scene"]
+    poses = random_poses_near_truth(small_case, 8)
+    # empty batches
+    c, s = gs.score_hypotheses(gm, np.zeros((0, 16), np.float32), DT)
+    assert len(c) == 0 and len(s) == 0
+    p, v, total = gs.generate_hypotheses(gm, np.zeros((0, 2), np.uint32))
+    assert len(p) == 0 and total == 0
+    # out-of-range and degenerate sample pairs are filtered, not faulted
+    n = small_case["scene"]["surfels"].shape[0]
+    bad = np.array([[n + 5, 0], [0, n + 7], [3, 3]], np.uint32)
+    p, v, total = gs.generate_hypotheses(gm, bad)
+    assert total == 0
+    # thresholds: huge (brick filter inert), zero and negative
+    for dt in (100.0, 0.0, -1.0):
+        co, _, _ = os_.score_hypotheses(om, poses, 0.5, dt)
+        for mode in (capi.SCORE_AUTO, capi.SCORE_BRUTEFORCE):
+            cg, _ = gs.score_hypotheses(gm, poses, dt, mode=mode)
+            assert np.array_equal(cg, co), (dt, mode)
+    # NaN / non-rigid poses: defined behaviour, identical on both paths
+    weird = poses.copy()
+    weird[0, 5] = np.nan
+    weird[1, :] *= 1.5  # scaled: not a rigid motion, still a valid 4x4
+    weird[1, 15] = 1.0
+    weird[2, 12:15] = 1e6
+    co, _, _ = os_.score_hypotheses(om, weird, 0.5, DT)
+    for mode in (capi.SCORE_AUTO, capi.SCORE_BRUTEFORCE):
+        cg, _ = gs.score_hypotheses(gm, weird, DT, mode=mode)
+        assert np.array_equal(cg, co), mode
+    # everything masked
+    mask = np.ones(n, np.int32)
+    gs.set_mask(mask)
+    try:
+        cg, sg = gs.score_hypotheses(gm, poses, DT)
+        assert not cg.any() and not sg.any()
+        sc, mc, score = gs.extract_correspondences(gm, poses[0], DT)
+        assert len(sc) == 0 and score == 0.0
+    finally:
+        gs.set_mask(None)
+    # early drop on an empty subset
+    cnt, sc, dr, sv = gs.score_hypotheses_early_drop(gm, poses, DT, 0.5, subset=np.zeros(0, np.int32))
+    assert not cnt.any() and (dr == -1).all() and not sv.any()
+    # a two-point tangent subset builds (or reports "no valid pair") without faulting
+    tiny = capi.Model(gpu_ctx, small_case["model"], small_case["resolution"])
+    try:
+        tiny.build_pairs(small_case["subset"][:2])
+        assert tiny.pair_counts()["entries"] <= 2
+    except capi.TmError as e:
+        assert e.code == capi.ERR_EMPTY

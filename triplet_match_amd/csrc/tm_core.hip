@@ -64,6 +64,8 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_HIP_CHECK(hipEventCreate(&c->ev0));
     TM_HIP_CHECK(hipEventCreate(&c->ev1));
     TM_FORWARD(c->stats.alloc(16));
+    c->ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
+    c->debug_stats = getenv("TM_DEBUG_STATS") != nullptr;
     *out = c;
     return TM_OK;
 }

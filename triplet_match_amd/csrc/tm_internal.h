@@ -77,6 +77,8 @@ struct tm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    int ablate = 0;          /* TM_ABLATE: timing experiments only */
+    bool debug_stats = false; /* TM_DEBUG_STATS: per-launch stage counts on stderr */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     tmx::score_timing last;
     tmx::dbuf<unsigned char> scratch;   /* rocprim temp storage */

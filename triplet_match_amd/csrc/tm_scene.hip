@@ -678,7 +678,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     const float thres = dist_thres * m->resolution; /* reference :413 */
     a.d2max = sq_threshold(thres);
     a.n_hyp = n_hyp;
-    a.ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
+    a.ablate = c->ablate;
     a.kind = m->metric_kind;
     a.radius = m->metric_radius;
     a.dmax = thres;
@@ -749,7 +749,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         c->last.evaluations = culled ? (uint64_t)h_stats[1] : (uint64_t)n_hyp * n_active;
         c->last.passing = h_stats[0];
         c->last.hypotheses = n_hyp;
-        if (getenv("TM_DEBUG_STATS"))
+        if (c->debug_stats)
             fprintf(stderr, "[tm] score: evals %llu in_grid %llu near %llu passing %llu ms %.3f\n", (unsigned long long)c->last.evaluations, h_stats[2], h_stats[3], h_stats[0], ms);
     }
     return TM_OK;
