@@ -94,6 +94,13 @@ int tm_features_batch(tm_ctx* ctx, const float* surfels, uint32_t n_points, cons
                       float distance_step_count, float angle_step, float* features4,
                       uint32_t* keys4, uint32_t* hashes);
 
+/* cloud->resolution(): mean distance to the nearest OTHER point (reference
+ * include/impl/pointcloud.hpp:66-82: kd-tree nearestKSearch(pnt, 2) -> sqrtf(ds[1]), then the running
+ * mean accum + (val - accum) / (++i) in f32 over the points in order, include/common:104-115).
+ * The 2-NN distances come from a kd-tree kernel on the GPU (exact), the order-dependent running mean is
+ * taken on the host. nn_dist (optional, n floats) receives the per-point distances. */
+int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* resolution, float* nn_dist);
+
 /* ---- model: replaces model<Point> (include/model:15-66, include/impl/model.hpp) ---- */
 /* model(cloud, discretization_params); `resolution` = cloud->resolution() (mean 1-NN distance) */
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,

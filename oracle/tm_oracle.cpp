@@ -473,6 +473,39 @@ void parallel_for(int n, int threads, F&& fn) {
 
 extern "C" {
 
+/* ref: include/impl/pointcloud.hpp:66-82 + include/common:104-115. nearestKSearch(pnt, 2) returns the
+ * point itself and its nearest other point (FLANN: exact L2); exhaustive scan here. The running mean is
+ * taken in f32 in point order, as `average` does. */
+float tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, int threads) {
+    std::vector<float> dist(n, 0.f);
+    parallel_for((int)n, threads, [&](int i) {
+        const float* q = surfels + (size_t)i * 12;
+        if (!finite3(s_pos(q))) return;
+        float b1 = std::numeric_limits<float>::infinity(), b2 = b1;
+        for (uint32_t j = 0; j < n; ++j) {
+            const float* p = surfels + (size_t)j * 12;
+            if (!finite3(s_pos(p))) continue;
+            float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < b1) {
+                b2 = b1;
+                b1 = d2;
+            } else if (d2 < b2) {
+                b2 = d2;
+            }
+        }
+        dist[i] = sqrtf(b2);
+    });
+    float accum = 0.f;
+    uint32_t i = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!finite3(s_pos(surfels + (size_t)k * 12))) continue;
+        accum = accum + (dist[k] - accum) / (float)(++i);
+    }
+    if (nn_dist) memcpy(nn_dist, dist.data(), (size_t)n * 4);
+    return accum;
+}
+
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step) {
     tmo_model* m = new tmo_model();

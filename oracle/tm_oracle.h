@@ -50,6 +50,9 @@ uint32_t tmo_early_drop_upper(uint32_t tried, uint32_t subset_size, uint32_t cor
 uint32_t tmo_early_drop_upper_literal(uint32_t tried, uint32_t subset_size, uint32_t corrs);
 void     tmo_early_drop_checkpoints(uint32_t subset_size, uint32_t tests[18]);
 
+/* cloud->resolution() (pointcloud.hpp:66-82): exhaustive 2-NN + f32 running mean in point order */
+float    tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, int threads);
+
 /* ---- model (a6..a9) ---- */
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step);

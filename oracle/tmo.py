@@ -60,6 +60,8 @@ def lib():
         L.tmo_early_drop_upper_literal.restype = C.c_uint32
         L.tmo_early_drop_upper_literal.argtypes = [C.c_uint32] * 3
         L.tmo_early_drop_checkpoints.argtypes = [C.c_uint32, u32p]
+        L.tmo_cloud_resolution.restype = C.c_float
+        L.tmo_cloud_resolution.argtypes = [f32p, C.c_uint32, f32p, C.c_int]
         L.tmo_model_create.restype = C.c_void_p
         L.tmo_model_create.argtypes = [f32p, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.tmo_model_destroy.argtypes = [C.c_void_p]
@@ -145,6 +147,13 @@ def _i(a):
 
 STATE_FLOATS = 37
 IDENTITY, PLANE, PLANE2, CYLINDER = 0, 1, 2, 3
+
+
+def cloud_resolution(surfels, threads=8):
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    d = np.zeros(s.shape[0], np.float32)
+    r = lib().tmo_cloud_resolution(p, s.shape[0], d.ctypes.data_as(f32p), threads)
+    return float(r), d
 
 
 def murmur3_32(words, seed):

@@ -46,7 +46,11 @@ int main(int argc, char** argv) {
     std::vector<mat4f_t> truth(n_truth); /* scene -> model, column-major */
     for (auto& t : truth) in.read((char*)t.m, 64);
     CHECK(in.good(), "fixture read");
-    mcloud->set_resolution(res);
+    {
+        float computed = mcloud->resolution(); /* GPU 2-NN + f32 running mean */
+        CHECK(std::fabs(computed - res) < 1e-5f * res + 1e-7f, "pointcloud::resolution() (GPU) agrees with the fixture's value");
+        mcloud->set_resolution(res);
+    }
 
     /* free functions */
     auto f = feature<P>(mcloud->points[0], mcloud->points[1], curvature_info_t(), curvature_info_t());

@@ -675,3 +675,16 @@ def test_edge_cases(gpu_ctx, gpu_small, oracle_small, small_case):
         assert tiny.pair_counts()["entries"] <= 2
     except capi.TmError as e:
         assert e.code == capi.ERR_EMPTY
+
+
+def test_cloud_resolution_bit_exact(gpu_ctx):
+    """cloud->resolution(): GPU 2-NN distances and the f32 running mean equal the oracle's exhaustive
+    version bit for bit (duplicates -> distance 0, non-finite points skipped)."""
+    model, _ = synth.synth_model(6000, seed=5)
+    model[100:110, 0:3] = model[200:210, 0:3]
+    model[50, 0] = np.nan
+    rg, dg = gpu_ctx.cloud_resolution(model)
+    ro, do = tmo.cloud_resolution(model)
+    assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+    assert np.float32(rg).view(np.uint32) == np.float32(ro).view(np.uint32)
+    assert (dg[100:110] == 0).all() and abs(rg - synth.resolution(model[np.isfinite(model[:, 0])])) < 1e-4

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tm_early_drop_upper": (C.c_uint32, [C.c_uint32] * 3),
     "tm_features_batch": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, f32p, f32p, C.c_float,
                                     C.c_float, f32p, u32p, u32p]),
+    "tm_cloud_resolution": (C.c_int, [vp, f32p, C.c_uint32, f32p, f32p]),
     "tm_model_create": (C.c_int, [vp, f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(vp)]),
     "tm_model_destroy": (C.c_int, [vp]),
@@ -283,6 +284,13 @@ class Context:
                                        feats.ctypes.data_as(f32p), keys.ctypes.data_as(u32p),
                                        hashes.ctypes.data_as(u32p)))
         return feats, keys, hashes
+
+    def cloud_resolution(self, surfels):
+        s, ps = _f(np.asarray(surfels).reshape(-1, 12))
+        res = C.c_float(0)
+        d = np.zeros(s.shape[0], np.float32)
+        _check(lib().tm_cloud_resolution(self.h, ps, s.shape[0], C.byref(res), d.ctypes.data_as(f32p)))
+        return res.value, d
 
     def best_of_batch(self, d_counts, d_scores, d_poses, n_hyp, id_offset=0, id_stride=1):
         rec = BestRecord()

@@ -194,6 +194,59 @@ __global__ __launch_bounds__(256) void k_voxel_nn_kd(const float4* __restrict__ 
     if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = bmin;
 }
 
+/* second-smallest squared distance from each point to the cloud (the point itself included, as
+ * nearestKSearch(pnt, 2) does): same box-pruned kd descent, bound = current second best */
+__global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, const float4* __restrict__ kd_hi,
+                                              const float4* __restrict__ pts, const float4* __restrict__ queries,
+                                              uint32_t n, float* __restrict__ out) {
+    __shared__ uint32_t st_node[kKdStack][256];
+    __shared__ float st_bound[kKdStack][256];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float4 Q = queries[t];
+    float q[3] = {Q.x, Q.y, Q.z};
+    float b1 = __builtin_inff(), b2 = __builtin_inff();
+    if (Q.x == Q.x) {
+        int sp = 1;
+        st_node[0][threadIdx.x] = 0u;
+        st_bound[0][threadIdx.x] = 0.f;
+        while (sp > 0) {
+            --sp;
+            uint32_t node = st_node[sp][threadIdx.x];
+            if (st_bound[sp][threadIdx.x] > b2) continue;
+            for (;;) {
+                const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
+                if (a & 0x80000000u) {
+                    for (uint32_t p = a & 0x7FFFFFFFu; p < b; ++p) {
+                        float4 P = pts[p];
+                        float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                        float d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (d2 < b1) {
+                            b2 = b1;
+                            b1 = d2;
+                        } else if (d2 < b2) {
+                            b2 = d2;
+                        }
+                    }
+                    break;
+                }
+                float dl = box_d2(q, kd_lo[a], kd_hi[a]);
+                float dr = box_d2(q, kd_lo[b], kd_hi[b]);
+                uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
+                float dn = fminf(dl, dr), df = fmaxf(dl, dr);
+                if (!(df > b2) && sp < kKdStack) {
+                    st_node[sp][threadIdx.x] = farc;
+                    st_bound[sp][threadIdx.x] = df;
+                    ++sp;
+                }
+                if (dn > b2) break;
+                node = nearc;
+            }
+        }
+    }
+    out[t] = (Q.x == Q.x) ? sqrtf(b2) : 0.f; /* non-finite points are not part of the tree */
+}
+
 /* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
 __global__ void k_unbrick(const uint32_t* __restrict__ bricked, const uint32_t* __restrict__ new2orig,
                           grid_t g, int bx, int by, uint64_t count, uint32_t* __restrict__ dense) {
@@ -628,6 +681,63 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
         m->bmax[d] = std::numeric_limits<float>::lowest();
     }
     *out = m;
+    return TM_OK;
+}
+
+int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* resolution, float* nn_dist) {
+    TM_REQUIRE(ctx && surfels && resolution, TM_ERR_INVALID, "tm_cloud_resolution: null argument");
+    *resolution = 0.f;
+    if (n < 2) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<float4> pos(n);
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* s = surfels + (size_t)i * 12;
+        pos[i] = fin3(s) ? make_float4(s[0], s[1], s[2], 0.f) : make_float4(nanv, 0.f, 0.f, 0.f);
+    }
+    kd_builder kb;
+    kb.pos = &pos;
+    for (uint32_t k = 0; k < n; ++k)
+        if (pos[k].x == pos[k].x) kb.order.push_back(k);
+    if (kb.order.size() < 2) return TM_OK;
+    kb.build(0, (int)kb.order.size(), 0);
+    std::vector<float4> kd_pts(kb.order.size());
+    for (size_t k = 0; k < kb.order.size(); ++k) kd_pts[k] = pos[kb.order[k]];
+    dbuf<float4> d_lo, d_hi, d_pts, d_q;
+    dbuf<float> d_out;
+    auto cleanup = [&]() { d_lo.release(); d_hi.release(); d_pts.release(); d_q.release(); d_out.release(); };
+    int rc;
+    if ((rc = d_lo.alloc(kb.lo.size())) || (rc = d_hi.alloc(kb.hi.size())) || (rc = d_pts.alloc(kd_pts.size())) ||
+        (rc = d_q.alloc(n)) || (rc = d_out.alloc(n))) {
+        cleanup();
+        return rc;
+    }
+    std::vector<float> dist(n);
+    hipError_t e = hipMemcpyAsync(d_lo.p, kb.lo.data(), kb.lo.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, kb.hi.data(), kb.hi.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_knn2, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_lo.p, d_hi.p, d_pts.p, d_q.p, n,
+                           d_out.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist.data(), d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_cloud_resolution: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    /* running mean in f32, in point order (include/common:104-115) */
+    float accum = 0.f;
+    uint32_t i = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!(pos[k].x == pos[k].x)) continue; /* non-finite points are not part of the tree */
+        accum = accum + (dist[k] - accum) / (float)(++i);
+    }
+    *resolution = accum;
+    if (nn_dist) memcpy(nn_dist, dist.data(), (size_t)n * 4);
     return TM_OK;
 }
 
