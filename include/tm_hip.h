@@ -101,6 +101,15 @@ int tm_features_batch(tm_ctx* ctx, const float* surfels, uint32_t n_points, cons
  * taken on the host. nn_dist (optional, n floats) receives the per-point distances. */
 int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* resolution, float* nn_dist);
 
+/* cloud->curvature(k, idx) for every point (reference include/impl/pointcloud.hpp:3-44,200-204):
+ * k nearest neighbours including the point itself (kd-tree kernel; order = distance ascending, ties by
+ * index — FLANN's tie order is unpinned), normals projected into the tangent plane of the point's own
+ * normal, running-mean centroid, 3x3 covariance, eigenvalues. pcl::eigen33 is third-party: defined here
+ * as a 10-sweep cyclic Jacobi iteration in f32. curv5[i] = (pc_max_dir xyz, pc_min, pc_max) with
+ * pc_min = middle, pc_max = largest eigenvalue, both / k. The reference's tangent masks are
+ * |tangent| > 0.7 && pc_min / pc_max < 0.2 (include/impl/scene.hpp:50, model.hpp:96-99). */
+int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5);
+
 /* ---- model: replaces model<Point> (include/model:15-66, include/impl/model.hpp) ---- */
 /* model(cloud, discretization_params); `resolution` = cloud->resolution() (mean 1-NN distance) */
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,

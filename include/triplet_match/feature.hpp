@@ -37,10 +37,6 @@ struct feature_bounds_t { /* Eigen::AlignedBox<float,4> as used by the reference
     }
 };
 
-struct curvature_info_t { /* include/pointcloud:24-28 */
-    vec3f_t pc_max_dir;
-    float pc_min = 0.f, pc_max = 0.f;
-};
 template <typename Point>
 using curv_info_t = curvature_info_t;
 

@@ -42,6 +42,11 @@ public:
     model(const model&) = delete;
     model& operator=(const model&) = delete;
 
+    /* apply the curvature half of the subset filter, `pc_min / pc_max < 0.2` on curvature(k, idx)
+     * (include/impl/model.hpp:68-71,96-99). The reference always applies it (k = 30); it is opt-in here
+     * because tangents from other edge detectors need not satisfy it. */
+    void enable_curvature_filter(uint32_t k = 30) { curvature_k_ = k; }
+
     void init(const sample_parameters& sample_params) { init(subset_t(), sample_params); }
 
     /* include/impl/model.hpp:15-167. The curvature-ratio half of the subset filter (:96-99) is a "next"
@@ -61,6 +66,10 @@ public:
             if (!finite) continue;
             if (!(tangent(p).norm() > 0.7f)) continue;
             if (curvature_ok && !(*curvature_ok)[idx]) continue;
+            if (curvature_k_) {
+                curvature_info_t ci = cloud_->curvature(curvature_k_, idx);
+                if (!((ci.pc_min / ci.pc_max) < 0.2f)) continue;
+            }
             subset_.push_back(idx);
         }
         s_params_ = sample_params;
@@ -129,6 +138,7 @@ protected:
     mat4f_t to_voxel_;
     feature_bounds_t bounds_;
     uint64_t pair_count_ = 0;
+    uint32_t curvature_k_ = 0;
     std::vector<entry_t> last_query_;
 };
 

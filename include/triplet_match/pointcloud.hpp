@@ -17,6 +17,11 @@
 
 namespace triplet_match {
 
+struct curvature_info_t { /* include/pointcloud:24-28 */
+    vec3f_t pc_max_dir;
+    float pc_min = 0.f, pc_max = 0.f;
+};
+
 template <typename Point>
 class pointcloud {
 public:
@@ -31,6 +36,7 @@ public:
     void push_back(const Point& p) {
         points.push_back(p);
         resolution_ = diameter_ = -1.f;
+        curv_k_ = 0;
     }
     const Point& operator[](size_t i) const { return points[i]; }
     Point& operator[](size_t i) { return points[i]; }
@@ -53,6 +59,24 @@ public:
         return resolution_ = r;
     }
 
+    /* curvature(k, idx), include/impl/pointcloud.hpp:200-204: kNN-k + principal curvatures of the projected
+     * normals (tm_cloud_curvature, GPU); all points are computed on first use and cached per k */
+    curvature_info_t curvature(uint32_t k, uint32_t idx) const {
+        if (curv_k_ != k || curv_.size() != 5 * points.size()) {
+            curv_.assign(5 * points.size(), 0.f);
+            auto ctx = detail::default_context(0);
+            if (!points.empty())
+                detail::check(tm_cloud_curvature(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, curv_.data()),
+                              "tm_cloud_curvature");
+            curv_k_ = k;
+        }
+        curvature_info_t c;
+        c.pc_max_dir = {curv_[5 * (size_t)idx], curv_[5 * (size_t)idx + 1], curv_[5 * (size_t)idx + 2]};
+        c.pc_min = curv_[5 * (size_t)idx + 3];
+        c.pc_max = curv_[5 * (size_t)idx + 4];
+        return c;
+    }
+
     float diameter() const { /* bounding-box diagonal, include/impl/pointcloud.hpp:84-97 */
         if (diameter_ >= 0.f) return diameter_;
         float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
@@ -71,6 +95,8 @@ public:
 private:
     mutable float resolution_ = -1.f;
     mutable float diameter_ = -1.f;
+    mutable std::vector<float> curv_;
+    mutable uint32_t curv_k_ = 0;
 };
 
 }  // namespace triplet_match

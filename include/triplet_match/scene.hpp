@@ -184,6 +184,8 @@ public:
     /* the curvature-ratio half of tangent_mask_ (include/impl/scene.hpp:50) is a "next" row; supply one
      * flag per point to apply it */
     void set_curvature_ok(const std::vector<uint8_t>& ok) { curvature_ok_ = ok; }
+    /* curvature half of tangent_mask_ computed like the reference (kNN-k, ratio < 0.2); opt-in */
+    void enable_curvature_filter(uint32_t k = 30) { curvature_k_ = k; }
     void set_workers(uint32_t w) { workers_ = w; }
     /* detail::early_drop of the reference (include/impl/scene.hpp:25) is true; switching it off scores
      * every hypothesis to the end and enables the batched GPU path (16 first points per launch) */
@@ -199,6 +201,10 @@ public:
         for (uint32_t i = 0; i < n; ++i) {
             bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
             if (t && !curvature_ok_.empty() && !curvature_ok_[i]) t = false;
+            if (t && curvature_k_) {
+                curvature_info_t ci = cloud_->curvature(curvature_k_, i); /* :49-50 */
+                if (!((ci.pc_min / ci.pc_max) < 0.2f)) t = false;
+            }
             tangent_mask[i] = t ? 1 : 0;
         }
         if (h_) tm_scene_destroy(h_);
@@ -260,6 +266,7 @@ protected:
     tm_scene* h_ = nullptr;
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
+    uint32_t curvature_k_ = 0;
     bool early_drop_ = true;
     bool verbose_ = false;
 };

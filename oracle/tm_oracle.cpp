@@ -17,6 +17,7 @@
 #include "tm_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -504,6 +505,95 @@ float tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, int
     }
     if (nn_dist) memcpy(nn_dist, dist.data(), (size_t)n * 4);
     return accum;
+}
+
+/* ref: include/impl/pointcloud.hpp:3-44 (principal_curvatures) + :200-204 (curvature(k, idx)).
+ * knn_inclusive: the k nearest points, the query itself included, by distance ascending (ties by index:
+ * FLANN's order on ties is unpinned). pcl::eigen33 / computeCorrespondingEigenVector are third-party:
+ * defined as a 10-sweep cyclic Jacobi iteration in f32. Exhaustive neighbour search. */
+static void oracle_jacobi3(const float a_in[6], float ev[3], float vmax[3]) {
+    float a[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
+    float v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < 10; ++sweep)
+        for (int pq = 0; pq < 3; ++pq) {
+            int p = P[pq], q = Q[pq], r = 3 - p - q;
+            float apq = a[p][q];
+            if (apq == 0.f) continue;
+            float theta = (a[q][q] - a[p][p]) / (2.f * apq);
+            float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+            float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+            a[p][p] = a[p][p] - t * apq;
+            a[q][q] = a[q][q] + t * apq;
+            a[p][q] = a[q][p] = 0.f;
+            float arp = a[r][p], arq = a[r][q];
+            a[r][p] = a[p][r] = c * arp - s * arq;
+            a[r][q] = a[q][r] = s * arp + c * arq;
+            for (int k = 0; k < 3; ++k) {
+                float vkp = v[k][p], vkq = v[k][q];
+                v[k][p] = c * vkp - s * vkq;
+                v[k][q] = s * vkp + c * vkq;
+            }
+        }
+    int o[3] = {0, 1, 2};
+    if (a[o[0]][o[0]] > a[o[1]][o[1]]) std::swap(o[0], o[1]);
+    if (a[o[1]][o[1]] > a[o[2]][o[2]]) std::swap(o[1], o[2]);
+    if (a[o[0]][o[0]] > a[o[1]][o[1]]) std::swap(o[0], o[1]);
+    for (int k = 0; k < 3; ++k) {
+        ev[k] = a[o[k]][o[k]];
+        vmax[k] = v[k][o[2]];
+    }
+}
+
+void tmo_cloud_curvature(const float* surfels, uint32_t n, uint32_t k, float* curv5, int threads) {
+    parallel_for((int)n, threads, [&](int i) {
+        float* out = curv5 + (size_t)i * 5;
+        for (int c = 0; c < 5; ++c) out[c] = 0.f;
+        const float* q = surfels + (size_t)i * 12;
+        if (!finite3(s_pos(q))) return;
+        std::vector<std::pair<float, uint32_t>> nb;
+        nb.reserve(n);
+        for (uint32_t j = 0; j < n; ++j) {
+            const float* p = surfels + (size_t)j * 12;
+            if (!finite3(s_pos(p))) continue;
+            float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            nb.push_back({(dx * dx + dy * dy) + dz * dz, j});
+        }
+        uint32_t kk = std::min<uint32_t>(k, (uint32_t)nb.size());
+        std::partial_sort(nb.begin(), nb.begin() + kk, nb.end()); /* (d2, index) ascending */
+        v3 n0 = s_nrm(q);
+        float n0a[3] = {n0.x, n0.y, n0.z};
+        float M[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) M[r][c] = (r == c ? 1.f : 0.f) - n0a[r] * n0a[c]; /* :8-10 */
+        float cen[3] = {0, 0, 0};
+        std::vector<std::array<float, 3>> proj(kk);
+        for (uint32_t j = 0; j < kk; ++j) { /* :13-16 */
+            v3 nj = s_nrm(surfels + (size_t)nb[j].second * 12);
+            for (int r = 0; r < 3; ++r) {
+                proj[j][r] = (M[r][0] * nj.x + M[r][1] * nj.y) + M[r][2] * nj.z;
+                cen[r] = cen[r] + (proj[j][r] - cen[r]) / (float)(j + 1);
+            }
+        }
+        float cov[6] = {0, 0, 0, 0, 0, 0};
+        for (uint32_t j = 0; j < kk; ++j) { /* :19-35 */
+            float d[3] = {proj[j][0] - cen[0], proj[j][1] - cen[1], proj[j][2] - cen[2]};
+            cov[0] += d[0] * d[0];
+            cov[1] += d[0] * d[1];
+            cov[2] += d[0] * d[2];
+            cov[3] += d[1] * d[1];
+            cov[4] += d[1] * d[2];
+            cov[5] += d[2] * d[2];
+        }
+        float ev[3], vmax[3];
+        oracle_jacobi3(cov, ev, vmax);
+        float area_inv = 1.0f / (float)kk; /* :42 */
+        out[0] = vmax[0];
+        out[1] = vmax[1];
+        out[2] = vmax[2];
+        out[3] = ev[1] * area_inv;
+        out[4] = ev[2] * area_inv;
+    });
 }
 
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,

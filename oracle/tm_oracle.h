@@ -53,6 +53,9 @@ void     tmo_early_drop_checkpoints(uint32_t subset_size, uint32_t tests[18]);
 /* cloud->resolution() (pointcloud.hpp:66-82): exhaustive 2-NN + f32 running mean in point order */
 float    tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, int threads);
 
+/* cloud->curvature(k, i) for all i (pointcloud.hpp:3-44,200-204): curv5 = (dir xyz, pc_min, pc_max) */
+void     tmo_cloud_curvature(const float* surfels, uint32_t n, uint32_t k, float* curv5, int threads);
+
 /* ---- model (a6..a9) ---- */
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step);

@@ -62,6 +62,7 @@ def lib():
         L.tmo_early_drop_checkpoints.argtypes = [C.c_uint32, u32p]
         L.tmo_cloud_resolution.restype = C.c_float
         L.tmo_cloud_resolution.argtypes = [f32p, C.c_uint32, f32p, C.c_int]
+        L.tmo_cloud_curvature.argtypes = [f32p, C.c_uint32, C.c_uint32, f32p, C.c_int]
         L.tmo_model_create.restype = C.c_void_p
         L.tmo_model_create.argtypes = [f32p, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.tmo_model_destroy.argtypes = [C.c_void_p]
@@ -154,6 +155,13 @@ def cloud_resolution(surfels, threads=8):
     d = np.zeros(s.shape[0], np.float32)
     r = lib().tmo_cloud_resolution(p, s.shape[0], d.ctypes.data_as(f32p), threads)
     return float(r), d
+
+
+def cloud_curvature(surfels, k=30, threads=8):
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    out = np.zeros((s.shape[0], 5), np.float32)
+    lib().tmo_cloud_curvature(p, s.shape[0], k, out.ctypes.data_as(f32p), threads)
+    return out
 
 
 def murmur3_32(words, seed):

@@ -688,3 +688,21 @@ def test_cloud_resolution_bit_exact(gpu_ctx):
     assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
     assert np.float32(rg).view(np.uint32) == np.float32(ro).view(np.uint32)
     assert (dg[100:110] == 0).all() and abs(rg - synth.resolution(model[np.isfinite(model[:, 0])])) < 1e-4
+
+
+def test_cloud_curvature_bit_exact(gpu_ctx):
+    """cloud->curvature(30, i): kNN-30 + projected-normal covariance + Jacobi eigenvalues, GPU vs oracle."""
+    model, _ = synth.synth_model(3000, seed=6)
+    model[10:14, 0:3] = model[20:24, 0:3]  # duplicates: ties in the neighbour order
+    model[77, 1] = np.inf
+    cg = gpu_ctx.cloud_curvature(model, 30)
+    co = tmo.cloud_curvature(model, 30)
+    assert np.array_equal(cg.view(np.uint32), co.view(np.uint32))
+    # edge-like points (normals of two faces among the neighbours) have pc_min / pc_max < 0.2
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ratio = cg[:, 3] / cg[:, 4]
+    edge = ratio < 0.2
+    assert 50 < edge.sum() < 2500 and cg[77].sum() == 0
+    for k in (1, 5, 32):
+        assert np.array_equal(gpu_ctx.cloud_curvature(model[:500], k).view(np.uint32),
+                              tmo.cloud_curvature(model[:500], k).view(np.uint32))

@@ -60,6 +60,7 @@ SIGNATURES = {
     "tm_features_batch": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, f32p, f32p, C.c_float,
                                     C.c_float, f32p, u32p, u32p]),
     "tm_cloud_resolution": (C.c_int, [vp, f32p, C.c_uint32, f32p, f32p]),
+    "tm_cloud_curvature": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, f32p]),
     "tm_model_create": (C.c_int, [vp, f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(vp)]),
     "tm_model_destroy": (C.c_int, [vp]),
@@ -291,6 +292,12 @@ class Context:
         d = np.zeros(s.shape[0], np.float32)
         _check(lib().tm_cloud_resolution(self.h, ps, s.shape[0], C.byref(res), d.ctypes.data_as(f32p)))
         return res.value, d
+
+    def cloud_curvature(self, surfels, k=30):
+        s, ps = _f(np.asarray(surfels).reshape(-1, 12))
+        out = np.zeros((s.shape[0], 5), np.float32)
+        _check(lib().tm_cloud_curvature(self.h, ps, s.shape[0], k, out.ctypes.data_as(f32p)))
+        return out
 
     def best_of_batch(self, d_counts, d_scores, d_poses, n_hyp, id_offset=0, id_stride=1):
         rec = BestRecord()

@@ -268,6 +268,48 @@ TM_HD uint32_t early_drop_upper(uint32_t tried, uint32_t subset, uint32_t corrs)
     return t - 1u;
 }
 
+/* ---- symmetric 3x3 eigen-decomposition: cyclic Jacobi, fixed 10 sweeps, f32 (the library's definition of
+ * the reference's pcl::eigen33 call, include/impl/pointcloud.hpp:38-40). a = (a00,a01,a02,a11,a12,a22).
+ * Eigenvalues ascending in ev[3]; vmax = unit eigenvector of the largest. ---- */
+TM_HD void jacobi_eigen3(const float a_in[6], float ev[3], float vmax[3]) {
+    float a[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
+    float v[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+    for (int sweep = 0; sweep < 10; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2, r = 3 - p - q;
+            const float apq = a[p][q];
+            if (apq == 0.f) continue;
+            const float theta = (a[q][q] - a[p][p]) / (2.f * apq);
+            const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+            const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+            a[p][p] = a[p][p] - t * apq;
+            a[q][q] = a[q][q] + t * apq;
+            a[p][q] = 0.f;
+            a[q][p] = 0.f;
+            const float arp = a[r][p], arq = a[r][q];
+            a[r][p] = c * arp - s * arq;
+            a[p][r] = a[r][p];
+            a[r][q] = s * arp + c * arq;
+            a[q][r] = a[r][q];
+            for (int k = 0; k < 3; ++k) {
+                const float vkp = v[k][p], vkq = v[k][q];
+                v[k][p] = c * vkp - s * vkq;
+                v[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    int i0 = 0, i1 = 1, i2 = 2; /* sort indices by eigenvalue, ascending */
+    if (a[i0][i0] > a[i1][i1]) { int t = i0; i0 = i1; i1 = t; }
+    if (a[i1][i1] > a[i2][i2]) { int t = i1; i1 = i2; i2 = t; }
+    if (a[i0][i0] > a[i1][i1]) { int t = i0; i0 = i1; i1 = t; }
+    ev[0] = a[i0][i0];
+    ev[1] = a[i1][i1];
+    ev[2] = a[i2][i2];
+    vmax[0] = v[0][i2];
+    vmax[1] = v[1][i2];
+    vmax[2] = v[2][i2];
+}
+
 /* voxel grid affine: v = s*p + t per axis; a hit is trunc(v) in [0, ext) which, for the float v,
  * is v > -1 && v < ext (reference include/impl/model.hpp:180-192; NaN fails both) */
 struct grid_t {

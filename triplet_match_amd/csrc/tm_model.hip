@@ -247,6 +247,119 @@ __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, 
     out[t] = (Q.x == Q.x) ? sqrtf(b2) : 0.f; /* non-finite points are not part of the tree */
 }
 
+/* k nearest neighbours (self included) + principal curvatures, one thread per point. The neighbour list
+ * lives in LDS, kept sorted by (d2, original index); a subtree is skipped only when its box distance
+ * exceeds the current k-th distance, so equal-distance candidates are always seen. */
+constexpr int kCurvK = 32;      /* capacity of the neighbour list (k <= 32) */
+constexpr int kCurvThreads = 128;
+
+__global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __restrict__ kd_lo,
+                                                            const float4* __restrict__ kd_hi,
+                                                            const float4* __restrict__ pts /* xyz, orig idx */,
+                                                            const float4* __restrict__ qpos /* orig order */,
+                                                            const float4* __restrict__ nrm /* orig order */,
+                                                            uint32_t n, uint32_t k, float* __restrict__ curv5) {
+    __shared__ uint32_t st_node[kKdStack][kCurvThreads];
+    __shared__ float st_bound[kKdStack][kCurvThreads];
+    __shared__ float nb_d2[kCurvK][kCurvThreads];
+    __shared__ uint32_t nb_idx[kCurvK][kCurvThreads];
+    const uint32_t t = blockIdx.x * kCurvThreads + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t tx = threadIdx.x;
+    const float4 Q = qpos[t];
+    float* out = curv5 + (size_t)t * 5;
+    if (!(Q.x == Q.x)) {
+        for (int c = 0; c < 5; ++c) out[c] = 0.f;
+        return;
+    }
+    float q[3] = {Q.x, Q.y, Q.z};
+    uint32_t have = 0;
+    int sp = 1;
+    st_node[0][tx] = 0u;
+    st_bound[0][tx] = 0.f;
+    while (sp > 0) {
+        --sp;
+        uint32_t node = st_node[sp][tx];
+        if (have == k && st_bound[sp][tx] > nb_d2[k - 1][tx]) continue;
+        for (;;) {
+            const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
+            if (a & 0x80000000u) {
+                for (uint32_t p = a & 0x7FFFFFFFu; p < b; ++p) {
+                    float4 P = pts[p];
+                    float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    uint32_t idx = __float_as_uint(P.w);
+                    if (have == k) {
+                        float wd = nb_d2[k - 1][tx];
+                        uint32_t wi = nb_idx[k - 1][tx];
+                        if (!(d2 < wd || (d2 == wd && idx < wi))) continue;
+                    }
+                    /* insertion into the sorted list */
+                    int pos = (int)(have < k ? have : k - 1);
+                    while (pos > 0) {
+                        float pd = nb_d2[pos - 1][tx];
+                        uint32_t pi = nb_idx[pos - 1][tx];
+                        if (pd < d2 || (pd == d2 && pi < idx)) break;
+                        nb_d2[pos][tx] = pd;
+                        nb_idx[pos][tx] = pi;
+                        --pos;
+                    }
+                    nb_d2[pos][tx] = d2;
+                    nb_idx[pos][tx] = idx;
+                    if (have < k) ++have;
+                }
+                break;
+            }
+            float dl = box_d2(q, kd_lo[a], kd_hi[a]);
+            float dr = box_d2(q, kd_lo[b], kd_hi[b]);
+            uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
+            float dn = fminf(dl, dr), df = fmaxf(dl, dr);
+            const float worst = have == k ? nb_d2[k - 1][tx] : __builtin_inff();
+            if (!(df > worst) && sp < kKdStack) {
+                st_node[sp][tx] = farc;
+                st_bound[sp][tx] = df;
+                ++sp;
+            }
+            if (dn > worst) break;
+            node = nearc;
+        }
+    }
+    /* principal curvatures (reference include/impl/pointcloud.hpp:5-43) */
+    const float4 N0 = nrm[t];
+    const float n0[3] = {N0.x, N0.y, N0.z};
+    float M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = (r == c ? 1.f : 0.f) - n0[r] * n0[c];
+    float cen[3] = {0.f, 0.f, 0.f};
+    for (uint32_t j = 0; j < have; ++j) {
+        const float4 Nj = nrm[nb_idx[j][tx]];
+        for (int r = 0; r < 3; ++r) {
+            float pr = (M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z;
+            cen[r] = cen[r] + (pr - cen[r]) / (float)(j + 1);
+        }
+    }
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; /* 00 01 02 11 12 22 */
+    for (uint32_t j = 0; j < have; ++j) {
+        const float4 Nj = nrm[nb_idx[j][tx]];
+        float d[3];
+        for (int r = 0; r < 3; ++r) d[r] = ((M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z) - cen[r];
+        cov[0] += d[0] * d[0];
+        cov[1] += d[0] * d[1];
+        cov[2] += d[0] * d[2];
+        cov[3] += d[1] * d[1];
+        cov[4] += d[1] * d[2];
+        cov[5] += d[2] * d[2];
+    }
+    float ev[3], vmax[3];
+    jacobi_eigen3(cov, ev, vmax);
+    const float area_inv = 1.0f / (float)have;
+    out[0] = vmax[0];
+    out[1] = vmax[1];
+    out[2] = vmax[2];
+    out[3] = ev[1] * area_inv;
+    out[4] = ev[2] * area_inv;
+}
+
 /* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
 __global__ void k_unbrick(const uint32_t* __restrict__ bricked, const uint32_t* __restrict__ new2orig,
                           grid_t g, int bx, int by, uint64_t count, uint32_t* __restrict__ dense) {
@@ -738,6 +851,63 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
     }
     *resolution = accum;
     if (nn_dist) memcpy(nn_dist, dist.data(), (size_t)n * 4);
+    return TM_OK;
+}
+
+int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5) {
+    TM_REQUIRE(ctx && surfels && curv5, TM_ERR_INVALID, "tm_cloud_curvature: null argument");
+    TM_REQUIRE(k >= 1 && k <= (uint32_t)kCurvK, TM_ERR_UNSUPPORTED, "tm_cloud_curvature: k must be in 1..32");
+    if (n == 0) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<float4> pos(n), nrm(n);
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* s = surfels + (size_t)i * 12;
+        pos[i] = fin3(s) ? make_float4(s[0], s[1], s[2], 0.f) : make_float4(nanv, 0.f, 0.f, 0.f);
+        nrm[i] = make_float4(s[4], s[5], s[6], 0.f);
+    }
+    kd_builder kb;
+    kb.pos = &pos;
+    for (uint32_t i = 0; i < n; ++i)
+        if (pos[i].x == pos[i].x) kb.order.push_back(i);
+    memset(curv5, 0, (size_t)n * 20);
+    if (kb.order.empty()) return TM_OK;
+    kb.build(0, (int)kb.order.size(), 0);
+    std::vector<float4> kd_pts(kb.order.size());
+    for (size_t i = 0; i < kb.order.size(); ++i) {
+        const float4& p = pos[kb.order[i]];
+        float w;
+        uint32_t oi = kb.order[i];
+        memcpy(&w, &oi, 4);
+        kd_pts[i] = make_float4(p.x, p.y, p.z, w);
+    }
+    const uint32_t kk = std::min<uint32_t>(k, (uint32_t)kb.order.size());
+    dbuf<float4> d_lo, d_hi, d_pts, d_q, d_n;
+    dbuf<float> d_out;
+    auto cleanup = [&]() { d_lo.release(); d_hi.release(); d_pts.release(); d_q.release(); d_n.release(); d_out.release(); };
+    int rc;
+    if ((rc = d_lo.alloc(kb.lo.size())) || (rc = d_hi.alloc(kb.hi.size())) || (rc = d_pts.alloc(kd_pts.size())) ||
+        (rc = d_q.alloc(n)) || (rc = d_n.alloc(n)) || (rc = d_out.alloc((size_t)n * 5))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_lo.p, kb.lo.data(), kb.lo.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, kb.hi.data(), kb.hi.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n.p, nrm.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_curvature, dim3((n + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0, ctx->stream,
+                           d_lo.p, d_hi.p, d_pts.p, d_q.p, d_n.p, n, kk, d_out.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(curv5, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_cloud_curvature: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
     return TM_OK;
 }
 
