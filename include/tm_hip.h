@@ -220,6 +220,14 @@ int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pos
                                float dist_thres, uint32_t* scene_corrs, uint32_t* model_corrs,
                                uint32_t cap, uint32_t* count, double* score);
 
+/* One ICP accumulation pass (reference icp_, include/impl/scene.hpp:385-393 + icp_correlation,
+ * opencl/icp.cl:55-86): finds the correspondences of `pose16` exactly like finish_find (all points) and
+ * returns their number and 15 sums over them — sum s (3), sum m (3), sum s_a*m_b (9, index 3*a+b) with s
+ * the scene point and m its model point — accumulated on the device in 2^-32 fixed point (each term
+ * (long long)(x * 2^32), integer adds: order-free and reproducible). The caller solves the rigid fit. */
+int tm_icp_accumulate(tm_scene* scene, tm_model* model, const float pose16[16], float dist_thres,
+                      uint32_t* count, long long sums15[15]);
+
 /* ---- best-hypothesis record and its reduction (new functionality) ---- */
 typedef struct tm_best_record {
     uint32_t inlier_count;

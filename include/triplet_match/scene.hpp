@@ -148,6 +148,11 @@ struct hip_backend {
         out.scene_corrs.resize(count);
         out.model_corrs.resize(count);
     }
+    search::detail::icp_sums_t icp_sums(const search::pose_t& T, float dist_thres) {
+        search::detail::icp_sums_t r;
+        check(tm_icp_accumulate(s, m, T.m, dist_thres, &r.n, r.v), "tm_icp_accumulate");
+        return r;
+    }
     void set_mask(const std::vector<int32_t>& mask) { check(tm_scene_set_mask(s, mask.data()), "tm_scene_set_mask"); }
 };
 

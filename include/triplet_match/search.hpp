@@ -70,29 +70,41 @@ struct params_t {
  *   void generate_with_pairs(ij, poses, pair_of_hyp); //   hypotheses + the sample pair each came from
  *   void score_ball(poses, centers, radius, counts, scores); // each pose on the ball around its first point
  *   void extract(const pose_t& T, float dist_thres, candidate_t& out);            // finish_find
+ *   detail::icp_sums_t icp_sums(const pose_t& T, float dist_thres);               // finish_find + ICP sums
  *   void set_mask(const std::vector<int32_t>& mask);
  */
 
 namespace detail {
 
-/* Horn's closed form (unit quaternion = dominant eigenvector of the 4x4 N matrix, Jacobi sweeps in
- * double): rigid T minimising sum |mdl - T*scn|^2, the no-scale case of Eigen::umeyama (:393) */
-inline pose_t rigid_fit(const std::vector<double>& scn, const std::vector<double>& mdl) {
-    const size_t n = scn.size() / 3;
-    double cs[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; ++i)
-        for (int d = 0; d < 3; ++d) {
-            cs[d] += scn[3 * i + d];
-            cm[d] += mdl[3 * i + d];
-        }
-    for (int d = 0; d < 3; ++d) {
-        cs[d] /= (double)n;
-        cm[d] /= (double)n;
+/* ICP sums: count n and, over the correspondences (s = scene point, m = model point), sum s (3),
+ * sum m (3), sum s_a*m_b (9, index 3*a+b), each term truncated to 2^-32 fixed point and added as
+ * integers (order-free: a GPU reduction and a host loop give the same 15 numbers). */
+struct icp_sums_t {
+    uint32_t n = 0;
+    long long v[15] = {0};
+};
+inline void icp_sums_add(icp_sums_t& acc, const float* s, const float* m) {
+    const double S = 4294967296.0;
+    for (int c = 0; c < 3; ++c) {
+        acc.v[c] += (long long)((double)s[c] * S);
+        acc.v[3 + c] += (long long)((double)m[c] * S);
     }
-    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (size_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) S[a][b] += (scn[3 * i + a] - cs[a]) * (mdl[3 * i + b] - cm[b]);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) acc.v[6 + 3 * r + c] += (long long)(((double)s[r] * (double)m[c]) * S);
+    ++acc.n;
+}
+
+/* Horn's closed form (unit quaternion = dominant eigenvector of the 4x4 N matrix, Jacobi sweeps in
+ * double): rigid T minimising sum |m - T*s|^2, the no-scale case of Eigen::umeyama (:393) */
+inline pose_t rigid_fit(const icp_sums_t& in) {
+    const double inv = 1.0 / 4294967296.0, n = (double)in.n;
+    double cs[3], cm[3], S[3][3];
+    for (int c = 0; c < 3; ++c) {
+        cs[c] = (double)in.v[c] * inv / n;
+        cm[c] = (double)in.v[3 + c] * inv / n;
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) S[a][b] = (double)in.v[6 + 3 * a + b] * inv - n * cs[a] * cm[b];
     double N[4][4] = {
         {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
         {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
@@ -253,31 +265,28 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     return {matches, cons};
 }
 
-/* icp_, include/impl/scene.hpp:369-404 (note the doubled distance threshold, :373,395) */
+/* icp_, include/impl/scene.hpp:369-404 (note the doubled distance threshold, :373,395). Each pass needs
+ * only the number of correspondences and their sums (be.icp_sums: finish_find + accumulation in one
+ * go); the correspondence lists are extracted once, for the pose that is returned. */
 template <class Backend>
 inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p) {
     if (p.max_icp_iterations == 0) return match;
-    candidate_t best;
-    be.extract(match.transform, 2.f * p.dist_thres, best);
+    const float dt2 = 2.f * p.dist_thres;
+    pose_t best_t = match.transform;
+    detail::icp_sums_t best = be.icp_sums(best_t, dt2);
     uint32_t iter = 0;
     for (;;) {
-        if (best.scene_corrs.size() < 3) return best;
-        std::vector<double> scn(3 * best.scene_corrs.size()), mdl(3 * best.scene_corrs.size());
-        for (size_t k = 0; k < best.scene_corrs.size(); ++k) {
-            const float* s = be.scene_surfel(best.scene_corrs[k]);
-            const float* m = be.model_surfel(best.model_corrs[k]);
-            for (int d = 0; d < 3; ++d) {
-                scn[3 * k + d] = s[d];
-                mdl[3 * k + d] = m[d];
-            }
-        }
-        pose_t trans = detail::rigid_fit(scn, mdl); /* :393 */
-        candidate_t proj;
-        be.extract(trans, 2.f * p.dist_thres, proj);
-        if (proj.scene_corrs.size() < best.scene_corrs.size()) return best; /* :396 */
-        best = std::move(proj);
-        if (++iter == p.max_icp_iterations) return best;
+        if (best.n < 3) break; /* :381 */
+        pose_t trans = detail::rigid_fit(best); /* :385-393 */
+        detail::icp_sums_t proj = be.icp_sums(trans, dt2);
+        if (proj.n < best.n) break; /* :396 */
+        best = proj;
+        best_t = trans;
+        if (++iter == p.max_icp_iterations) break;
     }
+    candidate_t out;
+    be.extract(best_t, dt2, out);
+    return out;
 }
 
 /* find_parallel, include/impl/scene.hpp:108-240 */

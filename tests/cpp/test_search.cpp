@@ -85,6 +85,14 @@ struct oracle_backend {
         out.scene_corrs.resize(n);
         out.model_corrs.resize(n);
     }
+    search::detail::icp_sums_t icp_sums(const search::pose_t& T, float dist_thres) {
+        search::candidate_t c;
+        extract(T, dist_thres, c);
+        search::detail::icp_sums_t r;
+        for (size_t k = 0; k < c.scene_corrs.size(); ++k)
+            search::detail::icp_sums_add(r, scloud->points[c.scene_corrs[k]].raw(), mcloud->points[c.model_corrs[k]].raw());
+        return r;
+    }
     void set_mask(const std::vector<int32_t>& mk) {
         mask = mk;
         tmo_scene_set_mask(s, mk.data());

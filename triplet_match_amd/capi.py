@@ -95,6 +95,7 @@ SIGNATURES = {
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
+    "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
     "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(BestRecord)]),
     "tm_best_select": (C.c_int, [C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
@@ -556,6 +557,14 @@ class Scene:
             self.h, model.h, pP, n, ps, ns, dist_thres, accept_prob, counts.ctypes.data_as(u32p),
             scores.ctypes.data_as(f64p), dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
         return counts, scores, dropped, saved
+
+    def icp_accumulate(self, model, pose16, dist_thres):
+        T, pT = _f(pose16)
+        cnt = C.c_uint32(0)
+        sums = np.zeros(15, np.int64)
+        _check(lib().tm_icp_accumulate(self.h, model.h, pT, dist_thres, C.byref(cnt),
+                                       sums.ctypes.data_as(C.POINTER(C.c_longlong))))
+        return cnt.value, sums
 
     def extract_correspondences(self, model, pose16, dist_thres):
         T, pT = _f(pose16)

@@ -316,6 +316,53 @@ __global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
     }
 }
 
+/* finish_find + cross-covariance sums for ICP: one thread per sorted scene point; the 15 fixed-point sums
+ * and the count are reduced per wave (shuffles) and added with integer atomics (order-free) */
+__global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n_pad,
+                                                        unsigned long long* __restrict__ sums /* 15 */) {
+    uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    long long acc[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] = 0;
+    uint32_t hit = 0;
+    if (s < n_pad) {
+        float4 v = a.spos[s];
+        if (v.x == v.x) {
+            const pose12 T = load_pose(a.poses);
+            long long fx = 0;
+            uint32_t pass = 0, m = 0;
+            hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
+            if (hit) {
+                float4 mp = a.mpos[m];
+                const double sc[3] = {(double)v.x, (double)v.y, (double)v.z};
+                const double mc[3] = {(double)mp.x, (double)mp.y, (double)mp.z};
+                const double S = 4294967296.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    acc[c] = (long long)(sc[c] * S);
+                    acc[3 + c] = (long long)(mc[c] * S);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] = (long long)((sc[r] * mc[c]) * S);
+            }
+        }
+    }
+    if (__ballot(hit != 0)) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+        }
+        for (int off = 32; off > 0; off >>= 1) hit += __shfl_down(hit, off);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) atomicAdd(&sums[k], (unsigned long long)acc[k]);
+            atomicAdd(&a.counts[0], hit);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * hypothesis generation
  * ---------------------------------------------------------------------------------------------- */
@@ -1183,6 +1230,55 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
             ++k;
         }
     }
+    return TM_OK;
+}
+
+int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t* count,
+                      long long sums15[15]) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(pose16 && count && sums15, TM_ERR_INVALID, "tm_icp_accumulate: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure(16));
+    TM_FORWARD(s->w_counts.ensure(1));
+    TM_FORWARD(s->w_scores_fx.ensure(16));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, 16 * 8, c->stream));
+    score_args a;
+    a.spos = s->spos.p;
+    a.sref = s->sref.p;
+    a.mpos = m->pos.p;
+    a.mref = m->ref.p;
+    a.vox = m->voxels.p;
+    a.active = nullptr;
+    a.poses = s->w_poses.p;
+    a.counts = s->w_counts.p;
+    a.scores_fx = s->w_scores_fx.p + 15;
+    a.g = m->grid;
+    a.d2max = sq_threshold(dist_thres * m->resolution);
+    a.n_hyp = 1;
+    a.hyp_per_block = 1;
+    a.ablate = 0;
+    a.kind = m->metric_kind;
+    a.radius = m->metric_radius;
+    a.dmax = dist_thres * m->resolution;
+    a.stat_slots = nullptr;
+    a.bcode = nullptr;
+    a.bx = m->bdim[0];
+    a.by = m->bdim[1];
+    a.code_max = 255u;
+    hipLaunchKernelGGL(k_icp_accumulate, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
+                       s->w_scores_fx.p);
+    TM_HIP_CHECK(hipGetLastError());
+    unsigned long long h_sums[15];
+    uint32_t h_n = 0;
+    TM_HIP_CHECK(hipMemcpyAsync(h_sums, s->w_scores_fx.p, 15 * 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(&h_n, s->w_counts.p, 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *count = h_n;
+    for (int k = 0; k < 15; ++k) sums15[k] = (long long)h_sums[k];
     return TM_OK;
 }
 
