@@ -234,6 +234,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.spos = nullptr;
     a.sc.sref = s->oref.p;
     a.sc.mpos = m->pos.p;
+    a.sc.mpos3 = m->pos3.p;
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;

@@ -114,6 +114,7 @@ struct tm_model {
     tmx::dbuf<float4> pos;  /* xyz, w = (|tangent| > 0.7) ? 1 : 0 ; non-finite points keep NaN */
     tmx::dbuf<float4> ref;  /* tangent if is_tangent else normal */
     tmx::dbuf<float4> tan4; /* raw tangent xyz (pair build / hypothesis generation) */
+    tmx::dbuf<float> pos3;  /* packed xyz, 12 B per point, for the culled scoring kernel (ref.w carries the flag) */
     tmx::dbuf<uint32_t> voxels; /* 4x4x4-bricked: [brick][z&3][y&3][x&3], entries are NEW indices */
     uint64_t voxel_count = 0;   /* dense count ex*ey*ez (ABI view) */
     uint64_t voxel_slots = 0;   /* bricks * 64 */
@@ -153,6 +154,7 @@ struct tm_scene {
     tmx::dbuf<float4> oref;  /* tangent if tangent_mask else normal, w = tangent_mask */
     /* Morton-sorted order (scoring): 64 consecutive points form a tile with a bounding sphere */
     tmx::dbuf<float4> spos;       /* sorted xyz (masked / padding / non-finite -> NaN in x), w = bits of original index */
+    tmx::dbuf<float> spos3;       /* sorted xyz packed 12 B per point (same NaN convention) */
     tmx::dbuf<float4> sref;       /* sorted ref (tangent or normal), w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> tiles;      /* per tile: centre xyz, radius (negative = empty) */
     tmx::dbuf<float4> supers;     /* per super-tile (64 tiles = 4096 points): bounding sphere */

@@ -732,7 +732,7 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
         bool is_t = len(t) > 0.7f; /* reference include/impl/scene.hpp:469-470 */
         pos[k] = make_float4(s[0], s[1], s[2], is_t ? 1.f : 0.f);
         if (!fin3(s)) pos[k].x = std::numeric_limits<float>::quiet_NaN();
-        ref[k] = is_t ? make_float4(s[9], s[10], s[11], 0.f) : make_float4(s[4], s[5], s[6], 0.f);
+        ref[k] = is_t ? make_float4(s[9], s[10], s[11], 1.f) : make_float4(s[4], s[5], s[6], 0.f); /* w = is_tangent */
         tan4[k] = make_float4(s[9], s[10], s[11], 0.f);
         float w;
         memcpy(&w, &i, 4);
@@ -757,12 +757,20 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
     m->kd_n_pts = (uint32_t)kd_pts.size();
     int rc;
     if ((rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n)) ||
-        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->kd_lo.alloc(kb.lo.size())) || (rc = m->kd_hi.alloc(kb.hi.size())) ||
+        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->pos3.alloc((size_t)n * 3)) || (rc = m->kd_lo.alloc(kb.lo.size())) || (rc = m->kd_hi.alloc(kb.hi.size())) ||
         (rc = m->kd_pts.alloc(kd_pts.size()))) {
         tm_model_destroy(m);
         return rc;
     }
+    std::vector<float> pos3((size_t)n * 3);
+    for (uint32_t k = 0; k < n; ++k) {
+        pos3[3 * (size_t)k] = pos[k].x;
+        pos3[3 * (size_t)k + 1] = pos[k].y;
+        pos3[3 * (size_t)k + 2] = pos[k].z;
+    }
     hipError_t e = hipMemcpyAsync(m->pos.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->pos3.p, pos3.data(), (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && !kb.lo.empty())
         e = hipMemcpyAsync(m->kd_lo.p, kb.lo.data(), kb.lo.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && !kb.hi.empty())
@@ -918,6 +926,7 @@ int tm_model_destroy(tm_model* m) {
     m->pos.release();
     m->ref.release();
     m->tan4.release();
+    m->pos3.release();
     m->vpos.release();
     m->kd_lo.release();
     m->kd_hi.release();

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             for (int k = 0; k < 4; ++k) {
                 const bool have = i + k < n;
                 sidx[k] = (have ? s_list[i + k] : s_list[i]) * 64u + lane;
-                P[k] = a.spos[sidx[k]];
+                const float* sp = a.spos3 + 3u * (size_t)sidx[k]; /* 12 B per point: 12 lines per tile, not 16 */
+                P[k] = make_float4(sp[0], sp[1], sp[2], 0.f);
                 in[k] = have;
                 if (ball) { /* exact membership: (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point */
                     f3 d = make3(P[k].x, P[k].y, P[k].z) - bc;
@@ -237,14 +238,12 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             if (a.ablate == 2) { cnt += m[0] + m[1] + m[2] + m[3]; continue; }
             /* stage 3: model point gathers + distance test */
             bool ok[4];
-            float mw[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float4 mp = a.mpos[m[k]];
-                float dx = q[k].x - mp.x, dy = q[k].y - mp.y, dz = q[k].z - mp.z;
+                const float* mp = a.mpos3 + 3u * (size_t)m[k]; /* packed xyz: 5.3 points per 64-B line */
+                float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
                 float d2 = (dx * dx + dy * dy) + dz * dz;
                 ok[k] = near[k] & (d2 <= a.d2max);
-                mw[k] = mp.w;
             }
             if (a.ablate == 1) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
             /* stage 4: orientation term for the distance-passing points */
@@ -254,9 +253,9 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                     if (ok[k]) {
                         ++pass;
                         float4 sr = a.sref[sidx[k]];
-                        if (sr.w == mw[k]) {
+                        float4 mr = a.mref[m[k]]; /* w = is_tangent of the model point */
+                        if (sr.w == mr.w) {       /* use_tangent == is_tangent, reference :472 */
                             f3 r = xform_dir(T, make3(sr.x, sr.y, sr.z));
-                            float4 mr = a.mref[m[k]];
                             float term = fabsf(dot3(r, make3(mr.x, mr.y, mr.z)));
                             fx += (long long)((double)term * kFx);
                             ++cnt;
@@ -658,6 +657,14 @@ static int build_sorted(tm_scene* s) {
     TM_FORWARD(s->sref.ensure(n_pad));
     TM_FORWARD(s->tiles.ensure(n_tiles));
     TM_FORWARD(s->supers.ensure(n_super));
+    std::vector<float> spos3((size_t)n_pad * 3);
+    for (uint32_t k = 0; k < n_pad; ++k) {
+        spos3[3 * (size_t)k] = spos[k].x;
+        spos3[3 * (size_t)k + 1] = spos[k].y;
+        spos3[3 * (size_t)k + 2] = spos[k].z;
+    }
+    TM_FORWARD(s->spos3.ensure((size_t)n_pad * 3));
+    TM_HIP_CHECK(hipMemcpyAsync(s->spos3.p, spos3.data(), (size_t)n_pad * 12, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->supers.p, supers.data(), (size_t)n_super * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->spos.p, spos.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->sref.p, sref.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
@@ -713,8 +720,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, (size_t)n_hyp * 8, c->stream));
     score_args a;
     a.spos = s->spos.p;
+    a.spos3 = s->spos3.p;
     a.sref = s->sref.p;
     a.mpos = m->pos.p;
+    a.mpos3 = m->pos3.p;
     a.mref = m->ref.p;
     a.vox = m->voxels.p;
     a.active = d_active;
@@ -959,6 +968,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->oref.release();
     s->spos.release();
     s->sref.release();
+    s->spos3.release();
     s->tiles.release();
     s->supers.release();
     s->w_poses.release();
@@ -1187,8 +1197,10 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     TM_HIP_CHECK(hipMemsetAsync(s->w_u32a.p, 0xFF, (size_t)s->n * 4, c->stream));
     score_args a;
     a.spos = s->spos.p;
+    a.spos3 = s->spos3.p;
     a.sref = s->sref.p;
     a.mpos = m->pos.p;
+    a.mpos3 = m->pos3.p;
     a.mref = m->ref.p;
     a.vox = m->voxels.p;
     a.active = nullptr;
@@ -1248,8 +1260,10 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, 16 * 8, c->stream));
     score_args a;
     a.spos = s->spos.p;
+    a.spos3 = s->spos3.p;
     a.sref = s->sref.p;
     a.mpos = m->pos.p;
+    a.mpos3 = m->pos3.p;
     a.mref = m->ref.p;
     a.vox = m->voxels.p;
     a.active = nullptr;

@@ -17,8 +17,10 @@ constexpr double kFx = 1099511627776.0;     /* 2^40: fixed-point scale of the sc
 
 struct score_args {
     const float4* spos;
+    const float* spos3; /* culled kernel: packed xyz, 12 B per point */
     const float4* sref;
     const float4* mpos;
+    const float* mpos3; /* culled kernel: packed model xyz, 12 B per point; the is_tangent flag rides in mref.w */
     const float4* mref;
     const uint32_t* vox;
     const unsigned char* active; /* per original index, or null */
