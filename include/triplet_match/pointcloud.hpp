@@ -2,10 +2,11 @@
  * triplet_match/pointcloud.hpp — cloud container of the drop-in API.
  *
  * Mirrors the parts of the reference's pointcloud<Point> (include/pointcloud:13-93) the hot path
- * consumes: points, size(), resolution() (mean 1-NN distance, include/impl/pointcloud.hpp:66-82),
- * diameter() (:84-97). The kd-tree queries, curvature() and the range-v3 view adaptors are "next" rows
- *  and are not provided; resolution() runs tm_cloud_resolution (GPU kd-tree 2-NN) unless
- * a value was supplied with set_resolution().
+ * consumes: points, size(), from_pcd() (include/impl/pointcloud.hpp:58-64), resolution() (mean 1-NN
+ * distance, :66-82; tm_cloud_resolution, GPU kd-tree 2-NN, unless set_resolution() supplied a value),
+ * diameter() (:84-97) and curvature(k, idx) (:200-204; tm_cloud_curvature). The generic knn_* and
+ * radius_search_* accessors and the range-v3 view adaptors are not on the path and are not provided
+ * (the search's radius neighbourhood lives in scene.hpp).
  */
 #ifndef TRIPLET_MATCH_POINTCLOUD_HPP_
 #define TRIPLET_MATCH_POINTCLOUD_HPP_
@@ -14,6 +15,7 @@
 #include <limits>
 
 #include "common.hpp"
+#include "pcd_io.hpp"
 
 namespace triplet_match {
 
@@ -31,6 +33,19 @@ public:
     std::vector<Point> points;
 
     static Ptr empty() { return std::make_shared<pointcloud<Point>>(); }
+
+    /* include/impl/pointcloud.hpp:58-64. The reference ignores loadPCDFile's status, so a missing or
+     * malformed file yields an empty cloud there; here the reason is also printed. pcd::read throws. */
+    static Ptr from_pcd(const std::string& filename) {
+        Ptr self = empty();
+        try {
+            pcd::read(filename, self->points);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "[triplet_match::pointcloud::from_pcd] %s\n", e.what());
+            self->points.clear();
+        }
+        return self;
+    }
 
     size_t size() const { return points.size(); }
     void push_back(const Point& p) {
