@@ -160,6 +160,14 @@ int tm_scene_destroy(tm_scene* scene);
 int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);
 uint32_t tm_scene_size(const tm_scene* scene);
 
+/* nn = cloud_->radius_search_inclusive(radius, p1) as used at include/impl/scene.hpp:273
+ * (include/impl/pointcloud.hpp:172-183; PCL/FLANN leave the result order open): the indices j with
+ * |p_j - p_center|^2 <= radius^2 (fp32, ((dx*dx + dy*dy) + dz*dz)), ascending, the centre included.
+ * Membership is computed on the device; *count = total, out receives min(cap, total) entries
+ * (out may be NULL to count only). */
+int tm_scene_radius_subset(tm_scene* scene, uint32_t center_idx, float radius, int32_t* out, uint32_t cap,
+                           uint32_t* count);
+
 /* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
  * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same
  * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */

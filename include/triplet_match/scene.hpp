@@ -7,8 +7,6 @@
 #ifndef TRIPLET_MATCH_SCENE_HPP_
 #define TRIPLET_MATCH_SCENE_HPP_
 
-#include <unordered_map>
-
 #include "model.hpp"
 #include "search.hpp"
 
@@ -26,10 +24,7 @@ struct hip_backend {
     uint32_t n_t;
     float diam;
     search::params_t p;
-    /* uniform grid for radius_search_inclusive (include/impl/scene.hpp:273): exact membership */
-    float cell = 0.f;
-    float gmin[3];
-    std::unordered_map<uint64_t, std::vector<uint32_t>> grid;
+    std::vector<int32_t> nn_scratch; /* radius_subset output buffer, one slot per scene point */
 
     uint32_t scene_size() const { return (uint32_t)scloud->size(); }
     uint32_t model_size() const { return (uint32_t)mcloud->size(); }
@@ -40,46 +35,13 @@ struct hip_backend {
     bool pair_is_valid_sample(uint32_t i, uint32_t j) const {
         return tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor) != 0;
     }
-    static uint64_t pack(int64_t a, int64_t b, int64_t c) {
-        return ((uint64_t)(a + 1) << 42) ^ ((uint64_t)(b + 1) << 21) ^ (uint64_t)(c + 1);
-    }
-    void build_grid(float radius) {
-        cell = radius;
-        gmin[0] = gmin[1] = gmin[2] = std::numeric_limits<float>::max();
-        for (const auto& q : scloud->points) {
-            if (!q.getVector3fMap().allFinite()) continue;
-            gmin[0] = std::min(gmin[0], q.x);
-            gmin[1] = std::min(gmin[1], q.y);
-            gmin[2] = std::min(gmin[2], q.z);
-        }
-        grid.clear();
-        for (uint32_t i = 0; i < scloud->size(); ++i) {
-            const auto& q = scloud->points[i];
-            if (!q.getVector3fMap().allFinite()) continue;
-            grid[pack((int64_t)std::floor((q.x - gmin[0]) / cell), (int64_t)std::floor((q.y - gmin[1]) / cell),
-                      (int64_t)std::floor((q.z - gmin[2]) / cell))]
-                .push_back(i);
-        }
-    }
+    /* radius_search_inclusive(radius, i), include/impl/scene.hpp:273: membership on the device */
     void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
-        if (cell != radius || grid.empty()) build_grid(radius);
-        out.clear();
-        const auto& c = scloud->points[i];
-        const float r2 = radius * radius;
-        int64_t k[3] = {(int64_t)std::floor((c.x - gmin[0]) / cell), (int64_t)std::floor((c.y - gmin[1]) / cell),
-                        (int64_t)std::floor((c.z - gmin[2]) / cell)};
-        for (int64_t a = k[0] - 1; a <= k[0] + 1; ++a)
-            for (int64_t b = k[1] - 1; b <= k[1] + 1; ++b)
-                for (int64_t d = k[2] - 1; d <= k[2] + 1; ++d) {
-                    auto it = grid.find(pack(a, b, d));
-                    if (it == grid.end()) continue;
-                    for (uint32_t j : it->second) {
-                        const auto& q = scloud->points[j];
-                        float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-                        if ((dx * dx + dy * dy) + dz * dz <= r2) out.push_back((int32_t)j);
-                    }
-                }
-        std::sort(out.begin(), out.end());
+        nn_scratch.resize(scloud->size());
+        uint32_t count = 0;
+        check(tm_scene_radius_subset(s, i, radius, nn_scratch.data(), (uint32_t)nn_scratch.size(), &count),
+              "tm_scene_radius_subset");
+        out.assign(nn_scratch.begin(), nn_scratch.begin() + count);
     }
     void generate(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses) {
         const uint32_t n_pairs = (uint32_t)(ij.size() / 2);
@@ -196,6 +158,8 @@ public:
      * every hypothesis to the end and enables the batched GPU path (16 first points per launch) */
     void set_early_drop(bool on) { early_drop_ = on; }
     void set_verbose(bool on) { verbose_ = on; }
+    /* wall-clock seconds per phase of the last find_all_parallel (search::stats_t) */
+    const search::stats_t& last_stats() const { return stats_; }
 
     /* include/impl/scene.hpp:39-98 */
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
@@ -233,6 +197,8 @@ public:
         be.p.workers = workers_;
         be.p.early_drop = early_drop_;
         be.p.verbose = verbose_;
+        stats_ = search::stats_t();
+        be.p.stats = &stats_;
         auto found = search::find_all(be, tangent_mask, be.p);
         std::vector<match_t> results;
         for (auto& c : found) {
@@ -274,6 +240,7 @@ protected:
     uint32_t curvature_k_ = 0;
     bool early_drop_ = true;
     bool verbose_ = false;
+    search::stats_t stats_;
 };
 
 }  // namespace triplet_match

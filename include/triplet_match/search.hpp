@@ -20,11 +20,11 @@
 #define TRIPLET_MATCH_SEARCH_HPP_
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <random>
-#include <set>
 #include <vector>
 
 namespace triplet_match {
@@ -44,6 +44,12 @@ struct candidate_t { /* match_t with the scene->model transform (inverted once a
     double signed_score = 0.0;
 };
 
+/* wall-clock seconds per phase of a search, filled when params_t::stats points at one */
+struct stats_t {
+    double radius = 0, shuffle = 0, sample = 0, generate_score = 0, extract = 0, icp = 0, arbitration = 0,
+           mask = 0, total = 0;
+};
+
 struct params_t {
     float dist_thres = 3.f;
     float accept_prob = 0.5f; /* model_match_factor */
@@ -55,6 +61,7 @@ struct params_t {
     uint64_t seed = 13;
     bool early_drop = true; /* detail::early_drop, :25 */
     bool verbose = false;   /* progress lines on stderr (the reference prints pdebug lines) */
+    stats_t* stats = nullptr;
 };
 
 /*
@@ -75,6 +82,19 @@ struct params_t {
  */
 
 namespace detail {
+
+/* adds the lifetime of the object to *acc (no-op for nullptr) */
+struct timed {
+    double* acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit timed(double* a) : acc(a) {
+        if (acc) t0 = std::chrono::steady_clock::now();
+    }
+    ~timed() {
+        if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+#define TM_TIMED(field) ::triplet_match::search::detail::timed _tm_timer_##field(p.stats ? &p.stats->field : nullptr)
 
 /* ICP sums: count n and, over the correspondences (s = scene point, m = model point), sum s (3),
  * sum m (3), sum s_a*m_b (9, index 3*a+b), each term truncated to 2^-32 fixed point and added as
@@ -196,6 +216,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             batch_ij.clear();
             return;
         }
+        TM_TIMED(generate_score);
         be.generate_with_pairs(batch_ij, poses, pair_of_hyp);
         if (!poses.empty()) {
             centers.resize(poses.size());
@@ -213,20 +234,28 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     for (uint32_t i : firsts) {
         if (fp_mask[i] || mask[i]) continue; /* :268 */
         ++cons;
-        be.radius_subset(i, be.model_diameter(), nn); /* :273 */
+        {
+            TM_TIMED(radius);
+            be.radius_subset(i, be.model_diameter(), nn); /* :273 */
+        }
         if (nn.empty()) continue;
         double prob = (double)n_model_all / (double)nn.size();
         uint64_t inner_bound = (uint64_t)(-std::log(1.0 - match_probability) / prob); /* :277 */
         inner_bound = std::max(inner_bound, min_sample_count);
         inner_bound = std::min<uint64_t>(inner_bound, nn.size());
         std::vector<int32_t> inner0(nn.begin(), nn.end());
-        detail::partial_shuffle(inner0, inner0.size(), rng); /* :285 */
+        {
+            TM_TIMED(shuffle);
+            detail::partial_shuffle(inner0, inner0.size(), rng); /* :285 */
+        }
         if (!best_ts.empty()) continue; /* the reference keeps looping without effect once a candidate
                                            exists (best_ts.empty() gates :331; early-out is unreachable,
                                            SURVEY Q8): skip the dead work, keep `cons` and the rng stream */
         /* the valid samples of this first point, up to inner_bound + 1 (:305, :350) */
         ij.clear();
         uint32_t valid_samples = 0;
+        {
+        TM_TIMED(sample);
         for (int32_t j : inner0) {
             if (!tangent_mask[j] || mask[j] || i == (uint32_t)j) continue; /* :290 */
             if (!be.pair_is_valid_sample(i, (uint32_t)j)) continue;         /* :293-302 */
@@ -234,6 +263,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             ij.push_back((uint32_t)j);
             ++valid_samples;
             if (valid_samples > inner_bound) break; /* :350 */
+        }
         }
         if (ij.empty()) continue;
         if (batched) {
@@ -244,6 +274,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             }
             continue;
         }
+        TM_TIMED(generate_score);
         be.generate(ij, poses); /* :304-319, visit order */
         if (poses.empty()) continue;
         be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
@@ -257,6 +288,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     }
     if (batched) flush_batch();
     std::vector<candidate_t> matches;
+    TM_TIMED(extract);
     for (size_t k = 0; k < best_ts.size() && matches.size() < 5; ++k) { /* :361-364 */
         candidate_t c;
         be.extract(best_ts[k], p.dist_thres, c);
@@ -271,6 +303,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
 template <class Backend>
 inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p) {
     if (p.max_icp_iterations == 0) return match;
+    TM_TIMED(icp);
     const float dt2 = 2.f * p.dist_thres;
     pose_t best_t = match.transform;
     detail::icp_sums_t best = be.icp_sums(best_t, dt2);
@@ -333,22 +366,26 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         for (uint32_t k = 0, seen = 0; k < chunk.size() && seen < cons; ++k, ++seen) fp_mask[chunk[k]] = 1; /* :160-162 */
         for (auto& mt : res.first) cands.push_back(icp(be, mt, p)); /* :169-171 */
     }
+    TM_TIMED(arbitration);
     std::stable_sort(cands.begin(), cands.end(), [](const candidate_t& a, const candidate_t& b) {
         return a.scene_corrs.size() > b.scene_corrs.size(); /* :193-195 */
     });
     std::vector<candidate_t> result;
-    std::set<uint32_t> used;
+    std::vector<unsigned char> used(be.scene_size(), 0); /* the reference's std::set<uint32_t> used, :198 */
+    std::vector<uint32_t> newly;
     for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
         candidate_t out;
         out.transform = cand.transform;
         out.signed_score = cand.signed_score;
-        std::set<uint32_t> used_copy = used;
+        newly.clear(); /* what this candidate adds to `used`; undone if it is rejected (used_copy, :203) */
         for (size_t k = 0; k < cand.scene_corrs.size(); ++k) {
-            if (used.find(cand.scene_corrs[k]) == used.end()) {
-                out.scene_corrs.push_back(cand.scene_corrs[k]);
+            const uint32_t idx = cand.scene_corrs[k];
+            if (!used[idx]) {
+                out.scene_corrs.push_back(idx);
                 out.model_corrs.push_back(cand.model_corrs[k]);
+                used[idx] = 1;
+                newly.push_back(idx);
             }
-            used.insert(cand.scene_corrs[k]);
         }
         uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
         for (uint32_t idx : out.scene_corrs)
@@ -357,7 +394,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
                     cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
         if (score < min_points || score_all < min_points_all) { /* :227 */
-            used = used_copy;
+            for (uint32_t idx : newly) used[idx] = 0;
             continue;
         }
         result.push_back(std::move(out));
@@ -376,6 +413,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     for (uint32_t i = 0; i < n; ++i)
         if (tangent_mask[i]) tangent_indices.push_back(i);
     const uint32_t n_scene = (uint32_t)tangent_indices.size();
+    TM_TIMED(total);
     be.set_mask(mask);
     std::vector<candidate_t> results;
     for (;;) {
@@ -385,6 +423,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             for (uint32_t idx : mt.scene_corrs) mask[idx] = 1; /* :88-90 */
             results.push_back(std::move(mt));
         }
+        TM_TIMED(mask);
         be.set_mask(mask);
     }
     return results;

@@ -706,3 +706,28 @@ def test_cloud_curvature_bit_exact(gpu_ctx):
     for k in (1, 5, 32):
         assert np.array_equal(gpu_ctx.cloud_curvature(model[:500], k).view(np.uint32),
                               tmo.cloud_curvature(model[:500], k).view(np.uint32))
+
+
+def test_radius_subset_bit_exact(gpu_ctx, gpu_small, oracle_small, small_case):
+    """nn = radius_search_inclusive(diameter, p1) (include/impl/scene.hpp:273): same members, ascending."""
+    gs, os_ = gpu_small["scene"], oracle_small["scene"]
+    diam = oracle_small["model"].diameter
+    rng = np.random.default_rng(21)
+    n = len(small_case["scene"]["surfels"])
+    for c in rng.integers(0, n, 12):
+        for r in (diam, 0.25 * diam, 0.0):
+            a, b = gs.radius_subset(int(c), r), os_.radius_subset(int(c), r)
+            assert np.array_equal(a, b)
+            assert int(c) in a  # inclusive
+    # points exactly on the sphere, and non-finite points
+    s = np.zeros((300, 12), np.float32)
+    s[:, 3] = 1
+    s[1:101, 0] = 0.5
+    s[101:201, 1] = np.nextafter(np.float32(0.5), np.float32(1))
+    s[201:250, 2] = np.nextafter(np.float32(0.5), np.float32(0))
+    s[250, 0] = np.nan
+    s[251, 1] = np.inf
+    gs2 = capi.Scene(gpu_ctx, s, np.zeros(300, np.int32))
+    os2 = tmo.Scene(s, np.zeros(300, np.int32))
+    a, b = gs2.radius_subset(0, 0.5), os2.radius_subset(0, 0.5)
+    assert np.array_equal(a, b) and len(a) == 1 + 100 + 49 + 48  # centre, on-sphere, just inside, origin

@@ -50,6 +50,13 @@ int main(int argc, char** argv) {
     printf("model init %.3f s; find_all_parallel(early_drop=%d, icp=%u) %.3f s -> %zu matches\n",
            std::chrono::duration<double>(t1 - t0).count(), (int)early_drop, icp,
            std::chrono::duration<double>(t2 - t1).count(), matches.size());
+    {
+        const auto& st = s.last_stats();
+        printf("   phases [s]: radius %.3f shuffle %.3f sample %.3f generate+score %.3f extract %.3f icp %.3f "
+               "arbitration %.3f mask %.3f | total %.3f (scene setup = %.3f)\n",
+               st.radius, st.shuffle, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask,
+               st.total, std::chrono::duration<double>(t2 - t1).count() - st.total);
+    }
     for (const auto& mt : matches) {
         double best = 1e30;
         for (const auto& t : truth) {

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
+    "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
@@ -485,6 +486,14 @@ class Scene:
         else:
             m, p = _i(mask)
             _check(lib().tm_scene_set_mask(self.h, p))
+
+    def radius_subset(self, center_idx, radius):
+        cnt = C.c_uint32(0)
+        _check(lib().tm_scene_radius_subset(self.h, center_idx, radius, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, np.int32)
+        _check(lib().tm_scene_radius_subset(self.h, center_idx, radius, out.ctypes.data_as(i32p), out.size,
+                                            C.byref(cnt)))
+        return out
 
     def generate_hypotheses(self, model, ij_pairs, min_diameter_factor=0.2,
                             max_diameter_factor=1.0, force_up=False, query_limit=200, cap=None):

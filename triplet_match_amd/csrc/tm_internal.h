@@ -147,7 +147,12 @@ struct tm_scene {
     uint32_t n = 0;
     std::vector<float> h_cloud;
     std::vector<int32_t> h_tmask, h_mask;
-    std::vector<uint32_t> h_order; /* Morton order of the points (independent of the mask): sorted -> original */
+    /* device copies of the inputs (original order) and the Morton order derived from them */
+    tmx::dbuf<float> d_cloud;         /* n x 12 floats: the surfels as handed over */
+    tmx::dbuf<int32_t> d_tmask, d_mask;
+    tmx::dbuf<uint32_t> d_order;      /* sorted slot -> original index (independent of the mask) */
+    tmx::dbuf<unsigned char> d_bounds; /* tmx::scene_bounds (tm_scene_build.hip) */
+    uint64_t n_live = 0;              /* finite and unmasked points */
     /* original order (hypothesis generation addresses points by original index) */
     tmx::dbuf<float4> opos;  /* xyz, w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> otan;  /* raw tangent xyz, w = masked ? 1 : 0 */
@@ -169,10 +174,15 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
     tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
+    tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
+    std::vector<unsigned long long> h_words;
 };
 
 namespace tmx {
 int scratch_ensure(tm_ctx* ctx, size_t bytes);
+/* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
+int scene_upload(tm_scene* s);
+int scene_build(tm_scene* s, bool resort);
 }
 
 #endif /* TM_INTERNAL_H_ */

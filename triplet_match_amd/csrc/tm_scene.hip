@@ -525,176 +525,6 @@ static inline bool fin3(const float* p) {
     return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
 }
 
-static inline uint64_t spread21(uint64_t v) {
-    v &= 0x1FFFFFull;
-    v = (v | (v << 32)) & 0x1F00000000FFFFull;
-    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
-    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
-    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
-    v = (v | (v << 2)) & 0x1249249249249249ull;
-    return v;
-}
-
-/* Sort the scene along a Morton curve (63-bit code over the finite bounding box) and upload the
- * scoring arrays. 64 consecutive sorted points form a tile with a bounding sphere used by the
- * culled kernel; masked and non-finite points carry NaN and never enter a sphere. */
-static int build_sorted(tm_scene* s) {
-    tm_ctx* c = s->ctx;
-    const uint32_t n = s->n;
-    const float big = std::numeric_limits<float>::max();
-    float mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* p = s->h_cloud.data() + (size_t)i * 12;
-        if (!fin3(p)) continue;
-        for (int d = 0; d < 3; ++d) {
-            mn[d] = std::min(mn[d], p[d]);
-            mx[d] = std::max(mx[d], p[d]);
-        }
-    }
-    if (mn[0] > mx[0])
-        for (int d = 0; d < 3; ++d) mn[d] = mx[d] = 0.f;
-    double ext = std::max(std::max((double)mx[0] - mn[0], (double)mx[1] - mn[1]), (double)mx[2] - mn[2]);
-    double inv = ext > 0.0 ? 2097151.0 / ext : 0.0;
-    float cmax = 0.f;
-    for (int d = 0; d < 3; ++d) cmax = std::max(cmax, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
-    s->coord_max = cmax;
-    if (s->h_order.size() != n) { /* the order does not depend on the mask: sort once per scene */
-        std::vector<std::pair<uint64_t, uint32_t>> order(n);
-        for (uint32_t i = 0; i < n; ++i) {
-            const float* p = s->h_cloud.data() + (size_t)i * 12;
-            uint64_t code = ~0ull; /* non-finite points sort last */
-            if (fin3(p)) {
-                uint64_t ix = (uint64_t)(((double)p[0] - mn[0]) * inv);
-                uint64_t iy = (uint64_t)(((double)p[1] - mn[1]) * inv);
-                uint64_t iz = (uint64_t)(((double)p[2] - mn[2]) * inv);
-                code = spread21(ix) | (spread21(iy) << 1) | (spread21(iz) << 2);
-            }
-            order[i] = {code, i};
-        }
-        std::sort(order.begin(), order.end());
-        s->h_order.resize(n);
-        for (uint32_t k = 0; k < n; ++k) s->h_order[k] = order[k].second;
-    }
-    const uint32_t n_pad = ((n + kScoreTile - 1) / kScoreTile) * kScoreTile;
-    const uint32_t n_tiles = n_pad / 64;
-    const float nanv = std::numeric_limits<float>::quiet_NaN();
-    std::vector<float4> spos(n_pad), sref(n_pad), tiles(n_tiles);
-    for (uint32_t k = 0; k < n_pad; ++k) {
-        if (k >= n) {
-            spos[k] = make_float4(nanv, 0.f, 0.f, 0.f);
-            sref[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        uint32_t i = s->h_order[k];
-        const float* p = s->h_cloud.data() + (size_t)i * 12;
-        float w;
-        memcpy(&w, &i, 4);
-        bool dead = !fin3(p) || s->h_mask[i] != 0;
-        spos[k] = make_float4(dead ? nanv : p[0], p[1], p[2], w);
-        bool ut = s->h_tmask[i] != 0;
-        sref[k] = ut ? make_float4(p[9], p[10], p[11], 1.f) : make_float4(p[4], p[5], p[6], 0.f);
-    }
-    for (uint32_t t = 0; t < n_tiles; ++t) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        int live = 0;
-        for (uint32_t k = t * 64; k < t * 64 + 64; ++k) {
-            if (!(spos[k].x == spos[k].x)) continue;
-            const float q[3] = {spos[k].x, spos[k].y, spos[k].z};
-            for (int d = 0; d < 3; ++d) {
-                lo[d] = std::min(lo[d], (double)q[d]);
-                hi[d] = std::max(hi[d], (double)q[d]);
-            }
-            ++live;
-        }
-        if (!live) {
-            tiles[t] = make_float4(0.f, 0.f, 0.f, -1.f);
-            continue;
-        }
-        float cx = (float)(0.5 * (lo[0] + hi[0])), cy = (float)(0.5 * (lo[1] + hi[1])),
-              cz = (float)(0.5 * (lo[2] + hi[2]));
-        double r2 = 0.0;
-        for (uint32_t k = t * 64; k < t * 64 + 64; ++k) {
-            if (!(spos[k].x == spos[k].x)) continue;
-            double dx = (double)spos[k].x - cx, dy = (double)spos[k].y - cy, dz = (double)spos[k].z - cz;
-            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-        }
-        float r = (float)(std::sqrt(r2) * (1.0 + 1e-6));
-        r = std::nextafter(r, std::numeric_limits<float>::infinity());
-        tiles[t] = make_float4(cx, cy, cz, r);
-    }
-    /* super-tiles: 64 consecutive tiles (one culling chunk row); sphere over the live points */
-    const uint32_t n_super = (n_tiles + 63) / 64;
-    std::vector<float4> supers(n_super);
-    for (uint32_t u = 0; u < n_super; ++u) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        int live = 0;
-        const uint32_t k0 = u * 4096u, k1 = std::min(k0 + 4096u, n_pad);
-        for (uint32_t k = k0; k < k1; ++k) {
-            if (!(spos[k].x == spos[k].x)) continue;
-            const float q[3] = {spos[k].x, spos[k].y, spos[k].z};
-            for (int d = 0; d < 3; ++d) {
-                lo[d] = std::min(lo[d], (double)q[d]);
-                hi[d] = std::max(hi[d], (double)q[d]);
-            }
-            ++live;
-        }
-        if (!live) {
-            supers[u] = make_float4(0.f, 0.f, 0.f, -1.f);
-            continue;
-        }
-        float cx = (float)(0.5 * (lo[0] + hi[0])), cy = (float)(0.5 * (lo[1] + hi[1])),
-              cz = (float)(0.5 * (lo[2] + hi[2]));
-        double r2 = 0.0;
-        for (uint32_t k = k0; k < k1; ++k) {
-            if (!(spos[k].x == spos[k].x)) continue;
-            double dx = (double)spos[k].x - cx, dy = (double)spos[k].y - cy, dz = (double)spos[k].z - cz;
-            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-        }
-        float r = (float)(std::sqrt(r2) * (1.0 + 1e-6));
-        supers[u] = make_float4(cx, cy, cz, std::nextafter(r, std::numeric_limits<float>::infinity()));
-    }
-    TM_FORWARD(s->spos.ensure(n_pad));
-    TM_FORWARD(s->sref.ensure(n_pad));
-    TM_FORWARD(s->tiles.ensure(n_tiles));
-    TM_FORWARD(s->supers.ensure(n_super));
-    std::vector<float> spos3((size_t)n_pad * 3);
-    for (uint32_t k = 0; k < n_pad; ++k) {
-        spos3[3 * (size_t)k] = spos[k].x;
-        spos3[3 * (size_t)k + 1] = spos[k].y;
-        spos3[3 * (size_t)k + 2] = spos[k].z;
-    }
-    TM_FORWARD(s->spos3.ensure((size_t)n_pad * 3));
-    TM_HIP_CHECK(hipMemcpyAsync(s->spos3.p, spos3.data(), (size_t)n_pad * 12, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->supers.p, supers.data(), (size_t)n_super * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->spos.p, spos.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->sref.p, sref.data(), (size_t)n_pad * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->tiles.p, tiles.data(), (size_t)n_tiles * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    s->n_sorted = n_pad;
-    s->n_tiles = n_tiles;
-    return TM_OK;
-}
-
-static int upload_original(tm_scene* s) {
-    tm_ctx* c = s->ctx;
-    const uint32_t n = s->n;
-    std::vector<float4> opos(n), otan(n), onrm(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* p = s->h_cloud.data() + (size_t)i * 12;
-        opos[i] = make_float4(p[0], p[1], p[2], s->h_tmask[i] ? 1.f : 0.f);
-        otan[i] = make_float4(p[9], p[10], p[11], s->h_mask[i] ? 1.f : 0.f);
-        onrm[i] = s->h_tmask[i] ? make_float4(p[9], p[10], p[11], 1.f) : make_float4(p[4], p[5], p[6], 0.f);
-    }
-    TM_FORWARD(s->opos.ensure(n));
-    TM_FORWARD(s->otan.ensure(n));
-    TM_FORWARD(s->oref.ensure(n));
-    TM_HIP_CHECK(hipMemcpyAsync(s->oref.p, onrm.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->opos.p, opos.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->otan.p, otan.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return TM_OK;
-}
-
 static int check_pair(const tm_scene* s, const tm_model* m) {
     TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
@@ -811,12 +641,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     return TM_OK;
 }
 
-static uint64_t count_active(const tm_scene* s) {
-    uint64_t k = 0;
-    for (uint32_t i = 0; i < s->n; ++i)
-        if (!s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++k;
-    return k;
-}
+static uint64_t count_active(const tm_scene* s) { return s->n_live; }
 
 static int generate_device(tm_scene* s, tm_model* m, const uint2* d_ij, uint32_t n_pairs, float minf,
                            float maxf, int force_up, int query_limit, float* d_poses, uint4* d_prov,
@@ -949,8 +774,8 @@ int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t
     s->h_cloud.assign(surfels, surfels + (size_t)n * 12);
     s->h_tmask.assign(tangent_mask, tangent_mask + n);
     s->h_mask.assign(n, 0);
-    int rc = upload_original(s);
-    if (!rc) rc = build_sorted(s);
+    int rc = scene_upload(s);
+    if (!rc) rc = scene_build(s, true);
     if (rc) {
         tm_scene_destroy(s);
         return rc;
@@ -963,6 +788,11 @@ int tm_scene_destroy(tm_scene* s) {
     if (!s) return TM_OK;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    s->d_cloud.release();
+    s->d_tmask.release();
+    s->d_mask.release();
+    s->d_order.release();
+    s->d_bounds.release();
     s->opos.release();
     s->otan.release();
     s->oref.release();
@@ -980,6 +810,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_u32c.release();
     s->w_stats.release();
     s->w_pairs.release();
+    s->w_words.release();
     delete s;
     return TM_OK;
 }
@@ -991,8 +822,9 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
         s->h_mask.assign(mask, mask + s->n);
     else
         s->h_mask.assign(s->n, 0);
-    TM_FORWARD(upload_original(s));
-    return build_sorted(s);
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)s->n * 4, hipMemcpyHostToDevice,
+                                s->ctx->stream));
+    return scene_build(s, false);
 }
 
 uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }

@@ -1,0 +1,421 @@
+/*
+ * tm_scene_build.hip — device-side preparation of a scene for the scoring kernels.
+ *
+ * The reference keeps the scene as a pcl::PointCloud plus two host bit-vectors (tangent_mask_, mask_,
+ * include/impl/scene.hpp:41-58,87-90) and walks it point by point. Here the cloud is uploaded once
+ * (48 B per surfel) and everything the kernels read is derived on the GPU:
+ *
+ *   k_scene_original   opos / otan / oref in original order (hypothesis generation addresses samples
+ *                      by their original index)
+ *   k_scene_bounds     bounding box of the finite points (ordered-integer atomics)
+ *   k_scene_morton     63-bit Morton code per point; non-finite points sort last
+ *   rocprim radix sort (code, index) pairs -> `order` (sorted slot -> original index); stable, so
+ *                      equal codes keep ascending index
+ *   k_scene_gather     spos / spos3 / sref in sorted order; masked, non-finite and padding slots carry
+ *                      NaN in x so that they fail the in-grid test; counts the live points
+ *   k_scene_tiles      bounding sphere of every 64 consecutive sorted points (one wave per tile)
+ *   k_scene_supers     bounding sphere of every 4096 consecutive sorted points (one block each)
+ *
+ * The order does not depend on mask_, so tm_scene_set_mask re-runs only the last four steps. Inlier
+ * counts and fixed-point scores are independent of the order of the points, and the spheres are
+ * conservative (radius rounded up), so none of this changes a result; it only decides what the culled
+ * kernel may skip. All of it is HBM-bound streaming: ~0.2 KB per point in total.
+ */
+#include <cstring>
+
+#include "tm_internal.h"
+#include "tm_score.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <limits>
+
+namespace tmx {
+
+struct scene_bounds {
+    unsigned int lo[3]; /* ordered-integer encodings of the minimum / maximum finite coordinate */
+    unsigned int hi[3];
+    unsigned int cmax;  /* bits of max |coordinate| (non-negative floats order like their bits) */
+    unsigned int live;  /* points that are finite and not masked */
+};
+
+__device__ __forceinline__ unsigned int f2ord(float f) {
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(unsigned int u) {
+    unsigned int b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+__global__ __launch_bounds__(256) void k_scene_original(const float* __restrict__ cloud,
+                                                        const int32_t* __restrict__ tmask,
+                                                        const int32_t* __restrict__ mask, uint32_t n,
+                                                        float4* __restrict__ opos, float4* __restrict__ otan,
+                                                        float4* __restrict__ oref) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4* s = reinterpret_cast<const float4*>(cloud) + (size_t)i * 3;
+    float4 a = s[0], b = s[1], c = s[2];
+    bool ut = tmask[i] != 0;
+    opos[i] = make_float4(a.x, a.y, a.z, ut ? 1.f : 0.f);
+    otan[i] = make_float4(c.y, c.z, c.w, mask[i] != 0 ? 1.f : 0.f);
+    oref[i] = ut ? make_float4(c.y, c.z, c.w, 1.f) : make_float4(b.x, b.y, b.z, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_scene_bounds(const float* __restrict__ cloud, uint32_t n,
+                                                      scene_bounds* __restrict__ out) {
+    __shared__ unsigned int s_lo[3][4], s_hi[3][4], s_c[4];
+    unsigned int lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u}, cm = 0u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(cloud)[(size_t)i * 3];
+        if (!finite3(a.x, a.y, a.z)) continue;
+        const float q[3] = {a.x, a.y, a.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            unsigned int o = f2ord(q[d]);
+            lo[d] = min(lo[d], o);
+            hi[d] = max(hi[d], o);
+            cm = max(cm, __float_as_uint(fabsf(q[d])));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = min(lo[d], (unsigned int)__shfl_xor((int)lo[d], off));
+            hi[d] = max(hi[d], (unsigned int)__shfl_xor((int)hi[d], off));
+        }
+        cm = max(cm, (unsigned int)__shfl_xor((int)cm, off));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < 3; ++d) {
+            s_lo[d][w] = lo[d];
+            s_hi[d][w] = hi[d];
+        }
+        s_c[w] = cm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int d = 0; d < 3; ++d) {
+            atomicMin(&out->lo[d], min(min(s_lo[d][0], s_lo[d][1]), min(s_lo[d][2], s_lo[d][3])));
+            atomicMax(&out->hi[d], max(max(s_hi[d][0], s_hi[d][1]), max(s_hi[d][2], s_hi[d][3])));
+        }
+        atomicMax(&out->cmax, max(max(s_c[0], s_c[1]), max(s_c[2], s_c[3])));
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21_dev(unsigned long long v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_scene_morton(const float* __restrict__ cloud, uint32_t n,
+                                                      const scene_bounds* __restrict__ bnd,
+                                                      unsigned long long* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 a = reinterpret_cast<const float4*>(cloud)[(size_t)i * 3];
+    unsigned long long code = ~0ull;
+    if (finite3(a.x, a.y, a.z)) {
+        const double mn0 = ord2f(bnd->lo[0]), mn1 = ord2f(bnd->lo[1]), mn2 = ord2f(bnd->lo[2]);
+        const double e0 = (double)ord2f(bnd->hi[0]) - mn0, e1 = (double)ord2f(bnd->hi[1]) - mn1,
+                     e2 = (double)ord2f(bnd->hi[2]) - mn2;
+        const double ext = fmax(fmax(e0, e1), e2);
+        const double inv = ext > 0.0 ? 2097151.0 / ext : 0.0;
+        unsigned long long ix = (unsigned long long)(((double)a.x - mn0) * inv);
+        unsigned long long iy = (unsigned long long)(((double)a.y - mn1) * inv);
+        unsigned long long iz = (unsigned long long)(((double)a.z - mn2) * inv);
+        code = spread21_dev(ix) | (spread21_dev(iy) << 1) | (spread21_dev(iz) << 2);
+    }
+    keys[i] = code;
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_scene_gather(const float* __restrict__ cloud,
+                                                      const int32_t* __restrict__ tmask,
+                                                      const int32_t* __restrict__ mask,
+                                                      const uint32_t* __restrict__ order, uint32_t n,
+                                                      uint32_t n_pad, float4* __restrict__ spos,
+                                                      float* __restrict__ spos3, float4* __restrict__ sref,
+                                                      scene_bounds* __restrict__ bnd) {
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    bool live = false;
+    if (k < n_pad) {
+        const float nanv = __builtin_nanf("");
+        float4 p = make_float4(nanv, 0.f, 0.f, 0.f), r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < n) {
+            uint32_t i = order[k];
+            const float4* s = reinterpret_cast<const float4*>(cloud) + (size_t)i * 3;
+            float4 a = s[0], b = s[1], c = s[2];
+            live = finite3(a.x, a.y, a.z) && mask[i] == 0;
+            p = make_float4(live ? a.x : nanv, a.y, a.z, __uint_as_float(i));
+            r = tmask[i] != 0 ? make_float4(c.y, c.z, c.w, 1.f) : make_float4(b.x, b.y, b.z, 0.f);
+        }
+        spos[k] = p;
+        sref[k] = r;
+        spos3[3 * (size_t)k] = p.x;
+        spos3[3 * (size_t)k + 1] = p.y;
+        spos3[3 * (size_t)k + 2] = p.z;
+    }
+    unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&bnd->live, (unsigned int)__popcll(b));
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+/* sphere = (centre of the bounding box of the live points, largest distance to it rounded up);
+ * w < 0 marks a tile without live points */
+__device__ __forceinline__ float4 sphere_of(double lo0, double lo1, double lo2, double hi0, double hi1,
+                                            double hi2, float& cx, float& cy, float& cz) {
+    cx = (float)(0.5 * (lo0 + hi0));
+    cy = (float)(0.5 * (lo1 + hi1));
+    cz = (float)(0.5 * (lo2 + hi2));
+    return make_float4(cx, cy, cz, 0.f);
+}
+__device__ __forceinline__ float radius_up(double r2) {
+    float r = (float)(sqrt(r2) * (1.0 + 1e-6));
+    return nextafterf(r, __builtin_inff());
+}
+
+__global__ __launch_bounds__(256) void k_scene_tiles(const float4* __restrict__ spos, uint32_t n_tiles,
+                                                     float4* __restrict__ tiles) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return; /* whole waves leave together */
+    float4 p = spos[(size_t)t * 64 + (threadIdx.x & 63)];
+    const bool live = p.x == p.x;
+    if (__ballot(live) == 0ull) {
+        if ((threadIdx.x & 63) == 0) tiles[t] = make_float4(0.f, 0.f, 0.f, -1.f);
+        return;
+    }
+    const double big = 1e300;
+    double lo0 = wave_min(live ? (double)p.x : big), hi0 = wave_max(live ? (double)p.x : -big);
+    double lo1 = wave_min(live ? (double)p.y : big), hi1 = wave_max(live ? (double)p.y : -big);
+    double lo2 = wave_min(live ? (double)p.z : big), hi2 = wave_max(live ? (double)p.z : -big);
+    float cx, cy, cz;
+    float4 s = sphere_of(lo0, lo1, lo2, hi0, hi1, hi2, cx, cy, cz);
+    double dx = (double)p.x - cx, dy = (double)p.y - cy, dz = (double)p.z - cz;
+    double r2 = wave_max(live ? dx * dx + dy * dy + dz * dz : 0.0);
+    s.w = radius_up(r2);
+    if ((threadIdx.x & 63) == 0) tiles[t] = s;
+}
+
+__global__ __launch_bounds__(256) void k_scene_supers(const float4* __restrict__ spos, uint32_t n_pad,
+                                                      float4* __restrict__ supers) {
+    __shared__ double s_lo[3][4], s_hi[3][4], s_r[4];
+    __shared__ int s_live[4];
+    const uint32_t k0 = blockIdx.x * 4096u, k1 = min(k0 + 4096u, n_pad);
+    const double big = 1e300;
+    double lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
+    int live = 0;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
+        float4 p = spos[k];
+        if (!(p.x == p.x)) continue;
+        const double q[3] = {(double)p.x, (double)p.y, (double)p.z};
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = fmin(lo[d], q[d]);
+            hi[d] = fmax(hi[d], q[d]);
+        }
+        live = 1;
+    }
+    const int w = threadIdx.x >> 6;
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = wave_min(lo[d]);
+        hi[d] = wave_max(hi[d]);
+    }
+    unsigned long long any = __ballot(live != 0);
+    if ((threadIdx.x & 63) == 0) {
+        for (int d = 0; d < 3; ++d) {
+            s_lo[d][w] = lo[d];
+            s_hi[d][w] = hi[d];
+        }
+        s_live[w] = any != 0ull;
+    }
+    __syncthreads();
+    if (!(s_live[0] | s_live[1] | s_live[2] | s_live[3])) {
+        if (threadIdx.x == 0) supers[blockIdx.x] = make_float4(0.f, 0.f, 0.f, -1.f);
+        return;
+    }
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = fmin(fmin(s_lo[d][0], s_lo[d][1]), fmin(s_lo[d][2], s_lo[d][3]));
+        hi[d] = fmax(fmax(s_hi[d][0], s_hi[d][1]), fmax(s_hi[d][2], s_hi[d][3]));
+    }
+    float cx, cy, cz;
+    float4 s = sphere_of(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], cx, cy, cz);
+    double r2 = 0.0;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
+        float4 p = spos[k];
+        if (!(p.x == p.x)) continue;
+        double dx = (double)p.x - cx, dy = (double)p.y - cy, dz = (double)p.z - cz;
+        r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+    }
+    r2 = wave_max(r2);
+    if ((threadIdx.x & 63) == 0) s_r[w] = r2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s.w = radius_up(fmax(fmax(s_r[0], s_r[1]), fmax(s_r[2], s_r[3])));
+        supers[blockIdx.x] = s;
+    }
+}
+
+/* radius_search_inclusive membership: one bit per point (original order), one 64-bit word per wave */
+__global__ __launch_bounds__(256) void k_radius_mask(const float4* __restrict__ opos, uint32_t n, uint32_t center,
+                                                     float r2, unsigned long long* __restrict__ words) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const float4 c = opos[center];
+    bool in = false;
+    if (i < n) {
+        float4 p = opos[i];
+        in = len2(make3(p.x, p.y, p.z) - make3(c.x, c.y, c.z)) <= r2;
+    }
+    unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0) words[i >> 6] = b;
+}
+
+/* uploads the cloud and the two masks (original order) */
+int scene_upload(tm_scene* s) {
+    tm_ctx* c = s->ctx;
+    const uint32_t n = s->n;
+    TM_FORWARD(s->d_cloud.ensure((size_t)n * 12));
+    TM_FORWARD(s->d_tmask.ensure(n));
+    TM_FORWARD(s->d_mask.ensure(n));
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, s->h_cloud.data(), (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, s->h_tmask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    return TM_OK;
+}
+
+/* (re)derives every device array of the scene from d_cloud / d_tmask / d_mask. `resort` = the cloud
+ * changed (new scene); false = only mask_ changed. */
+int scene_build(tm_scene* s, bool resort) {
+    tm_ctx* c = s->ctx;
+    const uint32_t n = s->n;
+    const uint32_t n_pad = ((n + kScoreTile - 1) / kScoreTile) * kScoreTile;
+    const uint32_t n_tiles = n_pad / 64, n_super = (n_tiles + 63) / 64;
+    const dim3 blk(256), grid_n((n + 255) / 256);
+    TM_FORWARD(s->opos.ensure(n));
+    TM_FORWARD(s->otan.ensure(n));
+    TM_FORWARD(s->oref.ensure(n));
+    TM_FORWARD(s->d_bounds.ensure(sizeof(scene_bounds)));
+    TM_FORWARD(s->d_order.ensure(n));
+    TM_FORWARD(s->spos.ensure(n_pad));
+    TM_FORWARD(s->sref.ensure(n_pad));
+    TM_FORWARD(s->spos3.ensure((size_t)n_pad * 3));
+    TM_FORWARD(s->tiles.ensure(n_tiles));
+    TM_FORWARD(s->supers.ensure(n_super));
+    scene_bounds* bnd = reinterpret_cast<scene_bounds*>(s->d_bounds.p);
+    hipLaunchKernelGGL(k_scene_original, grid_n, blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p, s->d_mask.p, n,
+                       s->opos.p, s->otan.p, s->oref.p);
+    if (resort) {
+        scene_bounds init;
+        for (int d = 0; d < 3; ++d) {
+            init.lo[d] = ~0u;
+            init.hi[d] = 0u;
+        }
+        init.cmax = 0u;
+        init.live = 0u;
+        TM_HIP_CHECK(hipMemcpyAsync(bnd, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scene_bounds, dim3(std::min<uint32_t>(512u, (n + 255) / 256)), blk, 0, c->stream,
+                           s->d_cloud.p, n, bnd);
+        dbuf<unsigned long long> k_in, k_out;
+        dbuf<uint32_t> v_in;
+        auto cleanup = [&]() {
+            k_in.release();
+            k_out.release();
+            v_in.release();
+        };
+        int rc;
+        if ((rc = k_in.alloc(n)) || (rc = k_out.alloc(n)) || (rc = v_in.alloc(n))) {
+            cleanup();
+            return rc;
+        }
+        hipLaunchKernelGGL(k_scene_morton, grid_n, blk, 0, c->stream, s->d_cloud.p, n, bnd, k_in.p, v_in.p);
+        size_t tmp = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, k_in.p, k_out.p, v_in.p, s->d_order.p, (size_t)n, 0,
+                                                 64, c->stream);
+        if (e == hipSuccess && (rc = scratch_ensure(c, tmp))) {
+            cleanup();
+            return rc;
+        }
+        if (e == hipSuccess)
+            e = rocprim::radix_sort_pairs(c->scratch.p, tmp, k_in.p, k_out.p, v_in.p, s->d_order.p, (size_t)n, 0,
+                                          64, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        cleanup();
+        if (e != hipSuccess) {
+            set_error("scene_build: Morton sort failed: %s", hipGetErrorString(e));
+            return TM_ERR_HIP;
+        }
+    } else {
+        TM_HIP_CHECK(hipMemsetAsync(&bnd->live, 0, 4, c->stream));
+    }
+    hipLaunchKernelGGL(k_scene_gather, dim3(n_pad / 256), blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p,
+                       s->d_mask.p, s->d_order.p, n, n_pad, s->spos.p, s->spos3.p, s->sref.p, bnd);
+    hipLaunchKernelGGL(k_scene_tiles, dim3((n_tiles + 3) / 4), blk, 0, c->stream, s->spos.p, n_tiles, s->tiles.p);
+    hipLaunchKernelGGL(k_scene_supers, dim3(n_super), blk, 0, c->stream, s->spos.p, n_pad, s->supers.p);
+    TM_HIP_CHECK(hipGetLastError());
+    scene_bounds h;
+    TM_HIP_CHECK(hipMemcpyAsync(&h, bnd, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s->coord_max = h.cmax ? [&] {
+        float f;
+        memcpy(&f, &h.cmax, 4);
+        return f;
+    }() : 0.f;
+    s->n_live = h.live;
+    s->n_sorted = n_pad;
+    s->n_tiles = n_tiles;
+    return TM_OK;
+}
+
+}  // namespace tmx
+
+using namespace tmx;
+
+extern "C" int tm_scene_radius_subset(tm_scene* s, uint32_t center_idx, float radius, int32_t* out, uint32_t cap,
+                                      uint32_t* count) {
+    TM_REQUIRE(s && count, TM_ERR_INVALID, "tm_scene_radius_subset: null argument");
+    TM_REQUIRE(center_idx < s->n, TM_ERR_INVALID, "tm_scene_radius_subset: centre index out of range");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t n_words = (s->n + 63) / 64, n_blocks = (s->n + 255) / 256;
+    TM_FORWARD(s->w_words.ensure((size_t)n_blocks * 4));
+    hipLaunchKernelGGL(k_radius_mask, dim3(n_blocks), dim3(256), 0, c->stream, s->opos.p, s->n, center_idx,
+                       radius * radius, s->w_words.p);
+    TM_HIP_CHECK(hipGetLastError());
+    s->h_words.resize(n_words);
+    TM_HIP_CHECK(hipMemcpyAsync(s->h_words.data(), s->w_words.p, (size_t)n_words * 8, hipMemcpyDeviceToHost,
+                                c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    uint32_t k = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+        unsigned long long b = s->h_words[w];
+        while (b) {
+            const uint32_t i = w * 64u + (uint32_t)__builtin_ctzll(b);
+            if (out && k < cap) out[k] = (int32_t)i;
+            ++k;
+            b &= b - 1;
+        }
+    }
+    *count = k;
+    return TM_OK;
+}

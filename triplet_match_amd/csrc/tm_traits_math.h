@@ -1,6 +1,6 @@
 /*
  * tm_traits_math.h — projector math of the four traits plugins (identity / plane / plane2 /
- * cylinder), host + device. Replaces the statics of the reference's include/impl/*_traits.hpp.
+ * cylinder), host + device. Replaces the statics of the reference's include/impl/<kind>_traits.hpp.
  * state layout (TM_STATE_FLOATS = 37): [radius, threshold, origin xyz, g2l 16 col-major, l2g 16].
  */
 #ifndef TM_TRAITS_MATH_H_
