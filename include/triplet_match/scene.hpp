@@ -25,6 +25,7 @@ struct hip_backend {
     float diam;
     search::params_t p;
     std::vector<int32_t> nn_scratch; /* radius_subset output buffer, one slot per scene point */
+    std::vector<uint32_t> sc_scratch, mc_scratch; /* extract output buffers */
 
     uint32_t scene_size() const { return (uint32_t)scloud->size(); }
     uint32_t model_size() const { return (uint32_t)mcloud->size(); }
@@ -101,14 +102,14 @@ struct hip_backend {
     void extract(const search::pose_t& T, float dist_thres, search::candidate_t& out) {
         const uint32_t cap = (uint32_t)scloud->size();
         out.transform = T;
-        out.scene_corrs.resize(cap);
-        out.model_corrs.resize(cap);
+        sc_scratch.resize(cap);
+        mc_scratch.resize(cap);
         uint32_t count = 0;
-        check(tm_extract_correspondences(s, m, T.m, dist_thres, out.scene_corrs.data(), out.model_corrs.data(), cap,
-                                         &count, &out.signed_score),
+        check(tm_extract_correspondences(s, m, T.m, dist_thres, sc_scratch.data(), mc_scratch.data(), cap, &count,
+                                         &out.signed_score),
               "tm_extract_correspondences");
-        out.scene_corrs.resize(count);
-        out.model_corrs.resize(count);
+        out.scene_corrs.assign(sc_scratch.begin(), sc_scratch.begin() + count);
+        out.model_corrs.assign(mc_scratch.begin(), mc_scratch.begin() + count);
     }
     search::detail::icp_sums_t icp_sums(const search::pose_t& T, float dist_thres) {
         search::detail::icp_sums_t r;

@@ -174,6 +174,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
     tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
+    tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;
 };

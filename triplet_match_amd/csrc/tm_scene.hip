@@ -315,51 +315,86 @@ __global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
     }
 }
 
-/* finish_find + cross-covariance sums for ICP: one thread per sorted scene point; the 15 fixed-point sums
- * and the count are reduced per wave (shuffles) and added with integer atomics (order-free) */
+/* finish_find + cross-covariance sums for ICP. Grid-stride over the sorted scene points; the 15
+ * fixed-point sums and the count are integers, so thread-local accumulation, the wave shuffles, the LDS
+ * step and the final pass may add them in any order. Each block stores its 16 partials; k_icp_finalize
+ * adds the blocks (no atomics: sixteen same-line atomics per wave serialise in one L2 channel). */
+constexpr int kIcpBlocks = 512;
+
 __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n_pad,
-                                                        unsigned long long* __restrict__ sums /* 15 */) {
-    uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    long long acc[15];
+                                                        unsigned long long* __restrict__ partials /* [grid][16] */) {
+    __shared__ long long s_acc[4][16];
+    long long acc[16];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) acc[k] = 0;
-    uint32_t hit = 0;
-    if (s < n_pad) {
+    for (int k = 0; k < 16; ++k) acc[k] = 0;
+    const pose12 T = load_pose(a.poses);
+    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < n_pad; s += gridDim.x * 256) {
         float4 v = a.spos[s];
-        if (v.x == v.x) {
-            const pose12 T = load_pose(a.poses);
-            long long fx = 0;
-            uint32_t pass = 0, m = 0;
-            hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
-            if (hit) {
-                float4 mp = a.mpos[m];
-                const double sc[3] = {(double)v.x, (double)v.y, (double)v.z};
-                const double mc[3] = {(double)mp.x, (double)mp.y, (double)mp.z};
-                const double S = 4294967296.0;
+        if (!(v.x == v.x)) continue;
+        long long fx = 0;
+        uint32_t pass = 0, m = 0;
+        if (!eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m)) continue;
+        float4 mp = a.mpos[m];
+        const double sc[3] = {(double)v.x, (double)v.y, (double)v.z};
+        const double mc[3] = {(double)mp.x, (double)mp.y, (double)mp.z};
+        const double S = 4294967296.0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    acc[c] = (long long)(sc[c] * S);
-                    acc[3 + c] = (long long)(mc[c] * S);
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] = (long long)((sc[r] * mc[c]) * S);
-            }
+        for (int c = 0; c < 3; ++c) {
+            acc[c] += (long long)(sc[c] * S);
+            acc[3 + c] += (long long)(mc[c] * S);
         }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += (long long)((sc[r] * mc[c]) * S);
+        acc[15] += 1;
     }
-    if (__ballot(hit != 0)) {
 #pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
-        }
-        for (int off = 32; off > 0; off >>= 1) hit += __shfl_down(hit, off);
-        if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 16; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-            for (int k = 0; k < 15; ++k) atomicAdd(&sums[k], (unsigned long long)acc[k]);
-            atomicAdd(&a.counts[0], hit);
-        }
+        for (int k = 0; k < 16; ++k) s_acc[threadIdx.x >> 6][k] = acc[k];
     }
+    __syncthreads();
+    if (threadIdx.x < 16)
+        partials[(size_t)blockIdx.x * 16 + threadIdx.x] = (unsigned long long)(
+            s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
+                                                     unsigned long long* __restrict__ sums /* 16 */) {
+    if (threadIdx.x >= 16) return;
+    unsigned long long t = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) t += partials[(size_t)b * 16 + threadIdx.x];
+    sums[threadIdx.x] = t;
+}
+
+/* ordered compaction of k_extract's per-point matches: ascending scene index = the reference's scan
+ * order (finish_find walks 0..n-1, include/impl/scene.hpp:100-106). One wave per 64 original indices. */
+__global__ __launch_bounds__(256) void k_extract_count(const uint32_t* __restrict__ match_of_orig, uint32_t n,
+                                                       uint32_t* __restrict__ wave_count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool hit = i < n && match_of_orig[i] != 0xFFFFFFFFu;
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) wave_count[i >> 6] = (uint32_t)__popcll(b);
+}
+
+__global__ __launch_bounds__(256) void k_extract_scatter(const uint32_t* __restrict__ match_of_orig, uint32_t n,
+                                                         const uint32_t* __restrict__ wave_offset,
+                                                         const uint32_t* __restrict__ new2orig,
+                                                         uint32_t* __restrict__ scene_corrs,
+                                                         uint32_t* __restrict__ model_corrs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mt = i < n ? match_of_orig[i] : 0xFFFFFFFFu;
+    const bool hit = mt != 0xFFFFFFFFu;
+    const unsigned long long b = __ballot(hit);
+    if (!hit) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    const uint32_t dst = wave_offset[i >> 6] + rank;
+    scene_corrs[dst] = i;
+    model_corrs[dst] = new2orig[mt];
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -811,6 +846,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_stats.release();
     s->w_pairs.release();
     s->w_words.release();
+    s->w_corr.release();
     delete s;
     return TM_OK;
 }
@@ -1055,24 +1091,37 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     hipLaunchKernelGGL(k_extract, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_u32a.p);
     TM_HIP_CHECK(hipGetLastError());
-    std::vector<uint32_t> match(s->n);
+    /* ordered compaction on the device: only the correspondences travel back */
+    const uint32_t n_blocks = (s->n + 255) / 256, n_waves = n_blocks * 4;
+    TM_FORWARD(s->w_u32b.ensure((size_t)n_waves + 1));
+    TM_FORWARD(s->w_u32c.ensure((size_t)n_waves + 1));
+    TM_FORWARD(s->w_corr.ensure(2 * (size_t)s->n));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_u32b.p + n_waves, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_extract_count, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32b.p);
+    size_t tmp = 0;
+    TM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp, s->w_u32b.p, s->w_u32c.p, 0u, (size_t)n_waves + 1,
+                                         rocprim::plus<uint32_t>(), c->stream));
+    TM_FORWARD(scratch_ensure(c, tmp));
+    TM_HIP_CHECK(rocprim::exclusive_scan(c->scratch.p, tmp, s->w_u32b.p, s->w_u32c.p, 0u, (size_t)n_waves + 1,
+                                         rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_extract_scatter, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32c.p,
+                       m->new2orig.p, s->w_corr.p, s->w_corr.p + s->n);
+    TM_HIP_CHECK(hipGetLastError());
     unsigned long long fx = 0;
     uint32_t n_corr = 0;
-    TM_HIP_CHECK(hipMemcpyAsync(match.data(), s->w_u32a.p, (size_t)s->n * 4, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(&fx, s->w_scores_fx.p, 8, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(&n_corr, s->w_counts.p, 4, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     *count = n_corr;
     if (score) *score = ((double)fx * (1.0 / kFx)) / (double)m->n;
-    if (scene_corrs || model_corrs) {
+    if ((scene_corrs || model_corrs) && n_corr) {
         TM_REQUIRE(cap >= n_corr, TM_ERR_CAPACITY, "correspondence buffers too small");
-        uint32_t k = 0;
-        for (uint32_t i = 0; i < s->n; ++i) { /* ascending scene index = reference scan order */
-            if (match[i] == 0xFFFFFFFFu) continue;
-            if (scene_corrs) scene_corrs[k] = i;
-            if (model_corrs) model_corrs[k] = m->h_new2orig[match[i]];
-            ++k;
-        }
+        if (scene_corrs)
+            TM_HIP_CHECK(hipMemcpyAsync(scene_corrs, s->w_corr.p, (size_t)n_corr * 4, hipMemcpyDeviceToHost, c->stream));
+        if (model_corrs)
+            TM_HIP_CHECK(hipMemcpyAsync(model_corrs, s->w_corr.p + s->n, (size_t)n_corr * 4, hipMemcpyDeviceToHost,
+                                        c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return TM_OK;
 }
@@ -1086,10 +1135,9 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     TM_HIP_CHECK(hipSetDevice(c->device));
     TM_FORWARD(s->w_poses.ensure(16));
     TM_FORWARD(s->w_counts.ensure(1));
-    TM_FORWARD(s->w_scores_fx.ensure(16));
+    const uint32_t icp_blocks = std::min<uint32_t>((uint32_t)kIcpBlocks, s->n_sorted / 256);
+    TM_FORWARD(s->w_scores_fx.ensure(16 + (size_t)kIcpBlocks * 16));
     TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, 4, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, 16 * 8, c->stream));
     score_args a;
     a.spos = s->spos.p;
     a.spos3 = s->spos3.p;
@@ -1115,15 +1163,15 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     a.code_max = 255u;
-    hipLaunchKernelGGL(k_icp_accumulate, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
+    hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
+                       s->w_scores_fx.p + 16);
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(64), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
                        s->w_scores_fx.p);
     TM_HIP_CHECK(hipGetLastError());
-    unsigned long long h_sums[15];
-    uint32_t h_n = 0;
-    TM_HIP_CHECK(hipMemcpyAsync(h_sums, s->w_scores_fx.p, 15 * 8, hipMemcpyDeviceToHost, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(&h_n, s->w_counts.p, 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h_sums[16];
+    TM_HIP_CHECK(hipMemcpyAsync(h_sums, s->w_scores_fx.p, 16 * 8, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    *count = h_n;
+    *count = (uint32_t)h_sums[15];
     for (int k = 0; k < 15; ++k) sums15[k] = (long long)h_sums[k];
     return TM_OK;
 }
