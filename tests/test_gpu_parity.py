@@ -2,6 +2,8 @@
 the CPU oracle on the same seeded inputs. Bar: bit-exact for keys, hashes, table contents, voxel
 indices, inlier counts, correspondences and (here) poses; scores (fp64 sums of fp32 terms,
 order-free fixed-point accumulation on the GPU) to 1e-9 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -230,10 +232,18 @@ def test_early_drop_rule_bit_exact(gpu_small, oracle_small, small_case):
     rng = np.random.default_rng(1)
     sub_shuffled = sub.copy()
     rng.shuffle(sub_shuffled)
+    sub_dup = np.concatenate([sub_shuffled[:200], sub_shuffled[:50], sub_shuffled[200:]])  # points named twice
     n_dropped = n_kept = 0
-    for subset in (None, sub, sub_shuffled):
+    for subset in (None, sub, sub_shuffled, sub_dup):
         cg, sg, dg, vg = gpu_small["scene"].score_hypotheses_early_drop(
             gpu_small["model"], poses, DT, 0.5, subset=subset)
+        if subset is sub_shuffled:  # the tile-culled bit kernel and the one-thread-per-position kernel agree
+            os.environ["TM_ED_BRUTEFORCE"] = "1"
+            try:
+                ref = gpu_small["scene"].score_hypotheses_early_drop(gpu_small["model"], poses, DT, 0.5, subset=subset)
+            finally:
+                del os.environ["TM_ED_BRUTEFORCE"]
+            assert all(np.array_equal(x, y) for x, y in zip((cg, sg, dg, vg), ref))
         for h in range(len(poses)):
             sc, mc, score, saved = oracle_small["scene"].project(
                 oracle_small["model"], poses[h], 0.5, DT, subset=subset, early_out=True)

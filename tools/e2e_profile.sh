@@ -11,4 +11,4 @@ _fixture("/tmp/c2.bin", model_n=100000, scene_n=1000000, copies=4)
 PY
 g++ -std=c++17 -O2 -Iinclude tools/e2e_demo.cpp -o /tmp/e2e_demo -Ltriplet_match_amd -ltm_hip -Wl,-rpath,$PWD/triplet_match_amd
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/e2e_prof -o e2e -- /tmp/e2e_demo /tmp/c2.bin 0 10
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/e2e_prof -o e2e -- /tmp/e2e_demo /tmp/c2.bin ${1:-0} 10

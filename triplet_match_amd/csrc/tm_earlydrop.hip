@@ -5,8 +5,11 @@
  * The rule is sequential in the subset's scan order: checkpoint k is tested at the first unmasked,
  * in-grid point whose 1-based position is >= tests[k] (points that `continue` at :434 / :458-460
  * bypass the test), with the correspondence count up to and including that point. Three passes:
- *   1. k_ed_bits   one thread per (position, hypothesis): in-grid bit and correspondence bit,
- *                  packed with a wave ballot into 64-bit words (scan order = bit order);
+ *   1. k_ed_bits_culled  one workgroup per hypothesis walks the Morton-sorted scene, skips every tile whose
+ *                  sphere cannot reach the voxel box, and sets the in-grid bit and the correspondence
+ *                  bit of each remaining point at its position in the scan order (64-bit atomicOr;
+ *                  pos_of_orig maps a scene point to its position). Subsets that name a point twice
+ *                  take k_ed_bits instead: one thread per (position, hypothesis), wave ballots;
  *   2. k_ed_walk   one wave per hypothesis walks the words, finds each checkpoint's test position
  *                  and applies the hypergeometric bound (SURVEY Q8 positive form);
  *   3. k_ed_score  score terms of the correspondences up to the stop position.
@@ -18,6 +21,7 @@
 #include "tm_score.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace tmx {
@@ -54,6 +58,84 @@ __global__ __launch_bounds__(256) void k_ed_bits(ed_args a) {
     if ((threadIdx.x & 63) == 0 && pos < a.S) {
         a.tail_bits[(size_t)hl * a.words + pos / 64] = tb;
         a.corr_bits[(size_t)hl * a.words + pos / 64] = cb;
+    }
+}
+
+/* position of every scene point in the scan order (0xFFFFFFFF = not in the subset) */
+__global__ __launch_bounds__(256) void k_ed_positions(const int32_t* __restrict__ subset, uint32_t S,
+                                                      uint32_t* __restrict__ pos_of_orig) {
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos < S) pos_of_orig[subset ? (uint32_t)subset[pos] : pos] = pos;
+}
+/* a point named twice keeps only one of its positions: flag it */
+__global__ __launch_bounds__(256) void k_ed_check_positions(const int32_t* __restrict__ subset, uint32_t S,
+                                                            const uint32_t* __restrict__ pos_of_orig,
+                                                            uint32_t* __restrict__ duplicate) {
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos < S && pos_of_orig[(uint32_t)subset[pos]] != pos) *duplicate = 1u;
+}
+
+struct ed_cull {
+    const float4* spos;   /* Morton order, w = bits of the original index, x = NaN for masked / non-finite */
+    const float4* tiles;  /* sphere per 64 sorted points */
+    const float4* supers; /* sphere per 4096 sorted points */
+    const uint32_t* pos_of_orig;
+    uint32_t n_tiles;
+    float coord_max;
+};
+
+constexpr int kEdChunk = 4096; /* tiles per culling round = 64 super-tiles */
+
+__global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
+    __shared__ uint32_t s_list[kEdChunk];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_smask;
+    const uint32_t hl = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                              T.r22 * T.r22);
+    const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
+    unsigned long long* tb = a.tail_bits + (size_t)hl * a.words;
+    unsigned long long* cb = a.corr_bits + (size_t)hl * a.words;
+    for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kEdChunk) {
+        if (wave == 0) {
+            const uint32_t u = (t0 >> 6) + lane;
+            bool hit = false;
+            if (u * 64u < ca.n_tiles) hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.supers[u]);
+            unsigned long long mask = __ballot(hit);
+            if (lane == 0) {
+                s_smask = mask;
+                s_n = 0;
+            }
+        }
+        __syncthreads();
+        const unsigned long long smask = s_smask;
+        for (uint32_t r = wave; r < (uint32_t)(kEdChunk / 64); r += 4) {
+            if (!((smask >> r) & 1ull)) continue;
+            const uint32_t t = t0 + r * 64u + lane;
+            if (t < ca.n_tiles && sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.tiles[t])) s_list[atomicAdd(&s_n, 1u)] = t;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        for (uint32_t i = wave; i < n; i += 4) {
+            const uint32_t sidx = s_list[i] * 64u + lane;
+            const float4 P = ca.spos[sidx];
+            if (!(P.x == P.x)) continue; /* mask_ (:434), non-finite, padding */
+            const uint32_t pos = ca.pos_of_orig[__float_as_uint(P.w)];
+            if (pos == 0xFFFFFFFFu) continue;
+            long long fx = 0;
+            uint32_t pass = 0;
+            bool tail = false;
+            const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), sidx, fx, pass, nullptr, &tail);
+            if (tail) {
+                const unsigned long long bit = 1ull << (pos & 63u);
+                atomicOr(&tb[pos >> 6], bit);
+                if (corr) atomicOr(&cb[pos >> 6], bit);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -193,30 +275,20 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     const uint64_t budget = 256ull << 20; /* bytes per bit array */
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_hyp, budget / ((uint64_t)words * 8)));
     chunk = std::min(chunk, 65535u);
-    dbuf<float> d_poses;
-    dbuf<int32_t> d_subset, d_dropped;
-    dbuf<uint32_t> d_tests, d_counts, d_saved, d_limit;
-    dbuf<unsigned long long> d_tail, d_corr, d_fx;
+    /* buffers live on the scene and are reused across calls */
+    dbuf<float>& d_poses = s->w_poses;
+    dbuf<int32_t>&d_subset = s->ed_subset, &d_dropped = s->ed_dropped;
+    dbuf<uint32_t>&d_tests = s->ed_tests, &d_counts = s->w_counts, &d_saved = s->ed_saved, &d_limit = s->ed_limit,
+                  &d_pos = s->ed_pos;
+    dbuf<unsigned long long>&d_tail = s->ed_tail, &d_corr = s->ed_corr, &d_fx = s->w_scores_fx;
     int rc = TM_OK;
-    auto cleanup = [&]() {
-        d_poses.release();
-        d_subset.release();
-        d_dropped.release();
-        d_tests.release();
-        d_counts.release();
-        d_saved.release();
-        d_limit.release();
-        d_tail.release();
-        d_corr.release();
-        d_fx.release();
-    };
-    if ((rc = d_poses.alloc((size_t)n_hyp * 16)) || (rc = d_tests.alloc(18)) || (rc = d_counts.alloc(n_hyp)) ||
-        (rc = d_saved.alloc(n_hyp)) || (rc = d_limit.alloc(n_hyp)) || (rc = d_dropped.alloc(n_hyp)) ||
-        (rc = d_fx.alloc(n_hyp)) || (rc = d_tail.alloc((size_t)chunk * words)) ||
-        (rc = d_corr.alloc((size_t)chunk * words)) || (subset && (rc = d_subset.alloc(S)))) {
-        cleanup();
+    auto cleanup = [&]() {};
+    if ((rc = d_poses.ensure((size_t)n_hyp * 16)) || (rc = d_tests.ensure(20)) || (rc = d_counts.ensure(n_hyp)) ||
+        (rc = d_saved.ensure(n_hyp)) || (rc = d_limit.ensure(n_hyp)) || (rc = d_dropped.ensure(n_hyp)) ||
+        (rc = d_fx.ensure(n_hyp)) || (rc = d_tail.ensure((size_t)chunk * words)) ||
+        (rc = d_corr.ensure((size_t)chunk * words)) || (rc = d_pos.ensure(s->n)) ||
+        (subset && (rc = d_subset.ensure(S))))
         return rc;
-    }
 #define ED_HIP(expr)                                                      \
     do {                                                                  \
         hipError_t _e = (expr);                                           \
@@ -267,11 +339,42 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     o.saved = d_saved.p;
     o.limit = d_limit.p;
     const float accept_thresh = accept_prob * (float)m->n; /* accept_prob * size() in float */
+    /* scan position of every scene point; a subset that names a point twice (or TM_ED_BRUTEFORCE=1)
+     * takes the one-thread-per-position kernel */
+    bool culled = getenv("TM_ED_BRUTEFORCE") == nullptr;
+    if (culled) {
+        uint32_t dup = 0;
+        ED_HIP(hipMemsetAsync(d_pos.p, 0xFF, (size_t)s->n * 4, c->stream));
+        ED_HIP(hipMemsetAsync(d_tests.p + 18, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_ed_positions, dim3((S + 255) / 256), dim3(256), 0, c->stream, a.subset, S, d_pos.p);
+        if (subset) {
+            hipLaunchKernelGGL(k_ed_check_positions, dim3((S + 255) / 256), dim3(256), 0, c->stream, a.subset, S,
+                               d_pos.p, d_tests.p + 18);
+            ED_HIP(hipMemcpyAsync(&dup, d_tests.p + 18, 4, hipMemcpyDeviceToHost, c->stream));
+            ED_HIP(hipStreamSynchronize(c->stream));
+        }
+        culled = dup == 0;
+    }
+    ed_args ac = a; /* the culled kernel addresses scene points by their sorted slot */
+    ac.sc.sref = s->sref.p;
+    ed_cull cu;
+    cu.spos = s->spos.p;
+    cu.tiles = s->tiles.p;
+    cu.supers = s->supers.p;
+    cu.pos_of_orig = d_pos.p;
+    cu.n_tiles = s->n_tiles;
+    cu.coord_max = s->coord_max;
     for (uint32_t h0 = 0; h0 < n_hyp; h0 += chunk) {
         const uint32_t nh = std::min(chunk, n_hyp - h0);
-        a.h0 = h0;
+        a.h0 = ac.h0 = h0;
         dim3 grid((S + 255) / 256, nh);
-        hipLaunchKernelGGL(k_ed_bits, grid, dim3(256), 0, c->stream, a);
+        if (culled) {
+            ED_HIP(hipMemsetAsync(d_tail.p, 0, (size_t)nh * words * 8, c->stream));
+            ED_HIP(hipMemsetAsync(d_corr.p, 0, (size_t)nh * words * 8, c->stream));
+            hipLaunchKernelGGL(k_ed_bits_culled, dim3(nh), dim3(256), 0, c->stream, ac, cu);
+        } else {
+            hipLaunchKernelGGL(k_ed_bits, grid, dim3(256), 0, c->stream, a);
+        }
         ED_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_ed_walk, dim3(nh), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests.p);
         ED_HIP(hipGetLastError());

@@ -174,6 +174,10 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
     tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
+    /* early-drop path (tm_earlydrop.hip) */
+    tmx::dbuf<int32_t> ed_subset, ed_dropped;
+    tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
+    tmx::dbuf<unsigned long long> ed_tail, ed_corr;
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;

@@ -115,17 +115,6 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
     return true;
 }
 
-/* sphere vs voxel box only (super-tiles) */
-__device__ __forceinline__ bool sphere_hits_box(const score_args& a, const pose12& T, float rnorm,
-                                                float abs_eps, float4 tb) {
-    f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
-    float rho = tb.w * rnorm * 1.0001f + abs_eps;
-    float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
-    float mx = a.g.sx * rho + 0.05f, my = a.g.sy * rho + 0.05f, mz = a.g.sz * rho + 0.05f;
-    return (tb.w >= 0.f) & (vx + mx > -1.f) & (vx - mx < a.g.fex) & (vy + my > -1.f) & (vy - my < a.g.fey) &
-           (vz + mz > -1.f) & (vz - mz < a.g.fez);
-}
-
 __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
     __shared__ uint32_t s_list[kCullChunk];
     __shared__ uint32_t s_n;
@@ -847,6 +836,14 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_pairs.release();
     s->w_words.release();
     s->w_corr.release();
+    s->ed_subset.release();
+    s->ed_dropped.release();
+    s->ed_tests.release();
+    s->ed_saved.release();
+    s->ed_limit.release();
+    s->ed_pos.release();
+    s->ed_tail.release();
+    s->ed_corr.release();
     delete s;
     return TM_OK;
 }

@@ -81,6 +81,19 @@ __device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12
     return 1u;
 }
 
+/* Conservative culling test shared by the tile-culled kernels: can the sphere `tb` (centre xyz, radius w;
+ * w < 0 = empty) of scene points, moved by T, reach the model's voxel box at all? rnorm = Frobenius norm
+ * of the rotation block (bounds the stretch of a radius), abs_eps = absolute rounding slack. */
+__device__ __forceinline__ bool sphere_hits_box(const score_args& a, const pose12& T, float rnorm,
+                                                float abs_eps, float4 tb) {
+    f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
+    float rho = tb.w * rnorm * 1.0001f + abs_eps;
+    float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
+    float mx = a.g.sx * rho + 0.05f, my = a.g.sy * rho + 0.05f, mz = a.g.sz * rho + 0.05f;
+    return (tb.w >= 0.f) & (vx + mx > -1.f) & (vx - mx < a.g.fex) & (vy + my > -1.f) & (vy - my < a.g.fey) &
+           (vz + mz > -1.f) & (vz - mz < a.g.fez);
+}
+
 /* largest float t with sqrtf(t) <= thres (sqrtf is correctly rounded and monotone) */
 static inline float sq_threshold(float thres) {
     if (!(thres >= 0.f)) return -1.f;
