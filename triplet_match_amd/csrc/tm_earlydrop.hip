@@ -75,7 +75,20 @@ __global__ __launch_bounds__(256) void k_ed_check_positions(const int32_t* __res
     if (pos < S && pos_of_orig[(uint32_t)subset[pos]] != pos) *duplicate = 1u;
 }
 
+/* which tiles / super-tiles hold at least one live point of the subset (bit per tile in 64-bit words:
+ * word u = super-tile u) */
+__global__ __launch_bounds__(256) void k_ed_tile_active(const float4* __restrict__ spos,
+                                                        const uint32_t* __restrict__ pos_of_orig, uint32_t n_tiles,
+                                                        unsigned long long* __restrict__ tile_bits) {
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const float4 P = spos[(size_t)t * 64 + (threadIdx.x & 63)];
+    const bool in = (P.x == P.x) && pos_of_orig[__float_as_uint(P.w)] != 0xFFFFFFFFu;
+    if (__ballot(in) && (threadIdx.x & 63) == 0) atomicOr(&tile_bits[t >> 6], 1ull << (t & 63u));
+}
+
 struct ed_cull {
+    const unsigned long long* tile_bits; /* per super-tile: which of its 64 tiles hold subset points */
     const float4* spos;   /* Morton order, w = bits of the original index, x = NaN for masked / non-finite */
     const float4* tiles;  /* sphere per 64 sorted points */
     const float4* supers; /* sphere per 4096 sorted points */
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
         if (wave == 0) {
             const uint32_t u = (t0 >> 6) + lane;
             bool hit = false;
-            if (u * 64u < ca.n_tiles) hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.supers[u]);
+            if (u * 64u < ca.n_tiles && ca.tile_bits[u]) hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.supers[u]);
             unsigned long long mask = __ballot(hit);
             if (lane == 0) {
                 s_smask = mask;
@@ -115,7 +128,9 @@ __global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
         for (uint32_t r = wave; r < (uint32_t)(kEdChunk / 64); r += 4) {
             if (!((smask >> r) & 1ull)) continue;
             const uint32_t t = t0 + r * 64u + lane;
-            if (t < ca.n_tiles && sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.tiles[t])) s_list[atomicAdd(&s_n, 1u)] = t;
+            if (t < ca.n_tiles && ((ca.tile_bits[t >> 6] >> lane) & 1ull) &&
+                sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.tiles[t]))
+                s_list[atomicAdd(&s_n, 1u)] = t;
         }
         __syncthreads();
         const uint32_t n = s_n;
@@ -286,7 +301,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     if ((rc = d_poses.ensure((size_t)n_hyp * 16)) || (rc = d_tests.ensure(20)) || (rc = d_counts.ensure(n_hyp)) ||
         (rc = d_saved.ensure(n_hyp)) || (rc = d_limit.ensure(n_hyp)) || (rc = d_dropped.ensure(n_hyp)) ||
         (rc = d_fx.ensure(n_hyp)) || (rc = d_tail.ensure((size_t)chunk * words)) ||
-        (rc = d_corr.ensure((size_t)chunk * words)) || (rc = d_pos.ensure(s->n)) ||
+        (rc = d_corr.ensure((size_t)chunk * words)) || (rc = d_pos.ensure(s->n)) || (rc = s->ed_tilebits.ensure((s->n_tiles + 63) / 64)) ||
         (subset && (rc = d_subset.ensure(S))))
         return rc;
 #define ED_HIP(expr)                                                      \
@@ -362,6 +377,13 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     cu.tiles = s->tiles.p;
     cu.supers = s->supers.p;
     cu.pos_of_orig = d_pos.p;
+    cu.tile_bits = s->ed_tilebits.p;
+    if (culled) {
+        const uint32_t n_super = (s->n_tiles + 63) / 64;
+        ED_HIP(hipMemsetAsync(s->ed_tilebits.p, 0, (size_t)n_super * 8, c->stream));
+        hipLaunchKernelGGL(k_ed_tile_active, dim3((s->n_tiles + 3) / 4), dim3(256), 0, c->stream, s->spos.p, d_pos.p,
+                           s->n_tiles, s->ed_tilebits.p);
+    }
     cu.n_tiles = s->n_tiles;
     cu.coord_max = s->coord_max;
     for (uint32_t h0 = 0; h0 < n_hyp; h0 += chunk) {

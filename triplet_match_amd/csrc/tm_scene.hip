@@ -351,12 +351,19 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n
             s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
 }
 
-__global__ __launch_bounds__(64) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
-                                                     unsigned long long* __restrict__ sums /* 16 */) {
-    if (threadIdx.x >= 16) return;
+__global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
+                                                      unsigned long long* __restrict__ sums /* 16 */) {
+    __shared__ unsigned long long s_part[16][16];
+    const uint32_t k = threadIdx.x & 15, slice = threadIdx.x >> 4; /* 16 slices of the block list */
     unsigned long long t = 0;
-    for (uint32_t b = 0; b < n_blocks; ++b) t += partials[(size_t)b * 16 + threadIdx.x];
-    sums[threadIdx.x] = t;
+    for (uint32_t b = slice; b < n_blocks; b += 16) t += partials[(size_t)b * 16 + k];
+    s_part[slice][k] = t;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        unsigned long long r = 0;
+        for (int sl = 0; sl < 16; ++sl) r += s_part[sl][threadIdx.x];
+        sums[threadIdx.x] = r;
+    }
 }
 
 /* ordered compaction of k_extract's per-point matches: ascending scene index = the reference's scan
@@ -844,6 +851,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->ed_pos.release();
     s->ed_tail.release();
     s->ed_corr.release();
+    s->ed_tilebits.release();
     delete s;
     return TM_OK;
 }
@@ -1162,7 +1170,7 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     a.code_max = 255u;
     hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_scores_fx.p + 16);
-    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(64), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
                        s->w_scores_fx.p);
     TM_HIP_CHECK(hipGetLastError());
     unsigned long long h_sums[16];
