@@ -265,6 +265,17 @@ float tm_traits_intrinsic_distance(int kind, const float* state, const float p0[
 int tm_traits_project_cloud(tm_ctx* ctx, int kind, const float* state, const float* surfels,
                             uint32_t n, float* uvw_surfels, int32_t* valid);
 
+/* The same projection kept on the device: a new scene whose points are the uvw images of `src`'s points
+ * under the projector (traits_kind, state) — positions = project(), tangent / normal = traits tangent() /
+ * normal(), tangent_mask = |projected tangent| > 0.7 (include/impl/scene.hpp:49-52), mask_ inherited; points
+ * whose project() is nullopt never take part. Indices are those of `src`. This is the per-projector step
+ * of the traits search (model<Proj,Point> / scene<Proj,Point>, include/impl/cylinder_traits.hpp:92-107,
+ * include/impl/plane2_traits.hpp:70-84): one pass over the cloud in HBM, then the identity kernels run
+ * on the result with the model's metric (tm_model_set_metric). */
+int tm_scene_create_projected(tm_scene* src, int traits_kind, const float* state, tm_scene** out);
+/* the surfels of a scene as the kernels see them (uvw surfels for a projected scene) and its tangent_mask */
+int tm_scene_download(const tm_scene* scene, float* surfels, int32_t* tangent_mask);
+
 /* ---- HIP equivalents of the reference's orphaned OpenCL kernels (opencl/icp.cl, cylinder.cl) ----
  * icp_projection (opencl/icp.cl:1-53, with uv_project opencl/cylinder.cl:1-25 and mat44_multiply
  * opencl/util.cl:1-9): per scene point align -> cylinder unroll -> normalise -> pixel lookup in the

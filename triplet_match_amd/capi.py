@@ -80,6 +80,8 @@ SIGNATURES = {
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
+    "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
+    "tm_scene_download": (C.c_int, [vp, f32p, i32p]),
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
@@ -479,6 +481,21 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+    def project(self, kind, state):
+        """Device-resident uvw scene of a projector (tm_scene_create_projected); indices are this scene's."""
+        st, pst = _f(state)
+        h = vp()
+        _check(lib().tm_scene_create_projected(self.h, kind, pst, C.byref(h)))
+        out = Scene.__new__(Scene)
+        out.ctx, out.n, out.h = self.ctx, self.n, h
+        return out
+
+    def download(self):
+        s = np.zeros((self.n, 12), np.float32)
+        tm = np.zeros(self.n, np.int32)
+        _check(lib().tm_scene_download(self.h, s.ctypes.data_as(f32p), tm.ctypes.data_as(i32p)))
+        return s, tm
 
     def set_mask(self, mask):
         if mask is None:

@@ -1,6 +1,10 @@
 /* tm_core.hip — context, error text, host-side scalar API and the batched descriptor kernel. */
 #include "tm_internal.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <set>
+
 namespace tmx {
 
 static thread_local std::string g_error;
@@ -46,6 +50,26 @@ extern "C" {
 const char* tm_last_error(void) { return g_error.c_str(); }
 const char* tm_version(void) { return "triplet_match_amd 0.1 (gfx950)"; }
 
+}  // extern "C"
+
+namespace tmx {
+/* live contexts: a model / scene destroyed after its context (garbage collection in arbitrary order at
+ * interpreter exit) must not touch the freed context or the runtime */
+static std::mutex g_ctx_mutex;
+static std::set<tm_ctx*> g_ctx_live;
+static bool g_exiting = false;
+bool ctx_alive(tm_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    return !g_exiting && g_ctx_live.count(c) != 0;
+}
+static void mark_exit() {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    g_exiting = true;
+}
+}  // namespace tmx
+
+extern "C" {
+
 int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_REQUIRE(out, TM_ERR_INVALID, "tm_ctx_create: null output");
     *out = nullptr;
@@ -66,12 +90,25 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_FORWARD(c->stats.alloc(16));
     c->ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
     c->debug_stats = getenv("TM_DEBUG_STATS") != nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        static bool registered = false;
+        if (!registered) {
+            atexit(mark_exit);
+            registered = true;
+        }
+        g_ctx_live.insert(c);
+    }
     *out = c;
     return TM_OK;
 }
 
 int tm_ctx_destroy(tm_ctx* c) {
-    if (!c) return TM_OK;
+    if (!c || !ctx_alive(c)) return TM_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        g_ctx_live.erase(c);
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->scratch.release();

@@ -185,6 +185,8 @@ struct tm_scene {
 
 namespace tmx {
 int scratch_ensure(tm_ctx* ctx, size_t bytes);
+/* false once the context was destroyed or the process is exiting: destroy calls then free host memory only */
+bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
 int scene_upload(tm_scene* s);
 int scene_build(tm_scene* s, bool resort);

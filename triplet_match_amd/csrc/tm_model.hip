@@ -921,6 +921,10 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
 
 int tm_model_destroy(tm_model* m) {
     if (!m) return TM_OK;
+    if (!ctx_alive(m->ctx)) { /* context already gone: the device memory went with it */
+        delete m;
+        return TM_OK;
+    }
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     m->pos.release();

@@ -817,6 +817,10 @@ int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t
 
 int tm_scene_destroy(tm_scene* s) {
     if (!s) return TM_OK;
+    if (!ctx_alive(s->ctx)) { /* context already gone: the device memory went with it */
+        delete s;
+        return TM_OK;
+    }
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     s->d_cloud.release();
@@ -869,6 +873,13 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
 }
 
 uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
+
+int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) {
+    TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
+    if (surfels) memcpy(surfels, s->h_cloud.data(), (size_t)s->n * 48);
+    if (tangent_mask) memcpy(tangent_mask, s->h_tmask.data(), (size_t)s->n * 4);
+    return TM_OK;
+}
 
 int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, uint32_t j, float minf,
                             float maxf) {

@@ -39,6 +39,21 @@ __global__ void k_project_cloud(int kind, const float* __restrict__ state, const
     valid[t] = 1;
 }
 
+/* turns k_project_cloud's output into the inputs of a scene: points whose project() is nullopt get a NaN
+ * x (they never take part), tangent_mask = valid && |traits tangent| > 0.7 (the reference's tangent test,
+ * include/impl/scene.hpp:49-52, on the projected tangent), mask_ is inherited */
+__global__ __launch_bounds__(256) void k_projected_masks(float* __restrict__ cloud, const int32_t* __restrict__ valid,
+                                                         const int32_t* __restrict__ src_mask, uint32_t n,
+                                                         int32_t* __restrict__ tmask, int32_t* __restrict__ mask) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float* o = cloud + (size_t)i * 12;
+    const bool ok = valid[i] != 0;
+    if (!ok) o[0] = __builtin_nanf("");
+    tmask[i] = (ok && len(make3(o[9], o[10], o[11])) > 0.7f) ? 1 : 0;
+    mask[i] = src_mask[i];
+}
+
 /* column-major 4x4 * float4, left-to-right sum like opencl/util.cl:4-7 */
 __device__ __forceinline__ float4 cl_mat44(float4 p, const float* __restrict__ m) {
     return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * p.w,
@@ -226,6 +241,55 @@ int tm_traits_project_cloud(tm_ctx* c, int kind, const float* state, const float
         set_error("tm_traits_project_cloud: %s", hipGetErrorString(e));
         return TM_ERR_HIP;
     }
+    return TM_OK;
+}
+
+int tm_scene_create_projected(tm_scene* src, int kind, const float* state, tm_scene** out) {
+    TM_REQUIRE(src && state && out, TM_ERR_INVALID, "tm_scene_create_projected: null argument");
+    TM_REQUIRE(kind >= 0 && kind <= 3, TM_ERR_INVALID, "bad traits kind");
+    tm_ctx* c = src->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t n = src->n;
+    tm_scene* t = new tm_scene();
+    t->ctx = c;
+    t->n = n;
+    dbuf<float> d_state;
+    dbuf<int32_t> d_valid;
+    int rc = TM_OK;
+    hipError_t e = hipSuccess;
+    if ((rc = d_state.alloc(TM_STATE_FLOATS)) || (rc = d_valid.alloc(n)) || (rc = t->d_cloud.ensure((size_t)n * 12)) ||
+        (rc = t->d_tmask.ensure(n)) || (rc = t->d_mask.ensure(n))) {
+    } else {
+        e = hipMemcpyAsync(d_state.p, state, TM_STATE_FLOATS * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_project_cloud, dim3((n + 255) / 256), dim3(256), 0, c->stream, kind, d_state.p,
+                               src->d_cloud.p, n, t->d_cloud.p, d_valid.p);
+            hipLaunchKernelGGL(k_projected_masks, dim3((n + 255) / 256), dim3(256), 0, c->stream, t->d_cloud.p,
+                               d_valid.p, src->d_mask.p, n, t->d_tmask.p, t->d_mask.p);
+            e = hipGetLastError();
+        }
+        /* host mirrors (sample filters, subset bookkeeping) */
+        t->h_cloud.resize((size_t)n * 12);
+        t->h_tmask.resize(n);
+        t->h_mask = src->h_mask;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(t->h_cloud.data(), t->d_cloud.p, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(t->h_tmask.data(), t->d_tmask.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            set_error("tm_scene_create_projected: %s", hipGetErrorString(e));
+            rc = TM_ERR_HIP;
+        }
+    }
+    d_state.release();
+    d_valid.release();
+    if (!rc) rc = scene_build(t, true);
+    if (rc) {
+        tm_scene_destroy(t);
+        return rc;
+    }
+    *out = t;
     return TM_OK;
 }
 

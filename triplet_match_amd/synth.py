@@ -260,3 +260,231 @@ def sample_scene_pairs(scene, model_diameter, n_first, per_first, seed=13,
         for b in nb[:per_first]:
             out.append((tidx[a], tidx[b]))
     return np.array(out, dtype=np.uint32).reshape(-1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs 3 / 4 of BASELINE.json: scenes for the projector traits (cylinder, plane2)
+# ---------------------------------------------------------------------------------------------
+def _frame(axis):
+    """right-handed orthonormal frame (x, y, axis) for a unit axis"""
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.linalg.norm(axis)
+    h = np.array([1.0, 0, 0]) if abs(axis[0]) < 0.9 else np.array([0, 1.0, 0])
+    x = np.cross(h, axis)
+    x /= np.linalg.norm(x)
+    return x, np.cross(axis, x), axis
+
+
+def _pipe_pattern(theta, h, radius, spacing):
+    """Tangent kind per point of a pipe section of height 2 (theta in [0, 2pi), h in [0, 2]):
+    0 = none, 1 = axial seam, 2 = flange ring. Asymmetric, so the in-surface pose is unique."""
+    w_arc = max(0.04, 1.5 * spacing)  # half width of a band, arc length / height units
+    d1 = np.abs(np.angle(np.exp(1j * (theta - 1.0)))) * radius
+    d2 = np.abs(np.angle(np.exp(1j * (theta - 4.0)))) * radius
+    seam = (d1 < w_arc) | ((d2 < w_arc) & (h < 1.2))
+    ring = (np.abs(h - 0.6) < w_arc) | (np.abs(h - 1.5) < 0.6 * w_arc)
+    kind = np.zeros(theta.shape, np.int32)
+    kind[ring] = 2
+    kind[seam] = 1
+    return kind
+
+
+def _pipe_points(rng, n, radius, length, origin, axis, spacing, instances=(), decoy_seam=None):
+    """n surfels on a pipe; `instances` = [(h0, theta0)] planted model sections of height 2."""
+    x, y, z = _frame(axis)
+    theta = rng.random(n) * 2 * np.pi
+    h = rng.random(n) * length
+    radial = np.cos(theta)[:, None] * x + np.sin(theta)[:, None] * y
+    pos = np.asarray(origin) + radius * radial + h[:, None] * z
+    nrm = -radial  # inward, as the cylinder projector's init_from_samples expects
+    circ = -np.sin(theta)[:, None] * x + np.cos(theta)[:, None] * y
+    tgt = np.zeros((n, 3))
+    inst = np.full(n, -1, np.int32)
+    for k, (h0, t0) in enumerate(instances):
+        sel = (h >= h0) & (h <= h0 + 2.0)
+        kind = _pipe_pattern(np.mod(theta[sel] - t0, 2 * np.pi), h[sel] - h0, radius, spacing)
+        idx = np.nonzero(sel)[0]
+        tgt[idx[kind == 1]] = z
+        tgt[idx[kind == 2]] = circ[idx[kind == 2]]
+        inst[idx] = k
+    if decoy_seam is not None:
+        d = np.abs(np.angle(np.exp(1j * (theta - decoy_seam)))) * radius
+        sel = (d < max(0.04, 1.5 * spacing)) & (inst < 0)
+        tgt[sel] = z
+    return pos, nrm, tgt, inst, theta, h
+
+
+def synth_pipe_section(n, seed=3, radius=0.5):
+    """Model of config 3: a pipe section (axis +z through the origin, height 2) with two axial seams and
+    two flange rings carrying tangents. Returns (surfels, tangent subset)."""
+    rng = np.random.default_rng(seed)
+    spacing = np.sqrt(2 * np.pi * radius * 2.0 / n)
+    pos, nrm, tgt, _, _, _ = _pipe_points(rng, n, radius, 2.0, np.zeros(3), [0, 0, 1.0], spacing, instances=[(0.0, 0.0)])
+    s = _pack(pos, nrm, tgt)
+    return s, np.nonzero(np.linalg.norm(s[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+
+
+def synth_pipe_plant(n, model_n, seed=4, radius=0.5, noise_sigma=0.0):
+    """Scene of config 3: axis-aligned pipe runs of three radii; each run of the model's radius carries one
+    planted section (known offset along and around the pipe); floor clutter + uniform outliers.
+
+    Returns dict(surfels, tangent_mask, instance_id (planted section or -1), pipe_id (-1 = clutter),
+    pipes = [(origin, axis, radius, length)], instances = [(pipe, h0, theta0)])."""
+    rng = np.random.default_rng(seed)
+    dens = model_n / (2 * np.pi * radius * 2.0)
+    spacing = 1.0 / np.sqrt(dens)
+    pipes = [  # origin, axis, radius, length, planted (h0, theta0) or None, decoy seam angle or None
+        (np.array([0.0, 0.0, 1.0]), [1.0, 0, 0], radius, 4.0, (1.1, 0.7), 2.6),
+        (np.array([5.0, 1.0, 1.5]), [0, 1.0, 0], radius, 4.0, (0.4, 3.9), None),
+        (np.array([2.0, 6.0, 0.0]), [0, 0, 1.0], radius, 4.0, (1.7, 5.5), 0.3),
+        (np.array([0.0, 3.0, 2.0]), [1.0, 0, 0], 0.6 * radius, 4.0, None, 1.0),
+        (np.array([7.0, 0.0, 0.5]), [0, 1.0, 0], 1.6 * radius, 3.0, None, 4.4),
+    ]
+    areas = np.array([2 * np.pi * p[2] * p[3] for p in pipes])
+    scale = min(1.0, 0.9 * n / (dens * areas.sum()))
+    pos_l, nrm_l, tgt_l, inst_l, pipe_l, instances = [], [], [], [], [], []
+    for k, (o, ax, r, L, planted, decoy) in enumerate(pipes):
+        cnt = int(dens * scale * 2 * np.pi * r * L)
+        inst_list = []
+        if planted is not None:
+            inst_list = [planted]
+        p, nn, tt, ii, _, _ = _pipe_points(rng, cnt, r, L, o, ax, spacing / np.sqrt(scale), inst_list, decoy)
+        if planted is not None:
+            ii[ii == 0] = len(instances)
+            instances.append((k, planted[0], planted[1]))
+        pos_l.append(p)
+        nrm_l.append(nn)
+        tgt_l.append(tt)
+        inst_l.append(ii)
+        pipe_l.append(np.full(cnt, k, np.int32))
+    used = sum(len(p) for p in pos_l)
+    n_out = int(0.02 * n)
+    n_floor = n - used - n_out
+    pf = np.stack([rng.random(n_floor) * 9 - 1, rng.random(n_floor) * 8 - 1, np.full(n_floor, -0.8)], 1)
+    pos_l.append(pf)
+    nrm_l.append(np.tile([0, 0, 1.0], (n_floor, 1)))
+    tgt_l.append(np.zeros((n_floor, 3)))
+    po = rng.random((n_out, 3)) * [9, 8, 5] - [1, 1, 0.8]
+    no = rng.normal(size=(n_out, 3))
+    no /= np.linalg.norm(no, axis=1, keepdims=True)
+    pos_l.append(po)
+    nrm_l.append(no)
+    tgt_l.append(np.zeros((n_out, 3)))
+    for m in (n_floor, n_out):
+        inst_l.append(np.full(m, -1, np.int32))
+        pipe_l.append(np.full(m, -1, np.int32))
+    pos, nrm, tgt = np.concatenate(pos_l), np.concatenate(nrm_l), np.concatenate(tgt_l)
+    inst, pipe = np.concatenate(inst_l), np.concatenate(pipe_l)
+    if noise_sigma > 0:
+        pos = pos + rng.normal(size=pos.shape) * noise_sigma
+    perm = rng.permutation(n)
+    s = _pack(pos[perm], nrm[perm], tgt[perm])
+    tmask = (np.linalg.norm(s[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    return dict(surfels=s, tangent_mask=tmask, instance_id=inst[perm], pipe_id=pipe[perm],
+                pipes=[(p[0], np.asarray(p[1], np.float64), p[2], p[3]) for p in pipes], instances=instances)
+
+
+def _panel_pattern(u, v, spacing):
+    """Tangent kind of a 2.0 x 1.0 wall panel (window frame): 0 none, 1 edge along u, 2 edge along v."""
+    w = max(0.02, 1.5 * spacing)
+    along_u = (v < w) | (v > 1.0 - w) | (np.abs(v - 0.3) < 0.6 * w)
+    along_v = (u < w) | (u > 2.0 - w) | (np.abs(u - 1.2) < w)
+    kind = np.zeros(u.shape, np.int32)
+    kind[along_u] = 1
+    kind[along_v & ~along_u] = 2
+    return kind
+
+
+def synth_wall_panel(n, seed=5, z_sigma=0.002):
+    """Model of config 4: a 2 x 1 planar panel in the xy-plane (normal +z) with frame, mullion and sill edges.
+    A little depth noise keeps the voxel grid's w axis non-degenerate (a zero range would make every w
+    land in the grid, i.e. the whole room would count under the 2-D metric)."""
+    rng = np.random.default_rng(seed)
+    spacing = np.sqrt(2.0 / n)
+    u, v = rng.random(n) * 2.0, rng.random(n)
+    kind = _panel_pattern(u, v, spacing)
+    pos = np.stack([u, v, rng.normal(size=n) * z_sigma], 1)
+    tgt = np.zeros((n, 3))
+    tgt[kind == 1] = [1.0, 0, 0]
+    tgt[kind == 2] = [0, 1.0, 0]
+    s = _pack(pos, np.tile([0, 0, 1.0], (n, 1)), tgt)
+    return s, np.nonzero(kind > 0)[0].astype(np.uint32)
+
+
+def synth_indoor(n, model_n, seed=6, noise_sigma=0.0):
+    """Scene of config 4: a room (floor + 4 walls, 8 x 6 x 3) sampled at the model's density; three walls
+    carry one planted panel each (in-plane rotation and offset known); door-frame decoy edges elsewhere.
+
+    Returns dict(surfels, tangent_mask, instance_id, wall_id, walls = [(origin, a, b, normal)],
+    instances = [(wall, u0, v0, angle)])."""
+    rng = np.random.default_rng(seed)
+    dens = model_n / 2.0
+    X, Y, Z = 8.0, 6.0, 3.0
+    walls = [  # origin, a (u direction), b (v direction): normal = a x b
+        (np.zeros(3), np.array([X, 0, 0]), np.array([0, 0, Z])),             # y = 0
+        (np.array([X, 0, 0]), np.array([0, Y, 0]), np.array([0, 0, Z])),     # x = X
+        (np.array([X, Y, 0]), np.array([-X, 0, 0]), np.array([0, 0, Z])),    # y = Y
+        (np.array([0, Y, 0]), np.array([0, -Y, 0]), np.array([0, 0, Z])),    # x = 0
+        (np.zeros(3), np.array([0, Y, 0]), np.array([X, 0, 0])),             # floor, normal +z... (a x b = -z)
+    ]
+    planted = {0: (2.5, 0.9, 0.0), 1: (2.5, 0.5, np.pi / 2), 2: (4.0, 0.6, 0.35)}  # u0, v0, in-plane angle
+    areas = np.array([np.linalg.norm(np.cross(a, b)) for (_, a, b) in walls])
+    scale = min(1.0, 0.97 * n / (dens * areas.sum()))
+    spacing = 1.0 / np.sqrt(dens * scale)
+    pos_l, nrm_l, tgt_l, inst_l, wall_l, instances, wall_out = [], [], [], [], [], [], []
+    for k, (o, a, b) in enumerate(walls):
+        cnt = int(dens * scale * areas[k])
+        la, lb = np.linalg.norm(a), np.linalg.norm(b)
+        ea, eb = a / la, b / lb
+        nrm = np.cross(ea, eb)
+        u, v = rng.random(cnt) * la, rng.random(cnt) * lb
+        pos = o + u[:, None] * ea + v[:, None] * eb
+        tgt = np.zeros((cnt, 3))
+        inst = np.full(cnt, -1, np.int32)
+        if k in planted:
+            u0, v0, ang = planted[k]
+            c, s_ = np.cos(ang), np.sin(ang)
+            pu = c * (u - u0) + s_ * (v - v0)   # panel coordinates of the wall point
+            pv = -s_ * (u - u0) + c * (v - v0)
+            sel = (pu >= 0) & (pu <= 2.0) & (pv >= 0) & (pv <= 1.0)
+            kind = _panel_pattern(pu[sel], pv[sel], spacing)
+            idx = np.nonzero(sel)[0]
+            du = c * ea + s_ * eb      # panel u / v directions in the world
+            dv = -s_ * ea + c * eb
+            tgt[idx[kind == 1]] = du
+            tgt[idx[kind == 2]] = dv
+            inst[idx] = len(instances)
+            instances.append((k, u0, v0, ang))
+        # decoy: a door frame (two verticals + lintel) on every wall, outside the panel
+        if k < 4:
+            w = max(0.02, 1.5 * spacing)
+            du0 = 0.6 if k not in planted else la - 1.4
+            door_v = ((np.abs(u - du0) < w) | (np.abs(u - du0 - 0.9) < w)) & (v < 2.1) & (inst < 0)
+            door_h = (np.abs(v - 2.1) < w) & (u > du0) & (u < du0 + 0.9) & (inst < 0)
+            tgt[door_v] = eb
+            tgt[door_h] = ea
+        pos_l.append(pos)
+        nrm_l.append(np.tile(nrm, (cnt, 1)))
+        tgt_l.append(tgt)
+        inst_l.append(inst)
+        wall_l.append(np.full(cnt, k, np.int32))
+        wall_out.append((o, a, b, nrm))
+    used = sum(len(p) for p in pos_l)
+    n_out = n - used
+    po = rng.random((n_out, 3)) * [X, Y, Z]
+    no = rng.normal(size=(n_out, 3))
+    no /= np.linalg.norm(no, axis=1, keepdims=True)
+    pos_l.append(po)
+    nrm_l.append(no)
+    tgt_l.append(np.zeros((n_out, 3)))
+    inst_l.append(np.full(n_out, -1, np.int32))
+    wall_l.append(np.full(n_out, -1, np.int32))
+    pos, nrm, tgt = np.concatenate(pos_l), np.concatenate(nrm_l), np.concatenate(tgt_l)
+    inst, wall = np.concatenate(inst_l), np.concatenate(wall_l)
+    if noise_sigma > 0:
+        pos = pos + rng.normal(size=pos.shape) * noise_sigma
+    perm = rng.permutation(n)
+    s = _pack(pos[perm], nrm[perm], tgt[perm])
+    tmask = (np.linalg.norm(s[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    return dict(surfels=s, tangent_mask=tmask, instance_id=inst[perm], wall_id=wall[perm], walls=wall_out,
+                instances=instances)
