@@ -84,3 +84,81 @@ def test_shard_is_a_partition():
         for r, s in enumerate(shards):
             merged[r::world] = s
         assert np.array_equal(merged, pairs)
+
+
+def _worker_multi(rank, world, port, out_dir, n_models):
+    """config 5 wiring: n_models models x sample pairs on a Wm x Wp grid, per-model best reduce"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from oracle import tmo
+    from triplet_match_amd import build as tm_build
+    from triplet_match_amd import dist as tmd
+    from triplet_match_amd import synth
+    tm_build.build()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scales = [(1.0, 1.0, 1.0), (0.7, 1.3, 1.1), (1.2, 0.8, 0.9)][:n_models]
+    clouds = []
+    for k, sc in enumerate(scales):
+        M, sub = synth.synth_model(900, seed=1 + k, scale=sc)
+        clouds.append((M, sub, synth.resolution(M)))
+    # one scene holding an instance of every model
+    rng = np.random.default_rng(5)
+    parts = []
+    for k, (M, sub, res) in enumerate(clouds):
+        inst, _ = synth.synth_model(900, seed=50 + k, scale=scales[k])
+        R = synth.random_rotation(rng)
+        t = np.array([3.0 * k, 1.0, 0.5])
+        inst[:, 0:3] = inst[:, 0:3] @ R.T + t
+        inst[:, 4:7] = inst[:, 4:7] @ R.T
+        inst[:, 9:12] = inst[:, 9:12] @ R.T
+        parts.append(inst)
+    surf = np.concatenate(parts).astype(np.float32)
+    tmask = (np.linalg.norm(surf[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    s = tmo.Scene(surf, tmask)
+    recs, all_best = [], []
+    mine = set(tmd.my_models(rank, world, n_models))
+    for k, (M, sub, res) in enumerate(clouds):
+        if k not in mine:
+            recs.append(tmd.empty_record())
+            continue
+        m = tmo.Model(M, res)
+        m.build_voxels(threads=2)
+        assert m.build_pairs(sub) == 0
+        pairs = synth.sample_scene_pairs(dict(surfels=surf, tangent_mask=tmask), m.diameter, 12, 3, seed=13)
+        shard = tmd.shard_pairs_2d(pairs, rank, world, n_models)
+        poses, _ = s.generate_hypotheses(m, shard)
+        if len(poses) == 0:
+            recs.append(tmd.empty_record())
+            continue
+        counts, scores, _ = s.score_hypotheses(m, poses, 0.5, 3.0, threads=2)
+        b = sorted(range(len(poses)), key=lambda i: (-int(counts[i]), -scores[i], i))[0]
+        recs.append(tmd.make_record(counts[b], tmd.global_hyp_id_2d(b, rank, world, n_models), scores[b], poses[b]))
+    best = tmd.allgather_best_many(recs)
+    out = np.array([[b.inlier_count, b.hyp_id, b.score] for b in best], dtype=np.float64)
+    loc = np.array([[r.inlier_count, r.hyp_id, r.score] for r in recs], dtype=np.float64)
+    np.save(os.path.join(out_dir, "mbest_%d.npy" % rank), out)
+    np.save(os.path.join(out_dir, "mlocal_%d.npy" % rank), loc)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_models", [2, 1])
+def test_two_rank_gloo_multi_model_reduce(tmp_path, n_models):
+    """n_models = 2: grid 2 x 1 (each rank owns one model); n_models = 1: grid 1 x 2 (pairs sharded)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from triplet_match_amd import dist as tmd
+    assert tmd.grid_2d(0, 2, n_models)[:2] == ((2, 1) if n_models == 2 else (1, 2))
+    assert tmd.grid_2d(5, 8, 32) == (8, 1, 5, 0) and tmd.grid_2d(5, 8, 2) == (2, 4, 1, 1)
+    assert sorted(sum((tmd.my_models(r, 8, 32) for r in range(8)), [])) == list(range(32))
+    port = _free_port()
+    mp.spawn(_worker_multi, args=(2, port, str(tmp_path), n_models), nprocs=2, join=True)
+    b0, b1 = np.load(tmp_path / "mbest_0.npy"), np.load(tmp_path / "mbest_1.npy")
+    assert np.array_equal(b0, b1) and b0.shape == (n_models, 3)
+    l0, l1 = np.load(tmp_path / "mlocal_0.npy"), np.load(tmp_path / "mlocal_1.npy")
+    for m in range(n_models):
+        exp = sorted([l0[m], l1[m]], key=lambda r: (-r[0], -r[2], r[1]))[0]
+        assert np.array_equal(b0[m], exp)
+        assert b0[m][0] > 400  # every model finds its own instance

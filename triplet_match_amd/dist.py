@@ -62,3 +62,56 @@ def empty_record():
     r = capi.BestRecord()
     r.hyp_id = 0xFFFFFFFF
     return r
+
+
+# ---- multi-model search (BASELINE config 5): models x sample pairs sharded 2-D, per-model reduce ----
+def grid_2d(rank, world, n_models):
+    """Splits `world` ranks into Wm model groups x Wp pair shards (Wm = the largest divisor of world that
+    is <= n_models). Returns (Wm, Wp, model_group, pair_shard): this rank searches the models
+    m % Wm == model_group with the sample pairs p % Wp == pair_shard of each."""
+    wm = max(d for d in range(1, world + 1) if world % d == 0 and d <= max(1, n_models))
+    wp = world // wm
+    return wm, wp, rank // wp, rank % wp
+
+
+def my_models(rank, world, n_models):
+    wm, _, g, _ = grid_2d(rank, world, n_models)
+    return list(range(g, n_models, wm))
+
+
+def shard_pairs_2d(pairs, rank, world, n_models):
+    """The pair shard of this rank inside its model group (global pair p -> shard p % Wp)."""
+    _, wp, _, shard = grid_2d(rank, world, n_models)
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    return np.ascontiguousarray(pairs[shard::wp])
+
+
+def global_hyp_id_2d(local_index, rank, world, n_models):
+    _, wp, _, shard = grid_2d(rank, world, n_models)
+    return shard + local_index * wp
+
+
+def allgather_best_many(recs, device=None, group=None):
+    """Per-model best records. `recs[m]` is this rank's best for model m (empty_record() for models it
+    did not search). ONE all-gather of world x n_models x 96 bytes, then tm_best_select per model;
+    every rank returns the same list."""
+    import torch
+    import torch.distributed as dist
+    n_models = len(recs)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [capi.best_select([r]) for r in recs]
+    local = torch.from_numpy(np.concatenate([record_to_bytes(r) for r in recs]))
+    if device is not None:
+        local = local.to(device)
+    gathered = torch.empty(RECORD_BYTES * n_models * world, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    raw = gathered.cpu().numpy().tobytes()
+    out = []
+    for m in range(n_models):
+        cand = []
+        for r in range(world):
+            o = RECORD_BYTES * (r * n_models + m)
+            cand.append(capi.BestRecord.from_buffer_copy(raw[o:o + RECORD_BYTES]))
+        out.append(capi.best_select(cand))
+    return out

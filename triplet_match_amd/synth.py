@@ -488,3 +488,66 @@ def synth_indoor(n, model_n, seed=6, noise_sigma=0.0):
     tmask = (np.linalg.norm(s[:, 9:12], axis=1) > 0.7).astype(np.int32)
     return dict(surfels=s, tangent_mask=tmask, instance_id=inst[perm], wall_id=wall[perm], walls=wall_out,
                 instances=instances)
+
+
+def synth_multi_model_scene(n, n_models=32, seed=7, min_points=20_000, max_points=100_000):
+    """Scene of config 5: one planted instance of each of `n_models` different models (scaled L-prisms,
+    min_points..max_points points at one common sampling density) on a grid of cells, plus a floor with
+    crease lines and outliers.
+
+    Returns (models, scene): models = [(surfels, tangent subset, resolution)], scene = dict(surfels,
+    tangent_mask, instance_id, poses_scene_to_model [n_models, 4, 4])."""
+    rng = np.random.default_rng(seed)
+    # one sampling density for every object (a scanner does not know the models): the point count of a
+    # model follows its surface area, overall size 0.45..1.0 with a mild anisotropic jitter
+    base = np.linspace(np.sqrt(min_points / max_points), 1.0, n_models)
+    scales = base[:, None] * (0.85 + 0.3 * rng.random((n_models, 3)))
+    rects, creases = _rects_and_creases()
+    areas = np.array([sum(np.linalg.norm(np.cross(a, b)) for (_, a, b, _) in _scaled(rects, creases, tuple(sc))[0])
+                      for sc in scales])
+    sizes = np.maximum(1000, (max_points * areas / areas.max()).astype(int))
+    models, parts, inst_l, s2m = [], [], [], []
+    cols = int(np.ceil(np.sqrt(2 * n_models)))
+    for k in range(n_models):
+        sc = tuple(float(x) for x in scales[k])
+        M, sub = synth_model(int(sizes[k]), seed=1 + k, scale=sc)
+        models.append((M, sub, resolution(M)))
+        inst, _ = synth_model(int(sizes[k]), seed=1000 + k, scale=sc)
+        R = random_rotation(rng)
+        t = np.array([3.0 * (k % cols) + 1.5, 3.0 * (k // cols) + 1.5, 1.0 + rng.random()])
+        inst[:, 0:3] = inst[:, 0:3] @ R.T + t
+        inst[:, 4:7] = inst[:, 4:7] @ R.T
+        inst[:, 9:12] = inst[:, 9:12] @ R.T
+        parts.append(inst.astype(np.float32))
+        inst_l.append(np.full(len(inst), k, np.int32))
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = t
+        s2m.append(np.linalg.inv(T))
+    used = sum(len(p) for p in parts)
+    if used > 0.9 * n:
+        raise ValueError("scene too small for the requested models")
+    rows = (n_models + cols - 1) // cols
+    X, Y = 3.0 * cols, 3.0 * rows
+    n_out = int(0.03 * n)
+    n_floor = n - used - n_out
+    pf = np.stack([rng.random(n_floor) * X, rng.random(n_floor) * Y, np.zeros(n_floor)], 1)
+    spacing = np.sqrt(X * Y / n_floor)
+    tf = np.zeros((n_floor, 3))
+    w = max(0.01, 1.5 * spacing)
+    gx = np.abs(np.mod(pf[:, 0], 3.0) - 1.5) > 1.5 - w   # grid lines between the cells
+    gy = np.abs(np.mod(pf[:, 1], 3.0) - 1.5) > 1.5 - w
+    tf[gx] = [0, 1.0, 0]
+    tf[gy & ~gx] = [1.0, 0, 0]
+    parts.append(_pack(pf, np.tile([0, 0, 1.0], (n_floor, 1)), tf))
+    po = rng.random((n_out, 3)) * [X, Y, 3.0]
+    no = rng.normal(size=(n_out, 3))
+    no /= np.linalg.norm(no, axis=1, keepdims=True)
+    parts.append(_pack(po, no, np.zeros((n_out, 3))))
+    inst_l += [np.full(n_floor, -1, np.int32), np.full(n_out, -1, np.int32)]
+    s = np.concatenate(parts)
+    inst = np.concatenate(inst_l)
+    perm = rng.permutation(len(s))
+    s, inst = np.ascontiguousarray(s[perm]), inst[perm]
+    tmask = (np.linalg.norm(s[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    return models, dict(surfels=s, tangent_mask=tmask, instance_id=inst, poses_scene_to_model=np.array(s2m))
