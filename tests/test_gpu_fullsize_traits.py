@@ -99,6 +99,9 @@ def _run_case(gpu_ctx, K, model, msamples, scene, ssamples, threshold, target_se
     cg, sg = gp.score_hypotheses(gm, pg, DT, traits=K)
     cg2, sg2 = gs2.score_hypotheses(gm, pg, DT, traits=K)
     assert np.array_equal(cg, cg2) and np.array_equal(sg, sg2)
+    # sphere-culled kernel (default) == exhaustive kernel under the traits' metric
+    cb, sb = gp.score_hypotheses(gm, pg[:8192], DT, traits=K, mode=capi.SCORE_BRUTEFORCE)
+    assert np.array_equal(cb, cg[:8192]) and np.array_equal(sb, sg[:8192])
 
     # --- oracle: generation for a sample of pairs, project_ for a sample of hypotheses incl. the best
     om = tmo.Model(mu, res)

@@ -178,6 +178,7 @@ struct tm_scene {
     tmx::dbuf<int32_t> ed_subset, ed_dropped;
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
     tmx::dbuf<unsigned long long> ed_tail, ed_corr, ed_tilebits;
+    tmx::dbuf<unsigned char> w_active_sorted; /* subset flags in sorted order */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;

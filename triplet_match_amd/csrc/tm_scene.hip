@@ -93,6 +93,7 @@ struct cull_args {
     const uint32_t* centers; /* per hypothesis: scene (original) index of the ball centre, or null */
     const float4* opos;      /* scene positions in original order (ball centres) */
     float ball_r, ball_r2;   /* radius and radius*radius of the neighbourhood restriction */
+    const unsigned char* active_sorted; /* SUBSET: per sorted slot, 1 = the point is in the subset */
 };
 
 __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, float rnorm, float abs_eps,
@@ -115,6 +116,11 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
     return true;
 }
 
+/* L2 = the model's metric is the 3-D Euclidean one (identity / plane): distance-field tile test, brick
+ * near-filter and the squared-distance comparison apply. Otherwise (plane2 / cylinder: the traits'
+ * intrinsic_distance can be small where the Euclidean one is not) only the sphere-vs-box test culls.
+ * SUBSET = only the points flagged in ca.active_sorted (sorted order) take part. */
+template <bool L2, bool SUBSET>
 __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
     __shared__ uint32_t s_list[kCullChunk];
     __shared__ uint32_t s_n;
@@ -173,7 +179,8 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             const uint32_t t = t0 + r * 64u + lane;
             if (t < ca.n_tiles) {
                 float4 tb = ca.tiles[t];
-                bool hit = tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb);
+                bool hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb)
+                              : sphere_hits_box(a, T, rnorm, abs_eps, tb);
                 if (ball) hit = hit && !(len(make3(tb.x, tb.y, tb.z) - bc) > ca.ball_r + tb.w * 1.00001f + ball_margin);
                 if (hit) s_list[atomicAdd(&s_n, 1u)] = t;
             }
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                 const float* sp = a.spos3 + 3u * (size_t)sidx[k]; /* 12 B per point: 12 lines per tile, not 16 */
                 P[k] = make_float4(sp[0], sp[1], sp[2], 0.f);
                 in[k] = have;
+                if (SUBSET) in[k] = in[k] & (ca.active_sorted[sidx[k]] != 0);
                 if (ball) { /* exact membership: (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point */
                     f3 d = make3(P[k].x, P[k].y, P[k].z) - bc;
                     in[k] = in[k] & (len2(d) <= ca.ball_r2);
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             }
             uint32_t code[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) code[k] = a.bcode[brick[k]];
+            for (int k = 0; k < 4; ++k) code[k] = L2 ? (uint32_t)a.bcode[brick[k]] : 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 near[k] = in[k] & (code[k] <= a.code_max);
@@ -230,9 +238,14 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float* mp = a.mpos3 + 3u * (size_t)m[k]; /* packed xyz: 5.3 points per 64-B line */
-                float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
-                float d2 = (dx * dx + dy * dy) + dz * dz;
-                ok[k] = near[k] & (d2 <= a.d2max);
+                if (L2) {
+                    float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    ok[k] = near[k] & (d2 <= a.d2max);
+                } else { /* reference voxel_distance: !(intrinsic_distance > thres) */
+                    float dist = traits_distance(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
+                    ok[k] = near[k] & !(dist > a.dmax);
+                }
             }
             if (a.ablate == 1) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
             /* stage 4: orientation term for the distance-passing points */
@@ -278,6 +291,14 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                                      (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]),
                                      (s_near[0] + s_near[1]) + (s_near[2] + s_near[3]));
     }
+}
+
+/* subset flags (original order) -> sorted order of the scoring arrays */
+__global__ __launch_bounds__(256) void k_active_sorted(const unsigned char* __restrict__ active,
+                                                       const uint32_t* __restrict__ order, uint32_t n, uint32_t n_pad,
+                                                       unsigned char* __restrict__ out) {
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n_pad) out[k] = k < n ? active[order[k]] : 0;
 }
 
 __global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uint32_t n, double inv_scale,
@@ -604,9 +625,11 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
      * the int cast truncates) from the model: then no model point is within thres of the query. */
     const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
     const float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
-    /* tile culling and the brick filter reason with 3-D Euclidean distances: L2 metrics only */
-    const bool culled = (mode != TM_SCORE_BRUTEFORCE) && !d_active && m->metric_kind <= TM_TRAITS_PLANE;
-    a.bcode = culled ? m->brick_code.p : nullptr;
+    /* the distance-field tile test and the brick filter reason with 3-D Euclidean distances: L2 metrics
+     * only; the other metrics keep the sphere-vs-box culling */
+    const bool culled = mode != TM_SCORE_BRUTEFORCE;
+    const bool l2 = m->metric_kind <= TM_TRAITS_PLANE;
+    a.bcode = (culled && l2) ? m->brick_code.p : nullptr;
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     {
@@ -637,7 +660,21 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         ca.ball_r2 = ball_radius * ball_radius;
         ca.tcode = (thres + slack) / m->brick_q + 1.f;
         if (!(thres >= 0.f)) ca.tcode = 1e30f;
-        hipLaunchKernelGGL(k_score_culled, dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+        ca.active_sorted = nullptr;
+        if (d_active) {
+            TM_FORWARD(s->w_active_sorted.ensure(s->n_sorted));
+            hipLaunchKernelGGL(k_active_sorted, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, d_active,
+                               s->d_order.p, s->n, s->n_sorted, s->w_active_sorted.p);
+            ca.active_sorted = s->w_active_sorted.p;
+        }
+        if (l2 && !d_active)
+            hipLaunchKernelGGL((k_score_culled<true, false>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+        else if (l2)
+            hipLaunchKernelGGL((k_score_culled<true, true>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+        else if (!d_active)
+            hipLaunchKernelGGL((k_score_culled<false, false>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+        else
+            hipLaunchKernelGGL((k_score_culled<false, true>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
     } else if (d_active) {
         hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
     } else {
@@ -847,6 +884,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_pairs.release();
     s->w_words.release();
     s->w_corr.release();
+    s->w_active_sorted.release();
     s->ed_subset.release();
     s->ed_dropped.release();
     s->ed_tests.release();
