@@ -44,7 +44,16 @@ def main():
     ap.add_argument("--mode", choices=["auto", "brute", "culled"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the 96-byte exchange goes "
+                         "over gloo (RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: send everything libraries print there (gloo / RCCL banners,
+    # compiler output) to stderr until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,9 +65,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from triplet_match_amd import build as tm_build
     if rank == 0:
@@ -112,7 +126,7 @@ def main():
     if n_hyp < H:
         log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (n_hyp, H))
 
-    cuda_dev = torch.device("cuda", local_rank)
+    cuda_dev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
 
     def step():
         n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
@@ -146,10 +160,10 @@ def main():
     ctx.enable_timing(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cuda_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        h = torch.tensor([hyps, evals], dtype=torch.float64, device="cuda")
+        h = torch.tensor([hyps, evals], dtype=torch.float64, device=cuda_dev)
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         hyps_all, evals_all = float(h[0].item()), float(h[1].item())
     else:
@@ -189,7 +203,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
