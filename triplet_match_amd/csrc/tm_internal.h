@@ -163,6 +163,7 @@ struct tm_scene {
     tmx::dbuf<float4> sref;       /* sorted ref (tangent or normal), w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> tiles;      /* per tile: centre xyz, radius (negative = empty) */
     tmx::dbuf<float4> supers;     /* per super-tile (64 tiles = 4096 points): bounding sphere */
+    tmx::dbuf<float4> subs;       /* per quarter tile (16 points): bounding sphere */
     uint32_t n_sorted = 0;        /* padded point count (multiple of the brute-force tile) */
     uint32_t n_tiles = 0;         /* n_sorted / 64 */
     float coord_max = 0.f;        /* max |coordinate| over the finite points */

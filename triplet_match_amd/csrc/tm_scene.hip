@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
  * per wave iteration with predicated (branch-free) gathers so that four independent
  * voxel -> model-point gather chains are in flight per lane. No atomics: one store per hypothesis.
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kCullChunk = 4096; /* tiles culled per round: 16 KiB of LDS */
+constexpr int kCullChunk = 1024; /* tiles culled per round; each may leave up to 4 sub-tiles in the 16 KiB list */
 
 struct cull_args {
     const float4* tiles;
     const float4* supers; /* bounding spheres of 64-tile groups */
+    const float4* subs;   /* bounding spheres of the four 16-point quarters of every tile */
     uint32_t n_tiles;
     float coord_max; /* max |coordinate| of the scene, for the rounding margin */
     float inv_q;     /* 1 / brick code quantum */
@@ -122,8 +123,9 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
  * SUBSET = only the points flagged in ca.active_sorted (sorted order) take part. */
 template <bool L2, bool SUBSET>
 __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
-    __shared__ uint32_t s_list[kCullChunk];
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_list[4 * kCullChunk]; /* surviving sub-tiles (16 points each) of the round */
+    __shared__ uint32_t s_tiles[kCullChunk];    /* surviving tiles of the round */
+    __shared__ uint32_t s_n, s_nt;
     __shared__ unsigned long long s_smask;
     __shared__ uint32_t s_cnt[4], s_pass[4];
     __shared__ unsigned long long s_fx[4];
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
         if (wave == 0) {
             const uint32_t u = (t0 >> 6) + lane;
             bool hit = false;
-            if (u * 64u < ca.n_tiles) {
+            if (lane < (uint32_t)(kCullChunk / 64) && u * 64u < ca.n_tiles) {
                 float4 sb = ca.supers[u];
                 hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
                 if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > ca.ball_r + sb.w * 1.00001f + ball_margin);
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             if (lane == 0) {
                 s_smask = mask;
                 s_n = 0;
+                s_nt = 0;
             }
         }
         __syncthreads();
@@ -177,18 +180,33 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             if (a.ablate == 5) break;
             if (!((smask >> r) & 1ull)) continue;
             const uint32_t t = t0 + r * 64u + lane;
+            bool hit = false;
             if (t < ca.n_tiles) {
                 float4 tb = ca.tiles[t];
-                bool hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb)
-                              : sphere_hits_box(a, T, rnorm, abs_eps, tb);
+                hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb)
+                         : sphere_hits_box(a, T, rnorm, abs_eps, tb);
                 if (ball) hit = hit && !(len(make3(tb.x, tb.y, tb.z) - bc) > ca.ball_r + tb.w * 1.00001f + ball_margin);
-                if (hit) s_list[atomicAdd(&s_n, 1u)] = t;
             }
+            if (hit) s_tiles[atomicAdd(&s_nt, 1u)] = t;
+        }
+        __syncthreads();
+        /* level 3: the four 16-point quarters of every surviving tile, the same tests with their own
+         * (smaller) spheres; one (tile, quarter) per thread */
+        const uint32_t n_quarters = 4u * s_nt;
+        for (uint32_t idx = threadIdx.x; idx < n_quarters; idx += 256) {
+            const uint32_t sub = s_tiles[idx >> 2] * 4u + (idx & 3u);
+            const float4 sb = ca.subs[sub];
+            bool hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, sb)
+                          : sphere_hits_box(a, T, rnorm, abs_eps, sb);
+            if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > ca.ball_r + sb.w * 1.00001f + ball_margin);
+            if (hit) s_list[atomicAdd(&s_n, 1u)] = sub;
         }
         __syncthreads();
         const uint32_t n = a.ablate == 4 ? 0u : s_n;
         tiles_done += n;
-        for (uint32_t i = wave * 4; i < n; i += 16) {
+        /* a wave's 64 lanes take four sub-tiles at a time (lane >> 4 picks the sub-tile), four such groups
+         * in flight: 16 list entries per iteration */
+        for (uint32_t i = wave * 16; i < n; i += 64) {
             /* stage 1: load 4 tiles' points, then transform + in-grid, then 4 brick-code loads */
             f3 q[4];
             uint32_t sidx[4], lin[4], m[4], brick[4];
@@ -196,8 +214,9 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
             float4 P[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const bool have = i + k < n;
-                sidx[k] = (have ? s_list[i + k] : s_list[i]) * 64u + lane;
+                const uint32_t e = i + 4u * k + (lane >> 4);
+                const bool have = e < n;
+                sidx[k] = (have ? s_list[e] : s_list[i]) * 16u + (lane & 15u);
                 const float* sp = a.spos3 + 3u * (size_t)sidx[k]; /* 12 B per point: 12 lines per tile, not 16 */
                 P[k] = make_float4(sp[0], sp[1], sp[2], 0.f);
                 in[k] = have;
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
     if (threadIdx.x == 0) {
         a.counts[h] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
         a.scores_fx[h] = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
-        a.stat_slots[h] = make_uint4((uint32_t)(tiles_done * 64ull), (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]),
+        a.stat_slots[h] = make_uint4((uint32_t)(tiles_done * 16ull), (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]),
                                      (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]),
                                      (s_near[0] + s_near[1]) + (s_near[2] + s_near[3]));
     }
@@ -651,6 +670,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         cull_args ca;
         ca.tiles = s->tiles.p;
         ca.supers = s->supers.p;
+        ca.subs = s->subs.p;
         ca.n_tiles = s->n_tiles;
         ca.coord_max = s->coord_max;
         ca.inv_q = 1.f / m->brick_q;
@@ -873,6 +893,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->spos3.release();
     s->tiles.release();
     s->supers.release();
+    s->subs.release();
     s->w_poses.release();
     s->w_counts.release();
     s->w_scores_fx.release();
