@@ -123,7 +123,7 @@ struct tm_model {
      * touching the big voxel table. */
     tmx::dbuf<uint32_t> brick_min_bits; /* f32 bits of min d2 per brick */
     tmx::dbuf<unsigned char> brick_code; /* floor(sqrt(min d2) / brick_q), clamped to 255 */
-    int bdim[3] = {0, 0, 0};
+    int bdim[3] = {0, 0, 0}; /* super-bricks (16^3 voxels = 64 bricks) per axis, see brick_of() */
     float brick_q = 0.f;
     /* pair table */
     std::vector<uint32_t> subset;

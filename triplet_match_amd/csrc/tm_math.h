@@ -37,6 +37,25 @@ TM_HD f3 operator+(f3 a, f3 b) { return make3(a.x + b.x, a.y + b.y, a.z + b.z); 
 TM_HD f3 scale(f3 a, float s) { return make3(a.x * s, a.y * s, a.z * s); }
 TM_HD f3 over(f3 a, float s) { return make3(a.x / s, a.y / s, a.z / s); }
 TM_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Voxel-table addressing. The table is stored in 4x4x4-voxel bricks (64 consecutive entries); the bricks
+ * themselves are grouped 4x4x4 into super-bricks (16^3 voxels, 64 consecutive bricks = 16 KB), which are laid
+ * out x-fastest. `bx`, `by` = super-brick counts along x and y. A wave's 8x8-point surface patch (16x16
+ * voxels) then touches one to four contiguous 16-KB blocks instead of bricks that are a whole grid row
+ * or slab apart. */
+TM_HD uint32_t brick_of(uint32_t ix, uint32_t iy, uint32_t iz, uint32_t bx, uint32_t by) {
+    return ((((iz >> 4) * by + (iy >> 4)) * bx + (ix >> 4)) << 6) |
+           ((((iz >> 2) & 3u) << 4) | (((iy >> 2) & 3u) << 2) | ((ix >> 2) & 3u));
+}
+/* inverse: brick number -> brick coordinates (units of 4 voxels) */
+TM_HD void brick_coords(uint32_t brick, uint32_t bx, uint32_t by, uint32_t& bi, uint32_t& bj, uint32_t& bk) {
+    const uint32_t sb = brick >> 6, loc = brick & 63u;
+    const uint32_t sk = sb / (bx * by), sr = sb - sk * (bx * by);
+    const uint32_t sj = sr / bx, si = sr - sj * bx;
+    bi = (si << 2) | (loc & 3u);
+    bj = (sj << 2) | ((loc >> 2) & 3u);
+    bk = (sk << 2) | (loc >> 4);
+}
+
 TM_HD float len2(f3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
 TM_HD float len(f3 a) { return sqrtf(len2(a)); }
 TM_HD f3 cross3(f3 a, f3 b) {

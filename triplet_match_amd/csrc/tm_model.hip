@@ -61,9 +61,8 @@ __global__ __launch_bounds__(256) void k_voxel_nn(const float4* __restrict__ pos
     for (int v = 0; v < kVoxVPT; ++v) {
         uint64_t slot = base + (uint64_t)v * 256 + threadIdx.x;
         uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
-        uint32_t bk = brick / (uint32_t)(bx * by);
-        uint32_t br = brick - bk * (uint32_t)(bx * by);
-        uint32_t bj = br / (uint32_t)bx, bi = br - bj * (uint32_t)bx;
+        uint32_t bi, bj, bk;
+        brick_coords(brick, (uint32_t)bx, (uint32_t)by, bi, bj, bk);
         uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
         live[v] = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
         qx[v] = isx * (float)i + itx;
@@ -134,9 +133,8 @@ __global__ __launch_bounds__(256) void k_voxel_nn_kd(const float4* __restrict__ 
     __shared__ float st_bound[kKdStack][256];
     const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
-    const uint32_t bk = brick / (uint32_t)(bx * by);
-    const uint32_t br = brick - bk * (uint32_t)(bx * by);
-    const uint32_t bj = br / (uint32_t)bx, bi = br - bj * (uint32_t)bx;
+    uint32_t bi, bj, bk;
+    brick_coords(brick, (uint32_t)bx, (uint32_t)by, bi, bj, bk);
     const uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
     const bool live = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
     const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
@@ -369,7 +367,7 @@ __global__ void k_unbrick(const uint32_t* __restrict__ bricked, const uint32_t* 
     uint32_t k = (uint32_t)(lin / exy);
     uint32_t r = (uint32_t)(lin - (uint64_t)k * exy);
     uint32_t j = r / (uint32_t)g.ex, i = r - j * (uint32_t)g.ex;
-    uint32_t brick = ((k >> 2) * (uint32_t)by + (j >> 2)) * (uint32_t)bx + (i >> 2);
+    uint32_t brick = brick_of(i, j, k, (uint32_t)bx, (uint32_t)by);
     uint32_t v = bricked[(uint64_t)brick * 64u + (((k & 3u) << 4) | ((j & 3u) << 2) | (i & 3u))];
     dense[lin] = v == 0xFFFFFFFFu ? v : new2orig[v];
 }
@@ -957,8 +955,8 @@ int tm_model_build_voxels(tm_model* m) {
     /* the reference's voxel_count is a uint32_t (include/impl/model.hpp:65) */
     TM_REQUIRE(count <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid exceeds 2^32 cells");
     m->voxel_count = count;
-    for (int d = 0; d < 3; ++d) m->bdim[d] = (m->extents[d] + 3) / 4;
-    const uint64_t n_bricks64 = (uint64_t)m->bdim[0] * m->bdim[1] * m->bdim[2];
+    for (int d = 0; d < 3; ++d) m->bdim[d] = (m->extents[d] + 15) / 16; /* super-bricks of 16^3 voxels */
+    const uint64_t n_bricks64 = (uint64_t)m->bdim[0] * m->bdim[1] * m->bdim[2] * 64ull;
     TM_REQUIRE(n_bricks64 * 64ull <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid exceeds 2^32 slots");
     const uint32_t n_bricks = (uint32_t)n_bricks64;
     m->voxel_slots = n_bricks64 * 64ull;
@@ -1314,7 +1312,7 @@ int tm_model_voxel_query(const tm_model* m, const float pos4[4], uint32_t* index
     *found = 0;
     if (!(vx > -1.f && vx < g.fex && vy > -1.f && vy < g.fey && vz > -1.f && vz < g.fez)) return TM_OK;
     const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-    const size_t brick = ((size_t)(iz >> 2) * m->bdim[1] + (iy >> 2)) * m->bdim[0] + (ix >> 2);
+    const size_t brick = brick_of((uint32_t)ix, (uint32_t)iy, (uint32_t)iz, (uint32_t)m->bdim[0], (uint32_t)m->bdim[1]);
     size_t lin = brick * 64 + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
     uint32_t v = 0;
     TM_HIP_CHECK(hipSetDevice(m->ctx->device));

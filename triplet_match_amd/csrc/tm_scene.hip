@@ -111,7 +111,7 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
      * the tile can become a correspondence (slack and the +1 code of safety are inside tcode). */
     if ((vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez)) {
         const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-        const float code = (float)a.bcode[((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2)];
+        const float code = (float)a.bcode[brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by)];
         if (code > ca_tcode + rho * ca_inv_q * 1.0001f) return false;
     }
     return true;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                         (vz < a.g.fez);
                 uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
                          iz = in[k] ? (uint32_t)(int)vz : 0u;
-                brick[k] = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
+                brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
                 lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
             }
             uint32_t code[4];

@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12
     if (in_grid) *in_grid = in;
     if (!in) return 0u;
     const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-    const uint32_t brick = ((iz >> 2) * (uint32_t)a.by + (iy >> 2)) * (uint32_t)a.bx + (ix >> 2);
+    const uint32_t brick = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
     if (a.bcode) { /* exact-safe: every model point is farther than thres from this voxel's cell */
         if ((uint32_t)a.bcode[brick] > a.code_max) return 0u;
     }
