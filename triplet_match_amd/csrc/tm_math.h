@@ -37,6 +37,32 @@ TM_HD f3 operator+(f3 a, f3 b) { return make3(a.x + b.x, a.y + b.y, a.z + b.z); 
 TM_HD f3 scale(f3 a, float s) { return make3(a.x * s, a.y * s, a.z * s); }
 TM_HD f3 over(f3 a, float s) { return make3(a.x / s, a.y / s, a.z / s); }
 TM_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Skilling's axes -> transposed Hilbert index (21 bits per axis), in place: after the call the Hilbert key
+ * is the bit-interleave of X[0] (most significant), X[1], X[2] */
+TM_HD void hilbert_transpose21(unsigned int X[3]) {
+    const unsigned int M = 1u << 20;
+    for (unsigned int Q = M; Q > 1; Q >>= 1) {
+        const unsigned int P = Q - 1;
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const unsigned int t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned int t = 0;
+    for (unsigned int Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t;
+    X[1] ^= t;
+    X[2] ^= t;
+}
+
 /* Voxel-table addressing. The table is stored in 4x4x4-voxel bricks (64 consecutive entries); the bricks
  * themselves are grouped 4x4x4 into super-bricks (16^3 voxels, 64 consecutive bricks = 16 KB), which are laid
  * out x-fastest. `bx`, `by` = super-brick counts along x and y. A wave's 8x8-point surface patch (16x16

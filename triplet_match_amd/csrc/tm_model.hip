@@ -692,8 +692,11 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
     m->distance_step_count = distance_step_count;
     m->angle_step = angle_step;
     m->h_cloud.assign(surfels, surfels + (size_t)n * 12);
-    /* internal order = Morton curve over the finite bounding box (non-finite points last) */
+    /* internal order = Hilbert curve over the finite bounding box (non-finite points last); neighbours in
+     * space are neighbours in the arrays, so the scoring kernel's gathers of model points share lines.
+     * TM_MODEL_MORTON=1 selects the plain Morton order (timing comparisons). */
     {
+        const bool hilbert = getenv("TM_MODEL_MORTON") == nullptr;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (uint32_t i = 0; i < n; ++i) {
             const float* s = surfels + (size_t)i * 12;
@@ -709,9 +712,16 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
         for (uint32_t i = 0; i < n; ++i) {
             const float* s = surfels + (size_t)i * 12;
             uint64_t code = ~0ull;
-            if (fin3(s))
-                code = spread21((uint64_t)((s[0] - lo[0]) * inv)) | (spread21((uint64_t)((s[1] - lo[1]) * inv)) << 1) |
-                       (spread21((uint64_t)((s[2] - lo[2]) * inv)) << 2);
+            if (fin3(s)) {
+                unsigned int X[3] = {(unsigned int)((s[0] - lo[0]) * inv), (unsigned int)((s[1] - lo[1]) * inv),
+                                     (unsigned int)((s[2] - lo[2]) * inv)};
+                if (hilbert) {
+                    hilbert_transpose21(X);
+                    code = (spread21(X[0]) << 2) | (spread21(X[1]) << 1) | spread21(X[2]);
+                } else {
+                    code = spread21(X[0]) | (spread21(X[1]) << 1) | (spread21(X[2]) << 2);
+                }
+            }
             order[i] = {code, i};
         }
         std::sort(order.begin(), order.end());

@@ -125,32 +125,6 @@ __device__ __forceinline__ unsigned long long spread21_dev(unsigned long long v)
     return v;
 }
 
-/* Skilling's axes -> transposed Hilbert index (21 bits per axis), in place */
-__device__ __forceinline__ void hilbert_transpose(unsigned int X[3]) {
-    const unsigned int M = 1u << 20;
-    for (unsigned int Q = M; Q > 1; Q >>= 1) {
-        const unsigned int P = Q - 1;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (X[i] & Q) {
-                X[0] ^= P;
-            } else {
-                const unsigned int t = (X[0] ^ X[i]) & P;
-                X[0] ^= t;
-                X[i] ^= t;
-            }
-        }
-    }
-    X[1] ^= X[0];
-    X[2] ^= X[1];
-    unsigned int t = 0;
-    for (unsigned int Q = M; Q > 1; Q >>= 1)
-        if (X[2] & Q) t ^= Q - 1;
-    X[0] ^= t;
-    X[1] ^= t;
-    X[2] ^= t;
-}
-
 __global__ __launch_bounds__(256) void k_scene_morton(const float* __restrict__ cloud, uint32_t n,
                                                       const scene_bounds* __restrict__ bnd, int hilbert,
                                                       unsigned long long* __restrict__ keys,
@@ -170,7 +144,7 @@ __global__ __launch_bounds__(256) void k_scene_morton(const float* __restrict__ 
         unsigned long long iz = (unsigned long long)(((double)a.z - mn2) * inv);
         if (hilbert) {
             unsigned int X[3] = {(unsigned int)ix, (unsigned int)iy, (unsigned int)iz};
-            hilbert_transpose(X);
+            hilbert_transpose21(X);
             code = (spread21_dev(X[0]) << 2) | (spread21_dev(X[1]) << 1) | spread21_dev(X[2]);
         } else {
             code = spread21_dev(ix) | (spread21_dev(iy) << 1) | (spread21_dev(iz) << 2);
