@@ -267,19 +267,29 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
                 }
             }
             if (a.ablate == 1) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
-            /* stage 4: orientation term for the distance-passing points */
+            /* stage 4: orientation term for the distance-passing points; the eight loads are issued before
+             * the first use so that they overlap */
             if (__ballot(ok[0] | ok[1] | ok[2] | ok[3])) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (ok[k]) {
-                        ++pass;
-                        float4 sr = a.sref[sidx[k]];
-                        float4 mr = a.mref[m[k]]; /* w = is_tangent of the model point */
-                        if (sr.w == mr.w) {       /* use_tangent == is_tangent, reference :472 */
-                            f3 r = xform_dir(T, make3(sr.x, sr.y, sr.z));
-                            float term = fabsf(dot3(r, make3(mr.x, mr.y, mr.z)));
-                            fx += (long long)((double)term * kFx);
-                            ++cnt;
+                for (int k0 = 0; k0 < 4; k0 += 2) {
+                    float4 sr[2], mr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (ok[k0 + j]) {
+                            sr[j] = a.sref[sidx[k0 + j]];
+                            mr[j] = a.mref[m[k0 + j]]; /* w = is_tangent of the model point */
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (ok[k0 + j]) {
+                            ++pass;
+                            if (sr[j].w == mr[j].w) { /* use_tangent == is_tangent, reference :472 */
+                                f3 r = xform_dir(T, make3(sr[j].x, sr[j].y, sr[j].z));
+                                float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
+                                fx += (long long)((double)term * kFx);
+                                ++cnt;
+                            }
                         }
                     }
                 }
