@@ -177,10 +177,13 @@ def main():
     alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = measured_traffic(args)
+    copy_gbs = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
-                "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes}
+                "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes,
+                "measured_copy_GBs": copy_gbs,
+                "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -210,6 +213,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_bandwidth(torch, local_rank):
+    """Device-to-device copy of 1 GiB on this GPU (read + write bytes / time, HIP events through torch):
+    the achievable streaming bandwidth next to the 8 TB/s spec figure (SURVEY.md section 8d asks for both)."""
+    try:
+        n = 1 << 28  # 1 GiB of fp32
+        a = torch.empty(n, dtype=torch.float32, device="cuda:%d" % local_rank).normal_()
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        return round(2.0 * n * 4 / (ms * 1e-3) / 1e9, 1)
+    except Exception as exc:  # the figure is informative; never fail the bench for it
+        log("copy bandwidth not measured: %s" % exc)
+        return None
 
 
 def measured_traffic(args):
