@@ -741,3 +741,36 @@ def test_radius_subset_bit_exact(gpu_ctx, gpu_small, oracle_small, small_case):
     os2 = tmo.Scene(s, np.zeros(300, np.int32))
     a, b = gs2.radius_subset(0, 0.5), os2.radius_subset(0, 0.5)
     assert np.array_equal(a, b) and len(a) == 1 + 100 + 49 + 48  # centre, on-sphere, just inside, origin
+
+
+def test_tiny_scenes_and_nonfinite_poses(gpu_ctx, gpu_small, oracle_small, small_case):
+    """Scenes smaller than a tile / a quarter tile, and poses with NaN / inf entries or a zero rotation."""
+    gm, om = gpu_small["model"], oracle_small["model"]
+    S, tmk = small_case["scene"]["surfels"], small_case["scene"]["tangent_mask"]
+    inst = np.nonzero(small_case["scene"]["instance_id"] == 0)[0]
+    poses = random_poses_near_truth(small_case, 6)
+    for n in (1, 15, 17, 63, 65, 1025):
+        idx = inst[:n]
+        gs = capi.Scene(gpu_ctx, S[idx], tmk[idx])
+        os_ = tmo.Scene(S[idx], tmk[idx])
+        cg, sg = gs.score_hypotheses(gm, poses, DT)
+        co, so, _ = os_.score_hypotheses(om, poses, 0.5, DT)
+        assert np.array_equal(cg, co), n
+        assert np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+        cb, _ = gs.score_hypotheses(gm, poses, DT, mode=capi.SCORE_BRUTEFORCE)
+        assert np.array_equal(cb, co)
+        a, b = gs.radius_subset(0, 1e9), os_.radius_subset(0, 1e9)
+        assert np.array_equal(a, b) and len(a) == n
+    bad = poses[:5].copy()
+    bad[0, 12] = np.nan        # NaN translation
+    bad[1, 0] = np.inf         # inf in the rotation block
+    bad[2, :] = 0.0            # all-zero matrix: every point lands on the origin
+    bad[3, 13] = 1e30          # far away
+    bad[4, :12] *= 1e-20       # collapsed rotation
+    gs, os_ = gpu_small["scene"], oracle_small["scene"]
+    cg, sg = gs.score_hypotheses(gm, bad, DT)
+    co, so, _ = os_.score_hypotheses(om, bad, 0.5, DT)
+    assert np.array_equal(cg, co)
+    assert np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15, equal_nan=True)
+    cb, _ = gs.score_hypotheses(gm, bad, DT, mode=capi.SCORE_BRUTEFORCE)
+    assert np.array_equal(cb, co)
