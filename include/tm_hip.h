@@ -222,6 +222,15 @@ int tm_score_hypotheses_early_drop(tm_scene* scene, tm_model* model, const float
                                    float dist_thres, float accept_prob, uint32_t* counts,
                                    double* scores, int32_t* dropped_at, uint32_t* saved);
 
+/* The same rule for a batch whose hypotheses each scan their own neighbourhood: hypothesis h scans
+ * nn = radius_search_inclusive(radius, centers[h]) in ascending index order — the subset find_in_subset
+ * hands to project_ for the first sample point centers[h] (include/impl/scene.hpp:273,326). Lets the host
+ * loop push the hypotheses of several first points through one call. */
+int tm_score_hypotheses_early_drop_ball(tm_scene* scene, tm_model* model, const float* poses16,
+                                        uint32_t n_hyp, const uint32_t* centers, float radius,
+                                        float dist_thres, float accept_prob, uint32_t* counts,
+                                        double* scores, int32_t* dropped_at, uint32_t* saved);
+
 /* finish_find (include/impl/scene.hpp:100-106): correspondences of one pose over all points,
  * ascending scene index; *score normalised by |model cloud| */
 int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pose16[16],

@@ -73,12 +73,21 @@ struct hip_backend {
         for (uint32_t h = 0; h < count; ++h) pair_of_hyp[h] = prov[4 * (size_t)h];
     }
     void score_ball(const std::vector<search::pose_t>& poses, const std::vector<uint32_t>& centers, float radius,
-                    std::vector<uint32_t>& counts, std::vector<double>& scores) {
+                    bool early_drop, std::vector<uint32_t>& counts, std::vector<double>& scores) {
         counts.assign(poses.size(), 0u);
         scores.assign(poses.size(), 0.0);
-        check(tm_score_hypotheses_ball(s, m, &poses[0].m[0], (uint32_t)poses.size(), centers.data(), radius,
-                                       p.dist_thres, counts.data(), scores.data()),
-              "tm_score_hypotheses_ball");
+        if (early_drop) {
+            std::vector<int32_t> dropped(poses.size());
+            std::vector<uint32_t> saved(poses.size());
+            check(tm_score_hypotheses_early_drop_ball(s, m, &poses[0].m[0], (uint32_t)poses.size(), centers.data(),
+                                                      radius, p.dist_thres, p.accept_prob, counts.data(),
+                                                      scores.data(), dropped.data(), saved.data()),
+                  "tm_score_hypotheses_early_drop_ball");
+        } else {
+            check(tm_score_hypotheses_ball(s, m, &poses[0].m[0], (uint32_t)poses.size(), centers.data(), radius,
+                                           p.dist_thres, counts.data(), scores.data()),
+                  "tm_score_hypotheses_ball");
+        }
     }
     void score(const std::vector<search::pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
                std::vector<uint32_t>& counts, std::vector<double>& scores) {

@@ -73,9 +73,9 @@ struct params_t {
  *   void generate(const std::vector<uint32_t>& ij, std::vector<pose_t>& poses);   // visit order
  *   void score(const std::vector<pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
  *              std::vector<uint32_t>& counts, std::vector<double>& scores);       // project_ per pose
- *   bool supports_batched();                          // optional fast path for early_drop == false:
+ *   bool supports_batched();                          // optional fast path:
  *   void generate_with_pairs(ij, poses, pair_of_hyp); //   hypotheses + the sample pair each came from
- *   void score_ball(poses, centers, radius, counts, scores); // each pose on the ball around its first point
+ *   void score_ball(poses, centers, radius, early_drop, counts, scores); // each pose on nn(its first point)
  *   void extract(const pose_t& T, float dist_thres, candidate_t& out);            // finish_find
  *   detail::icp_sums_t icp_sums(const pose_t& T, float dist_thres);               // finish_find + ICP sums
  *   void set_mask(const std::vector<int32_t>& mask);
@@ -206,10 +206,12 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     std::vector<pose_t> poses;
     std::vector<uint32_t> counts;
     std::vector<double> scores;
-    /* Batched path (early_drop off): the valid samples of up to 16 first points go through one
-     * generate + one ball-restricted scoring launch; scanning the results in visit order gives the same
-     * first sufficient hypothesis as the one-first-point-at-a-time loop below. */
-    const bool batched = !p.early_drop && be.supports_batched();
+    /* Batched path: the valid samples of up to 16 first points go through one generate + one scoring
+     * call in which every hypothesis is scored on the neighbourhood of its own first point (with the
+     * early-drop rule applied per hypothesis on that neighbourhood's scan order when p.early_drop);
+     * scanning the results in visit order gives the same first sufficient hypothesis as the
+     * one-first-point-at-a-time loop below. */
+    const bool batched = be.supports_batched();
     std::vector<uint32_t> batch_ij, pair_of_hyp, centers;
     auto flush_batch = [&]() {
         if (batch_ij.empty() || !best_ts.empty()) {
@@ -221,7 +223,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         if (!poses.empty()) {
             centers.resize(poses.size());
             for (size_t h = 0; h < poses.size(); ++h) centers[h] = batch_ij[2 * (size_t)pair_of_hyp[h]];
-            be.score_ball(poses, centers, be.model_diameter(), counts, scores);
+            be.score_ball(poses, centers, be.model_diameter(), p.early_drop, counts, scores);
             for (size_t h = 0; h < poses.size(); ++h)
                 if (scores[h] > 0.0 && (float)counts[h] > sufficient) {
                     best_ts.push_back(poses[h]);

@@ -52,7 +52,7 @@ struct oracle_backend {
     }
     bool supports_batched() const { return false; } /* the oracle always takes the one-at-a-time loop */
     void generate_with_pairs(const std::vector<uint32_t>&, std::vector<search::pose_t>&, std::vector<uint32_t>&) {}
-    void score_ball(const std::vector<search::pose_t>&, const std::vector<uint32_t>&, float, std::vector<uint32_t>&,
+    void score_ball(const std::vector<search::pose_t>&, const std::vector<uint32_t>&, float, bool, std::vector<uint32_t>&,
                     std::vector<double>&) {}
     void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
         uint32_t n = tmo_scene_radius_subset(s, i, radius, nullptr, 0);

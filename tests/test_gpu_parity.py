@@ -774,3 +774,39 @@ def test_tiny_scenes_and_nonfinite_poses(gpu_ctx, gpu_small, oracle_small, small
     assert np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15, equal_nan=True)
     cb, _ = gs.score_hypotheses(gm, bad, DT, mode=capi.SCORE_BRUTEFORCE)
     assert np.array_equal(cb, co)
+
+
+def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_small, small_case):
+    """One call for hypotheses that each scan their own radius neighbourhood == one early-drop call per
+    neighbourhood == the oracle's project_ with early-out on nn(centre)."""
+    gs, gm = gpu_small["scene"], gpu_small["model"]
+    os_, om = oracle_small["scene"], oracle_small["model"]
+    pairs = sample_pairs(small_case, om, n_first=20, per_first=5)
+    poses, _ = os_.generate_hypotheses(om, pairs)
+    poses = np.concatenate([poses[:240], random_poses_near_truth(small_case, 24)])
+    rng = np.random.default_rng(4)
+    tidx = np.nonzero(small_case["scene"]["tangent_mask"])[0]
+    cset = rng.choice(tidx, size=5, replace=False).astype(np.uint32)
+    centers = cset[rng.integers(0, 5, len(poses))]
+    diam = om.diameter
+    mask = np.zeros(len(small_case["scene"]["surfels"]), np.int32)
+    mask[rng.integers(0, len(mask), 800)] = 1
+    for use_mask in (False, True):
+        gs.set_mask(mask if use_mask else None)
+        os_.set_mask(mask if use_mask else None)
+        try:
+            cb, sb, db, vb = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
+            for c in cset:
+                sel = np.nonzero(centers == c)[0]
+                nn = gs.radius_subset(int(c), diam)
+                c1, s1, d1, v1 = gs.score_hypotheses_early_drop(gm, poses[sel], DT, 0.5, subset=nn)
+                assert np.array_equal(cb[sel], c1) and np.array_equal(sb[sel], s1)
+                assert np.array_equal(db[sel], d1) and np.array_equal(vb[sel], v1)
+                for h in sel[:12]:
+                    sc, mc, score, saved = os_.project(om, poses[h], 0.5, DT, subset=nn, early_out=True)
+                    assert cb[h] == len(sc) and vb[h] == saved
+                    assert abs(sb[h] - score) <= SCORE_RTOL * max(abs(score), 1e-30)
+            assert (db >= 0).any() and (db < 0).any()
+        finally:
+            gs.set_mask(None)
+            os_.set_mask(None)

@@ -96,6 +96,8 @@ SIGNATURES = {
     "tm_score_hypotheses_ball_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_float, C.c_float, vp, vp]),
     "tm_score_hypotheses_early_drop": (C.c_int, [vp, vp, f32p, C.c_uint32, i32p, C.c_uint32,
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
+    "tm_score_hypotheses_early_drop_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, C.c_float,
+                                                     u32p, f64p, i32p, u32p]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
@@ -582,6 +584,19 @@ class Scene:
         _check(lib().tm_score_hypotheses_early_drop(
             self.h, model.h, pP, n, ps, ns, dist_thres, accept_prob, counts.ctypes.data_as(u32p),
             scores.ctypes.data_as(f64p), dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
+        return counts, scores, dropped, saved
+
+    def score_hypotheses_early_drop_ball(self, model, poses16, centers, radius, dist_thres, accept_prob):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        cn, pc = _u(centers)
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        dropped = np.zeros(n, np.int32)
+        saved = np.zeros(n, np.uint32)
+        _check(lib().tm_score_hypotheses_early_drop_ball(self.h, model.h, pP, n, pc, radius, dist_thres, accept_prob,
+                                                         counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p),
+                                                         dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
         return counts, scores, dropped, saved
 
     def icp_accumulate(self, model, pose16, dist_thres):

@@ -26,7 +26,25 @@
 
 namespace tmx {
 
+/* "ball mode": every hypothesis scans its own neighbourhood nn(centre) = radius_search_inclusive(radius,
+ * centre) in ascending index order (what find_in_subset hands to project_, include/impl/scene.hpp:273,326).
+ * Hypotheses name their centre by slot; per slot: membership bits by original index, the number of members
+ * before each 64-bit word, the member list, the subset size and its 18 checkpoints. slot_of_hyp == null
+ * selects the single-subset mode. */
+struct ed_ball {
+    const uint32_t* slot_of_hyp;
+    const unsigned long long* member; /* [slots][mwords] */
+    const uint32_t* wprefix;          /* [slots][mwords] */
+    const uint32_t* S_of_slot;        /* [slots] */
+    const uint32_t* tests_of_slot;    /* [slots][18] */
+    const int32_t* list;              /* [slots][list_stride], ascending */
+    const float4* centre_pos;         /* [slots] xyz of the centre */
+    uint32_t mwords, list_stride;
+    float radius;
+};
+
 struct ed_args {
+    ed_ball ball;
     score_args sc;           /* sref = scene oref (original order) */
     const float4* opos;      /* original order positions */
     const float4* otan;      /* .w = mask */
@@ -87,6 +105,60 @@ __global__ __launch_bounds__(256) void k_ed_tile_active(const float4* __restrict
     if (__ballot(in) && (threadIdx.x & 63) == 0) atomicOr(&tile_bits[t >> 6], 1ull << (t & 63u));
 }
 
+/* membership bits of several balls at once: blockIdx.y = slot */
+__global__ __launch_bounds__(256) void k_ball_members(const float4* __restrict__ opos, uint32_t n,
+                                                      const uint32_t* __restrict__ centres, float r2, uint32_t mwords,
+                                                      unsigned long long* __restrict__ member,
+                                                      float4* __restrict__ centre_pos) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    const float4 C = opos[centres[c]];
+    bool in = false;
+    if (i < n) {
+        float4 p = opos[i];
+        in = len2(make3(p.x, p.y, p.z) - make3(C.x, C.y, C.z)) <= r2;
+    }
+    unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < mwords) member[(size_t)c * mwords + (i >> 6)] = b;
+    if (i == 0) centre_pos[c] = C;
+}
+
+/* exclusive prefix of the word popcounts of one slot (one 1024-thread block per slot) and the total */
+__global__ __launch_bounds__(1024) void k_ball_prefix(const unsigned long long* __restrict__ member, uint32_t mwords,
+                                                      uint32_t* __restrict__ wprefix, uint32_t* __restrict__ S_of_slot) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const unsigned long long* mb = member + (size_t)c * mwords;
+    const uint32_t per = (mwords + 1023) / 1024, w0 = t * per, w1 = min(w0 + per, mwords);
+    uint32_t local = 0;
+    for (uint32_t w = w0; w < w1; ++w) local += (uint32_t)__popcll(mb[w]);
+    s_sum[t] = local;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
+        uint32_t v = t >= off ? s_sum[t - off] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - local;
+    for (uint32_t w = w0; w < w1; ++w) {
+        wprefix[(size_t)c * mwords + w] = run;
+        run += (uint32_t)__popcll(mb[w]);
+    }
+    if (t == 1023) S_of_slot[c] = s_sum[1023];
+}
+
+/* member lists (ascending original index): blockIdx.y = slot */
+__global__ __launch_bounds__(256) void k_ball_list(const unsigned long long* __restrict__ member,
+                                                   const uint32_t* __restrict__ wprefix, uint32_t n, uint32_t mwords,
+                                                   uint32_t list_stride, int32_t* __restrict__ list) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (i >= n) return;
+    const unsigned long long b = member[(size_t)c * mwords + (i >> 6)];
+    if (!((b >> (i & 63u)) & 1ull)) return;
+    const uint32_t pos = wprefix[(size_t)c * mwords + (i >> 6)] + (uint32_t)__popcll(b & ((1ull << (i & 63u)) - 1ull));
+    list[(size_t)c * list_stride + pos] = (int32_t)i;
+}
+
 struct ed_cull {
     const unsigned long long* tile_bits; /* per super-tile: which of its 64 tiles hold subset points */
     const float4* spos;   /* Morton order, w = bits of the original index, x = NaN for masked / non-finite */
@@ -112,11 +184,25 @@ __global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
     const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
     unsigned long long* tb = a.tail_bits + (size_t)hl * a.words;
     unsigned long long* cb = a.corr_bits + (size_t)hl * a.words;
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+    f3 bc = make3(0.f, 0.f, 0.f);
+    if (ball) {
+        float4 C = a.ball.centre_pos[slot];
+        bc = make3(C.x, C.y, C.z);
+    }
+    const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
+    const unsigned long long* member = ball ? a.ball.member + (size_t)slot * a.ball.mwords : nullptr;
+    const uint32_t* wprefix = ball ? a.ball.wprefix + (size_t)slot * a.ball.mwords : nullptr;
     for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kEdChunk) {
         if (wave == 0) {
             const uint32_t u = (t0 >> 6) + lane;
             bool hit = false;
-            if (u * 64u < ca.n_tiles && ca.tile_bits[u]) hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.supers[u]);
+            if (u * 64u < ca.n_tiles && (ball || ca.tile_bits[u])) {
+                float4 sb = ca.supers[u];
+                hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, sb);
+                if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > a.ball.radius + sb.w * 1.00001f + ball_margin);
+            }
             unsigned long long mask = __ballot(hit);
             if (lane == 0) {
                 s_smask = mask;
@@ -128,9 +214,12 @@ __global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
         for (uint32_t r = wave; r < (uint32_t)(kEdChunk / 64); r += 4) {
             if (!((smask >> r) & 1ull)) continue;
             const uint32_t t = t0 + r * 64u + lane;
-            if (t < ca.n_tiles && ((ca.tile_bits[t >> 6] >> lane) & 1ull) &&
-                sphere_hits_box(a.sc, T, rnorm, abs_eps, ca.tiles[t]))
-                s_list[atomicAdd(&s_n, 1u)] = t;
+            if (t < ca.n_tiles && (ball || ((ca.tile_bits[t >> 6] >> lane) & 1ull))) {
+                float4 tbs = ca.tiles[t];
+                bool hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, tbs);
+                if (ball) hit = hit && !(len(make3(tbs.x, tbs.y, tbs.z) - bc) > a.ball.radius + tbs.w * 1.00001f + ball_margin);
+                if (hit) s_list[atomicAdd(&s_n, 1u)] = t;
+            }
         }
         __syncthreads();
         const uint32_t n = s_n;
@@ -138,8 +227,16 @@ __global__ __launch_bounds__(256) void k_ed_bits_culled(ed_args a, ed_cull ca) {
             const uint32_t sidx = s_list[i] * 64u + lane;
             const float4 P = ca.spos[sidx];
             if (!(P.x == P.x)) continue; /* mask_ (:434), non-finite, padding */
-            const uint32_t pos = ca.pos_of_orig[__float_as_uint(P.w)];
-            if (pos == 0xFFFFFFFFu) continue;
+            uint32_t pos;
+            if (ball) { /* position = rank of the point inside its centre's neighbourhood */
+                const uint32_t orig = __float_as_uint(P.w);
+                const unsigned long long mbits = member[orig >> 6];
+                if (!((mbits >> (orig & 63u)) & 1ull)) continue;
+                pos = wprefix[orig >> 6] + (uint32_t)__popcll(mbits & ((1ull << (orig & 63u)) - 1ull));
+            } else {
+                pos = ca.pos_of_orig[__float_as_uint(P.w)];
+                if (pos == 0xFFFFFFFFu) continue;
+            }
             long long fx = 0;
             uint32_t pass = 0;
             bool tail = false;
@@ -164,6 +261,10 @@ struct ed_out {
 __global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accept_thresh,
                                                 const uint32_t* __restrict__ tests) {
     const uint32_t hl = blockIdx.x, lane = threadIdx.x;
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+    const uint32_t S = ball ? a.ball.S_of_slot[slot] : a.S;
+    if (ball) tests = a.ball.tests_of_slot + 18u * slot;
     const unsigned long long* tb = a.tail_bits + (size_t)hl * a.words;
     const unsigned long long* cb = a.corr_bits + (size_t)hl * a.words;
     uint32_t k = 0;           /* next_test */
@@ -203,7 +304,7 @@ __global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accep
             const unsigned long long upto = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
             const uint32_t corrs = corr_before + (lincl - lpc) + (uint32_t)__popcll(lcorr & upto);
             const uint32_t tried = pos + 1;
-            const uint32_t upper = early_drop_upper(tried, a.S, corrs);
+            const uint32_t upper = early_drop_upper(tried, S, corrs);
             if ((float)upper < accept_thresh) { /* reference :500 */
                 dropped = (int32_t)k;
                 drop_count = corrs;
@@ -220,13 +321,13 @@ __global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accep
         if (dropped >= 0) {
             o.counts[a.h0 + hl] = drop_count;
             o.dropped_at[a.h0 + hl] = dropped;
-            o.saved[a.h0 + hl] = a.S - (drop_pos + 1);
+            o.saved[a.h0 + hl] = S - (drop_pos + 1);
             o.limit[a.h0 + hl] = drop_pos;
         } else {
             o.counts[a.h0 + hl] = corr_before;
             o.dropped_at[a.h0 + hl] = -1;
             o.saved[a.h0 + hl] = 0;
-            o.limit[a.h0 + hl] = a.S ? a.S - 1 : 0xFFFFFFFFu;
+            o.limit[a.h0 + hl] = S ? S - 1 : 0xFFFFFFFFu;
         }
     }
 }
@@ -235,11 +336,15 @@ __global__ __launch_bounds__(256) void k_ed_score(ed_args a, const uint32_t* __r
     const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
     const uint32_t hl = blockIdx.y;
     long long fx = 0;
-    if (pos < a.S) {
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+    const uint32_t S = ball ? a.ball.S_of_slot[slot] : a.S;
+    if (pos < S) {
         const uint32_t lim = limit[a.h0 + hl];
         const unsigned long long cw = a.corr_bits[(size_t)hl * a.words + pos / 64];
         if (lim != 0xFFFFFFFFu && pos <= lim && ((cw >> (pos & 63)) & 1ull)) {
-            uint32_t idx = a.subset ? (uint32_t)a.subset[pos] : pos;
+            uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
+                                : (a.subset ? (uint32_t)a.subset[pos] : pos);
             float4 P = a.opos[idx];
             const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
             uint32_t pass = 0;
@@ -250,9 +355,204 @@ __global__ __launch_bounds__(256) void k_ed_score(ed_args a, const uint32_t* __r
     if ((threadIdx.x & 63) == 0 && fx) atomicAdd(&a.sc.scores_fx[a.h0 + hl], (unsigned long long)fx);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused variant: one workgroup does all three passes for its hypothesis with the two bit arrays in LDS
+ * (LDS atomics instead of global ones, no memsets, one launch). Used whenever 2 * words * 8 bytes fit
+ * next to the tile list; the three-kernel path above remains for larger subsets and as the cross-check
+ * (TM_ED_UNFUSED=1).
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kEdFusedChunk = 2048; /* tiles per culling round in the fused kernel: 8 KB of LDS */
+constexpr size_t kEdFusedLdsMax = 48 * 1024; /* dynamic LDS for the two bit arrays: subsets up to 196k points */
+
+__global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out o, float accept_thresh,
+                                                  const uint32_t* __restrict__ tests, const float4* __restrict__ oref) {
+    extern __shared__ unsigned long long s_bits[]; /* [words] in-grid bits, then [words] correspondence bits */
+    __shared__ uint32_t s_list[kEdFusedChunk];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_smask;
+    __shared__ uint32_t s_limit, s_count, s_saved;
+    __shared__ int32_t s_dropped;
+    __shared__ unsigned long long s_fx[4];
+    const uint32_t hl = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* tb = s_bits;
+    unsigned long long* cb = s_bits + a.words;
+    for (uint32_t w = threadIdx.x; w < 2u * a.words; w += 256) s_bits[w] = 0ull;
+    const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                              T.r22 * T.r22);
+    const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+    const uint32_t S = ball ? a.ball.S_of_slot[slot] : a.S;
+    if (ball) tests = a.ball.tests_of_slot + 18u * slot;
+    f3 bc = make3(0.f, 0.f, 0.f);
+    if (ball) {
+        float4 C = a.ball.centre_pos[slot];
+        bc = make3(C.x, C.y, C.z);
+    }
+    const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
+    const unsigned long long* member = ball ? a.ball.member + (size_t)slot * a.ball.mwords : nullptr;
+    const uint32_t* wprefix = ball ? a.ball.wprefix + (size_t)slot * a.ball.mwords : nullptr;
+    /* ---- pass 1: bits ---- */
+    for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kEdFusedChunk) {
+        if (wave == 0) {
+            const uint32_t u = (t0 >> 6) + lane;
+            bool hit = false;
+            if (lane < (uint32_t)(kEdFusedChunk / 64) && u * 64u < ca.n_tiles && (ball || ca.tile_bits[u])) {
+                float4 sb = ca.supers[u];
+                hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, sb);
+                if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > a.ball.radius + sb.w * 1.00001f + ball_margin);
+            }
+            unsigned long long mask = __ballot(hit);
+            if (lane == 0) {
+                s_smask = mask;
+                s_n = 0;
+            }
+        }
+        __syncthreads();
+        const unsigned long long smask = s_smask;
+        for (uint32_t r = wave; r < (uint32_t)(kEdFusedChunk / 64); r += 4) {
+            if (!((smask >> r) & 1ull)) continue;
+            const uint32_t t = t0 + r * 64u + lane;
+            if (t < ca.n_tiles && (ball || ((ca.tile_bits[t >> 6] >> lane) & 1ull))) {
+                float4 tbs = ca.tiles[t];
+                bool hit = sphere_hits_box(a.sc, T, rnorm, abs_eps, tbs);
+                if (ball) hit = hit && !(len(make3(tbs.x, tbs.y, tbs.z) - bc) > a.ball.radius + tbs.w * 1.00001f + ball_margin);
+                if (hit) s_list[atomicAdd(&s_n, 1u)] = t;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        for (uint32_t i = wave; i < n; i += 4) {
+            const uint32_t sidx = s_list[i] * 64u + lane;
+            const float4 P = ca.spos[sidx];
+            if (!(P.x == P.x)) continue; /* mask_ (:434), non-finite, padding */
+            long long fx = 0;
+            uint32_t pass = 0;
+            bool tail = false;
+            const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), sidx, fx, pass, nullptr, &tail);
+            if (!tail) continue; /* only in-grid points need their scan position */
+            const uint32_t orig = __float_as_uint(P.w);
+            uint32_t pos;
+            if (ball) {
+                const unsigned long long mbits = member[orig >> 6];
+                if (!((mbits >> (orig & 63u)) & 1ull)) continue;
+                pos = wprefix[orig >> 6] + (uint32_t)__popcll(mbits & ((1ull << (orig & 63u)) - 1ull));
+            } else {
+                pos = ca.pos_of_orig[orig];
+                if (pos == 0xFFFFFFFFu) continue;
+            }
+            const unsigned long long bit = 1ull << (pos & 63u);
+            atomicOr(&tb[pos >> 6], bit);
+            if (corr) atomicOr(&cb[pos >> 6], bit);
+        }
+        __syncthreads();
+    }
+    /* ---- pass 2: the sequential rule, one wave ---- */
+    if (wave == 0) {
+        uint32_t k = 0, min_pos = 0;
+        if (tests[0] > 0) min_pos = tests[0] - 1;
+        uint32_t corr_before = 0;
+        int32_t dropped = -1;
+        uint32_t drop_count = 0, drop_pos = 0;
+        for (uint32_t w0 = 0; w0 < a.words && dropped < 0; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const unsigned long long tword = w < a.words ? tb[w] : 0ull;
+            const unsigned long long cword = w < a.words ? cb[w] : 0ull;
+            uint32_t pc = (uint32_t)__popcll(cword);
+            uint32_t incl = pc;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t v = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += v;
+            }
+            const uint32_t chunk_end = (w0 + 64) * 64;
+            while (k < 18 && min_pos < chunk_end) {
+                unsigned long long bits = tword;
+                const uint32_t wbase = w * 64;
+                if (min_pos >= wbase + 64)
+                    bits = 0ull;
+                else if (min_pos > wbase)
+                    bits &= ~0ull << (min_pos - wbase);
+                unsigned long long have = __ballot(bits != 0ull);
+                if (!have) break;
+                const int L = __ffsll((long long)have) - 1;
+                const unsigned long long lbits = __shfl(bits, L);
+                const unsigned long long lcorr = __shfl(cword, L);
+                const uint32_t lincl = __shfl(incl, L);
+                const uint32_t lpc = __shfl(pc, L);
+                const int b = __ffsll((long long)lbits) - 1;
+                const uint32_t pos = (w0 + (uint32_t)L) * 64 + (uint32_t)b;
+                const unsigned long long upto = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
+                const uint32_t corrs = corr_before + (lincl - lpc) + (uint32_t)__popcll(lcorr & upto);
+                const uint32_t upper = early_drop_upper(pos + 1, S, corrs);
+                if ((float)upper < accept_thresh) { /* reference :500 */
+                    dropped = (int32_t)k;
+                    drop_count = corrs;
+                    drop_pos = pos;
+                    break;
+                }
+                ++k;
+                min_pos = pos + 1;
+                if (k < 18 && tests[k] > 0 && tests[k] - 1 > min_pos) min_pos = tests[k] - 1;
+            }
+            corr_before += __shfl(incl, 63);
+        }
+        if (lane == 0) {
+            s_dropped = dropped;
+            s_count = dropped >= 0 ? drop_count : corr_before;
+            s_saved = dropped >= 0 ? S - (drop_pos + 1) : 0u;
+            s_limit = dropped >= 0 ? drop_pos : (S ? S - 1 : 0xFFFFFFFFu);
+        }
+    }
+    __syncthreads();
+    /* ---- pass 3: score terms of the correspondences up to the stop position ---- */
+    const uint32_t lim = s_limit;
+    long long fx = 0;
+    if (lim != 0xFFFFFFFFu) {
+        score_args sc = a.sc;
+        sc.sref = oref; /* original order */
+        for (uint32_t pos = threadIdx.x; pos <= lim; pos += 256) {
+            if (!((cb[pos >> 6] >> (pos & 63u)) & 1ull)) continue;
+            const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
+                                      : (a.subset ? (uint32_t)a.subset[pos] : pos);
+            const float4 P = a.opos[idx];
+            uint32_t pass = 0;
+            (void)eval_point(sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) fx += __shfl_down(fx, off);
+    if (lane == 0) s_fx[wave] = (unsigned long long)fx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t h = a.h0 + hl;
+        a.sc.scores_fx[h] = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
+        o.counts[h] = s_count;
+        o.dropped_at[h] = s_dropped;
+        o.saved[h] = s_saved;
+        o.limit[h] = lim;
+    }
+}
+
 }  // namespace tmx
 
 using namespace tmx;
+
+/* brick near-filter for the correspondence part of eval_point (same bound as the scoring kernel): a voxel
+ * whose brick code exceeds code_max has no model point within thres; Euclidean metrics only */
+static void ed_brick_filter(const tm_model* m, float thres, score_args& sc) {
+    sc.bcode = nullptr;
+    sc.code_max = 255u;
+    if (m->metric_kind > TM_TRAITS_PLANE || !(thres >= 0.f)) return;
+    const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
+    const float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
+    const float cm = std::floor((thres + slack) / m->brick_q) + 1.f;
+    if (cm < 255.f) {
+        sc.bcode = m->brick_code.p;
+        sc.code_max = (uint32_t)cm;
+    }
+}
 
 extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const float* poses16,
                                               uint32_t n_hyp, const int32_t* subset, uint32_t n_subset,
@@ -318,6 +618,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     if (subset) ED_HIP(hipMemcpyAsync(d_subset.p, subset, (size_t)S * 4, hipMemcpyHostToDevice, c->stream));
     ED_HIP(hipMemsetAsync(d_fx.p, 0, (size_t)n_hyp * 8, c->stream));
     ed_args a;
+    memset(&a.ball, 0, sizeof a.ball);
     a.sc.spos = nullptr;
     a.sc.sref = s->oref.p;
     a.sc.mpos = m->pos.p;
@@ -372,6 +673,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     }
     ed_args ac = a; /* the culled kernel addresses scene points by their sorted slot */
     ac.sc.sref = s->sref.p;
+    ed_brick_filter(m, dist_thres * m->resolution, ac.sc);
     ed_cull cu;
     cu.spos = s->spos.p;
     cu.tiles = s->tiles.p;
@@ -386,7 +688,15 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     }
     cu.n_tiles = s->n_tiles;
     cu.coord_max = s->coord_max;
-    for (uint32_t h0 = 0; h0 < n_hyp; h0 += chunk) {
+    const size_t fused_lds = 2 * (size_t)words * 8;
+    const bool fused = culled && fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
+    if (fused) { /* bits, walk and score in one kernel, bit arrays in LDS */
+        ac.h0 = 0;
+        hipLaunchKernelGGL(k_ed_fused, dim3(n_hyp), dim3(256), fused_lds, c->stream, ac, cu, o, accept_thresh,
+                           d_tests.p, s->oref.p);
+        ED_HIP(hipGetLastError());
+    }
+    for (uint32_t h0 = 0; h0 < n_hyp && !fused; h0 += chunk) {
         const uint32_t nh = std::min(chunk, n_hyp - h0);
         a.h0 = ac.h0 = h0;
         dim3 grid((S + 255) / 256, nh);
@@ -418,3 +728,166 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     }
     return TM_OK;
 }
+
+extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
+                                                   const uint32_t* centers, float radius, float dist_thres,
+                                                   float accept_prob, uint32_t* counts, double* scores,
+                                                   int32_t* dropped_at, uint32_t* saved) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(counts && scores && dropped_at && saved, TM_ERR_INVALID, "null outputs");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(poses16 && centers, TM_ERR_INVALID, "null poses or centres");
+    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    /* distinct centres -> slots */
+    std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
+        for (uint32_t h = 0; h < n_hyp; ++h) {
+            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
+            order[h] = {centers[h], h};
+        }
+        std::sort(order.begin(), order.end());
+        for (uint32_t k = 0; k < n_hyp; ++k) {
+            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
+            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
+        }
+    }
+    const uint32_t n_slots = (uint32_t)uniq.size();
+    const uint32_t mwords = (s->n + 63) / 64;
+    dbuf<uint32_t>&d_slot = s->ed_slot, &d_cent = s->ed_centres, &d_wprefix = s->ed_wprefix, &d_S = s->ed_S,
+                  &d_tests = s->ed_tests, &d_counts = s->w_counts, &d_saved = s->ed_saved, &d_limit = s->ed_limit;
+    dbuf<unsigned long long>&d_member = s->ed_member, &d_tail = s->ed_tail, &d_corr = s->ed_corr, &d_fx = s->w_scores_fx;
+    dbuf<int32_t>&d_list = s->ed_subset, &d_dropped = s->ed_dropped;
+    dbuf<float>& d_poses = s->w_poses;
+    int rc;
+    if ((rc = d_slot.ensure(n_hyp)) || (rc = d_cent.ensure(n_slots)) || (rc = d_member.ensure((size_t)n_slots * mwords)) ||
+        (rc = d_wprefix.ensure((size_t)n_slots * mwords)) || (rc = d_S.ensure(n_slots)) ||
+        (rc = s->ed_cpos.ensure(n_slots)) || (rc = d_poses.ensure((size_t)n_hyp * 16)) || (rc = d_counts.ensure(n_hyp)) ||
+        (rc = d_saved.ensure(n_hyp)) || (rc = d_limit.ensure(n_hyp)) || (rc = d_dropped.ensure(n_hyp)) ||
+        (rc = d_fx.ensure(n_hyp)) || (rc = d_tests.ensure((size_t)n_slots * 18 + 2)))
+        return rc;
+    TM_HIP_CHECK(hipMemcpyAsync(d_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(d_cent.p, uniq.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_fx.p, 0, (size_t)n_hyp * 8, c->stream));
+    const dim3 grid_n((s->n + 255) / 256, n_slots);
+    hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, d_cent.p, radius * radius,
+                       mwords, d_member.p, s->ed_cpos.p);
+    hipLaunchKernelGGL(k_ball_prefix, dim3(n_slots), dim3(1024), 0, c->stream, d_member.p, mwords, d_wprefix.p, d_S.p);
+    TM_HIP_CHECK(hipGetLastError());
+    std::vector<uint32_t> h_S(n_slots);
+    TM_HIP_CHECK(hipMemcpyAsync(h_S.data(), d_S.p, (size_t)n_slots * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    uint32_t S_max = 0;
+    std::vector<uint32_t> h_tests((size_t)n_slots * 18);
+    for (uint32_t k = 0; k < n_slots; ++k) {
+        S_max = std::max(S_max, h_S[k]);
+        constexpr float step_size = 0.05f; /* reference :422-426 */
+        for (uint32_t i = 0; i < 18; ++i) h_tests[(size_t)k * 18 + i] = (uint32_t)(step_size * (i + 1) * h_S[k]);
+    }
+    const uint32_t list_stride = std::max(1u, S_max);
+    TM_FORWARD(d_list.ensure((size_t)n_slots * list_stride));
+    TM_HIP_CHECK(hipMemcpyAsync(d_tests.p, h_tests.data(), h_tests.size() * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ball_list, grid_n, dim3(256), 0, c->stream, d_member.p, d_wprefix.p, s->n, mwords, list_stride,
+                       d_list.p);
+    TM_HIP_CHECK(hipGetLastError());
+    const uint32_t words = std::max(1u, (S_max + 63) / 64);
+    const uint64_t budget = 256ull << 20; /* bytes per bit array */
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_hyp, budget / ((uint64_t)words * 8)));
+    chunk = std::min(chunk, 65535u);
+    TM_FORWARD(d_tail.ensure((size_t)chunk * words));
+    TM_FORWARD(d_corr.ensure((size_t)chunk * words));
+    ed_args a;
+    a.ball.slot_of_hyp = d_slot.p;
+    a.ball.member = d_member.p;
+    a.ball.wprefix = d_wprefix.p;
+    a.ball.S_of_slot = d_S.p;
+    a.ball.tests_of_slot = d_tests.p;
+    a.ball.list = d_list.p;
+    a.ball.centre_pos = s->ed_cpos.p;
+    a.ball.mwords = mwords;
+    a.ball.list_stride = list_stride;
+    a.ball.radius = radius;
+    a.sc.spos = nullptr;
+    a.sc.spos3 = nullptr;
+    a.sc.sref = s->sref.p; /* the culled kernel addresses scene points by their sorted slot */
+    a.sc.mpos = m->pos.p;
+    a.sc.mpos3 = m->pos3.p;
+    a.sc.mref = m->ref.p;
+    a.sc.vox = m->voxels.p;
+    a.sc.active = nullptr;
+    a.sc.ablate = 0;
+    a.sc.kind = m->metric_kind;
+    a.sc.radius = m->metric_radius;
+    a.sc.dmax = dist_thres * m->resolution;
+    a.sc.bcode = nullptr;
+    a.sc.bx = m->bdim[0];
+    a.sc.by = m->bdim[1];
+    a.sc.code_max = 255u;
+    a.sc.poses = d_poses.p;
+    a.sc.counts = d_counts.p;
+    a.sc.scores_fx = d_fx.p;
+    a.sc.stat_slots = nullptr;
+    a.sc.g = m->grid;
+    a.sc.d2max = sq_threshold(dist_thres * m->resolution);
+    a.sc.n_hyp = n_hyp;
+    a.sc.hyp_per_block = 1;
+    a.opos = s->opos.p;
+    a.otan = s->otan.p;
+    a.subset = nullptr;
+    a.S = S_max;
+    a.words = words;
+    a.tail_bits = d_tail.p;
+    a.corr_bits = d_corr.p;
+    ed_brick_filter(m, dist_thres * m->resolution, a.sc);
+    ed_args as = a; /* k_ed_score addresses scene points by original index */
+    as.sc.sref = s->oref.p;
+    ed_cull cu;
+    cu.tile_bits = nullptr;
+    cu.spos = s->spos.p;
+    cu.tiles = s->tiles.p;
+    cu.supers = s->supers.p;
+    cu.pos_of_orig = nullptr;
+    cu.n_tiles = s->n_tiles;
+    cu.coord_max = s->coord_max;
+    ed_out o;
+    o.counts = d_counts.p;
+    o.dropped_at = d_dropped.p;
+    o.saved = d_saved.p;
+    o.limit = d_limit.p;
+    const float accept_thresh = accept_prob * (float)m->n;
+    const size_t fused_lds = 2 * (size_t)words * 8;
+    const bool fused = fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
+    if (fused) {
+        a.h0 = 0;
+        hipLaunchKernelGGL(k_ed_fused, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh, d_tests.p,
+                           s->oref.p);
+        TM_HIP_CHECK(hipGetLastError());
+    }
+    for (uint32_t h0 = 0; h0 < n_hyp && !fused; h0 += chunk) {
+        const uint32_t nh = std::min(chunk, n_hyp - h0);
+        a.h0 = as.h0 = h0;
+        TM_HIP_CHECK(hipMemsetAsync(d_tail.p, 0, (size_t)nh * words * 8, c->stream));
+        TM_HIP_CHECK(hipMemsetAsync(d_corr.p, 0, (size_t)nh * words * 8, c->stream));
+        hipLaunchKernelGGL(k_ed_bits_culled, dim3(nh), dim3(256), 0, c->stream, a, cu);
+        hipLaunchKernelGGL(k_ed_walk, dim3(nh), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests.p);
+        hipLaunchKernelGGL(k_ed_score, dim3((S_max + 255) / 256, nh), dim3(256), 0, c->stream, as, d_limit.p);
+        TM_HIP_CHECK(hipGetLastError());
+    }
+    std::vector<unsigned long long> fx(n_hyp);
+    TM_HIP_CHECK(hipMemcpyAsync(counts, d_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(saved, d_saved.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(dropped_at, d_dropped.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(fx.data(), d_fx.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (uint32_t h = 0; h < n_hyp; ++h) {
+        double raw = (double)fx[h] * (1.0 / kFx);
+        scores[h] = dropped_at[h] >= 0 ? raw : raw / (double)m->n; /* :502 / :509 */
+    }
+    return TM_OK;
+}
+

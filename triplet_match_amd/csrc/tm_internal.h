@@ -178,7 +178,9 @@ struct tm_scene {
     /* early-drop path (tm_earlydrop.hip) */
     tmx::dbuf<int32_t> ed_subset, ed_dropped;
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
-    tmx::dbuf<unsigned long long> ed_tail, ed_corr, ed_tilebits;
+    tmx::dbuf<unsigned long long> ed_tail, ed_corr, ed_tilebits, ed_member;
+    tmx::dbuf<uint32_t> ed_slot, ed_centres, ed_wprefix, ed_S;
+    tmx::dbuf<float4> ed_cpos;
     tmx::dbuf<unsigned char> w_active_sorted; /* subset flags in sorted order */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */

@@ -925,6 +925,12 @@ int tm_scene_destroy(tm_scene* s) {
     s->ed_tail.release();
     s->ed_corr.release();
     s->ed_tilebits.release();
+    s->ed_member.release();
+    s->ed_slot.release();
+    s->ed_centres.release();
+    s->ed_wprefix.release();
+    s->ed_S.release();
+    s->ed_cpos.release();
     delete s;
     return TM_OK;
 }
