@@ -168,3 +168,22 @@ def test_writer_round_trips_and_errors(exe, tmp_path):
     assert n.strip() == b"0"
     n = subprocess.check_output([exe, "from_pcd", str(tmp_path / "rt_ascii.pcd")])
     assert n.strip() == b"5000"
+
+
+def test_reader_survives_mutated_files(exe, tmp_path):
+    """Byte-flipped and truncated files end in a clean error (exit 3) or a successful read, never a crash."""
+    import random
+    subprocess.check_output([exe, "roundtrip", str(tmp_path)])
+    rnd = random.Random(1)
+    for mode in ("ascii", "binary", "binary_compressed"):
+        data = open(tmp_path / ("rt_%s.pcd" % mode), "rb").read()[:40000]
+        for _ in range(40):
+            b = bytearray(data)
+            for _ in range(rnd.choice([1, 1, 2, 5, 20])):
+                b[rnd.randrange(0, min(len(b), 600 if rnd.random() < 0.6 else len(b)))] = rnd.randrange(256)
+            if rnd.random() < 0.3:
+                b = b[:rnd.randrange(1, len(b))]
+            p = tmp_path / "fuzz.pcd"
+            p.write_bytes(bytes(b))
+            rc = subprocess.call([exe, "dump", str(p), str(tmp_path / "fuzz.raw")], stderr=subprocess.DEVNULL, timeout=60)
+            assert rc in (0, 3), (mode, rc)
