@@ -132,9 +132,9 @@ def main():
         n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
         gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
         best = ctx.best_of_batch(d_counts, d_scores, d_poses, n, id_offset=rank, id_stride=world)
-        if world > 1:  # one 96-byte-per-rank RCCL all-gather + deterministic argmax (tm_best_select)
-            best = tmd.allgather_best(best, device=cuda_dev)
-        return n, best
+        # one 96-byte-per-rank RCCL all-gather + deterministic argmax (tm_best_select); started here, awaited
+        # after the next batch has been launched, so the exchange overlaps that batch's kernels
+        return n, tmd.allgather_best_async(best, device=cuda_dev)
 
     def sync_all():
         if world > 1:
@@ -143,18 +143,23 @@ def main():
         ctx.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        step()[1].result()
     ctx.enable_timing(True)
     kern_ms, evals, passing, hyps = [], 0, 0, 0
     sync_all()
     t_start = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
-        n, best = step()
+        n, nxt = step()
+        if pending is not None:
+            best = pending.result()
+        pending = nxt
         tm_ = ctx.last_score_timing()
         kern_ms.append(tm_["ms"])
         evals += tm_["evaluations"]
         passing += tm_["passing"]
         hyps += n
+    best = pending.result()  # the last exchange completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t_start
     ctx.enable_timing(False)

@@ -49,6 +49,10 @@ def _worker(rank, world, port, out_dir):
     else:
         rec = tmd.empty_record()
     best = tmd.allgather_best(rec)
+    pending = tmd.allgather_best_async(rec)  # what bench.py uses: started now, awaited later
+    best2 = pending.result()
+    assert (best2.inlier_count, best2.hyp_id, best2.score) == (best.inlier_count, best.hyp_id, best.score)
+    assert list(best2.pose) == list(best.pose)
     np.save(os.path.join(out_dir, "best_%d.npy" % rank),
             np.array([best.inlier_count, best.hyp_id, best.score] + list(best.pose), dtype=np.float64))
     np.save(os.path.join(out_dir, "local_%d.npy" % rank),

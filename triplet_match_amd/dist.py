@@ -48,6 +48,38 @@ def allgather_best(rec, device=None, group=None):
     return capi.best_select(recs)
 
 
+class PendingBest:
+    """An all-gather of best records in flight (allgather_best_async); result() waits and selects."""
+
+    def __init__(self, work, gathered, world, local):
+        self._work, self._gathered, self._world, self._local = work, gathered, world, local
+
+    def result(self):
+        if self._work is None:
+            return capi.best_select([self._local])
+        self._work.wait()
+        raw = self._gathered.cpu().numpy().tobytes()
+        recs = [capi.BestRecord.from_buffer_copy(raw[RECORD_BYTES * r:RECORD_BYTES * (r + 1)])
+                for r in range(self._world)]
+        return capi.best_select(recs)
+
+
+def allgather_best_async(rec, device=None, group=None):
+    """Starts the 96-byte-per-rank all-gather and returns at once, so that the next batch's kernels (on the
+    library's own stream) overlap the exchange; call .result() when the global best is needed."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return PendingBest(None, None, 1, rec)
+    local = torch.from_numpy(record_to_bytes(rec))
+    if device is not None:
+        local = local.to(device, non_blocking=True)
+    gathered = torch.empty(RECORD_BYTES * world, dtype=torch.uint8, device=local.device)
+    work = dist.all_gather_into_tensor(gathered, local, group=group, async_op=True)
+    return PendingBest(work, gathered, world, rec)
+
+
 def make_record(count, hyp_id, score, pose16):
     r = capi.BestRecord()
     r.inlier_count = int(count)
