@@ -159,6 +159,8 @@ def main():
         evals += tm_["evaluations"]
         passing += tm_["passing"]
         hyps += n
+    if pending is None:
+        raise SystemExit("--steps must be at least 1")
     best = pending.result()  # the last exchange completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t_start
