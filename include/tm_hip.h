@@ -168,6 +168,13 @@ uint32_t tm_scene_size(const tm_scene* scene);
 int tm_scene_radius_subset(tm_scene* scene, uint32_t center_idx, float radius, int32_t* out, uint32_t cap,
                            uint32_t* count);
 
+/* The same for several centres in one call, with the index lists built on the device (membership bits ->
+ * per-word prefix counts -> ordered scatter): counts[k] = size of the neighbourhood of centers[k],
+ * lists[k * stride + j] its j-th index (ascending). lists may be NULL to get the counts only; stride must
+ * cover the largest neighbourhood (TM_ERR_CAPACITY otherwise). */
+int tm_scene_radius_lists(tm_scene* scene, const uint32_t* centers, uint32_t n_centers, float radius,
+                          int32_t* lists, uint32_t stride, uint32_t* counts);
+
 /* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
  * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same
  * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */

@@ -24,7 +24,6 @@ struct hip_backend {
     uint32_t n_t;
     float diam;
     search::params_t p;
-    std::vector<int32_t> nn_scratch; /* radius_subset output buffer, one slot per scene point */
     std::vector<uint32_t> sc_scratch, mc_scratch; /* extract output buffers */
 
     uint32_t scene_size() const { return (uint32_t)scloud->size(); }
@@ -36,13 +35,48 @@ struct hip_backend {
     bool pair_is_valid_sample(uint32_t i, uint32_t j) const {
         return tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor) != 0;
     }
-    /* radius_search_inclusive(radius, i), include/impl/scene.hpp:273: membership on the device */
+    /* radius_search_inclusive(radius, i), include/impl/scene.hpp:273: the ascending index lists are built on
+     * the device for up to 16 of the announced first points per call (announce_firsts) and handed out when
+     * the loop reaches each point */
+    std::vector<uint32_t> upcoming;   /* first points of the current find_in_subset call */
+    std::vector<int32_t> list_cache;  /* lists of upcoming[cache_lo .. cache_hi), cache_stride apart */
+    std::vector<uint32_t> count_cache;
+    size_t cache_lo = 0, cache_hi = 0, cache_stride = 0;
+    float cache_radius = -1.f;
+    void announce_firsts(const std::vector<uint32_t>& firsts) {
+        upcoming = firsts;
+        cache_lo = cache_hi = 0;
+    }
     void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
-        nn_scratch.resize(scloud->size());
-        uint32_t count = 0;
-        check(tm_scene_radius_subset(s, i, radius, nn_scratch.data(), (uint32_t)nn_scratch.size(), &count),
-              "tm_scene_radius_subset");
-        out.assign(nn_scratch.begin(), nn_scratch.begin() + count);
+        size_t k = cache_lo;
+        while (k < cache_hi && upcoming[k] != i) ++k;
+        if (k >= cache_hi || cache_radius != radius) { /* not cached: fetch i and the firsts that follow it */
+            size_t pos = 0;
+            while (pos < upcoming.size() && upcoming[pos] != i) ++pos;
+            std::vector<uint32_t> batch;
+            if (pos < upcoming.size()) {
+                for (size_t q = pos; q < upcoming.size() && batch.size() < 16; ++q) batch.push_back(upcoming[q]);
+                cache_lo = pos;
+            } else { /* a point that was not announced */
+                batch.push_back(i);
+                upcoming.assign(1, i);
+                cache_lo = 0;
+            }
+            cache_hi = cache_lo + batch.size();
+            cache_radius = radius;
+            count_cache.assign(batch.size(), 0u);
+            check(tm_scene_radius_lists(s, batch.data(), (uint32_t)batch.size(), radius, nullptr, 0, count_cache.data()),
+                  "tm_scene_radius_lists");
+            cache_stride = 1;
+            for (uint32_t cnt : count_cache) cache_stride = std::max<size_t>(cache_stride, cnt);
+            if (list_cache.size() < batch.size() * cache_stride) list_cache.resize(batch.size() * cache_stride);
+            check(tm_scene_radius_lists(s, batch.data(), (uint32_t)batch.size(), radius, list_cache.data(),
+                                        (uint32_t)cache_stride, count_cache.data()),
+                  "tm_scene_radius_lists");
+            k = cache_lo;
+        }
+        const int32_t* src = list_cache.data() + (k - cache_lo) * cache_stride;
+        out.assign(src, src + count_cache[k - cache_lo]);
     }
     void generate(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses) {
         const uint32_t n_pairs = (uint32_t)(ij.size() / 2);

@@ -69,6 +69,7 @@ struct params_t {
  *   uint32_t scene_size(); uint32_t model_size(); uint32_t model_point_count(); float model_diameter();
  *   const float* scene_surfel(uint32_t i);            // 12 floats
  *   bool pair_is_valid_sample(uint32_t i, uint32_t j);// filters :290-297 + feature/valid :299-302
+ *   void announce_firsts(const std::vector<uint32_t>& firsts); // the points radius_subset will be asked for, in order
  *   void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out);
  *   void generate(const std::vector<uint32_t>& ij, std::vector<pose_t>& poses);   // visit order
  *   void score(const std::vector<pose_t>& poses, const std::vector<int32_t>& subset, bool early_drop,
@@ -233,6 +234,12 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         batch_ij.clear();
     };
     uint32_t firsts_in_batch = 0;
+    {
+        std::vector<uint32_t> live; /* the first points the loop will actually look at (:268) */
+        for (uint32_t i : firsts)
+            if (!fp_mask[i] && !mask[i]) live.push_back(i);
+        be.announce_firsts(live);
+    }
     for (uint32_t i : firsts) {
         if (fp_mask[i] || mask[i]) continue; /* :268 */
         ++cons;

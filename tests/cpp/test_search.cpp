@@ -54,6 +54,7 @@ struct oracle_backend {
     void generate_with_pairs(const std::vector<uint32_t>&, std::vector<search::pose_t>&, std::vector<uint32_t>&) {}
     void score_ball(const std::vector<search::pose_t>&, const std::vector<uint32_t>&, float, bool, std::vector<uint32_t>&,
                     std::vector<double>&) {}
+    void announce_firsts(const std::vector<uint32_t>&) {}
     void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
         uint32_t n = tmo_scene_radius_subset(s, i, radius, nullptr, 0);
         out.resize(n);

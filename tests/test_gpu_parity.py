@@ -810,3 +810,14 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
         finally:
             gs.set_mask(None)
             os_.set_mask(None)
+
+
+def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
+    gs, os_ = gpu_small["scene"], oracle_small["scene"]
+    diam = oracle_small["model"].diameter
+    rng = np.random.default_rng(23)
+    centers = rng.integers(0, gs.n, 11).astype(np.uint32)
+    for r in (diam, 0.0):
+        lists = gs.radius_lists(centers, r)
+        for k, c in enumerate(centers):
+            assert np.array_equal(lists[k], os_.radius_subset(int(c), r))

@@ -83,6 +83,7 @@ SIGNATURES = {
     "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
     "tm_scene_download": (C.c_int, [vp, f32p, i32p]),
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
+    "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
@@ -513,6 +514,16 @@ class Scene:
         _check(lib().tm_scene_radius_subset(self.h, center_idx, radius, out.ctypes.data_as(i32p), out.size,
                                             C.byref(cnt)))
         return out
+
+    def radius_lists(self, centers, radius):
+        cn, pc = _u(centers)
+        counts = np.zeros(cn.size, np.uint32)
+        _check(lib().tm_scene_radius_lists(self.h, pc, cn.size, radius, None, 0, counts.ctypes.data_as(u32p)))
+        stride = max(int(counts.max()) if cn.size else 0, 1)
+        lists = np.zeros((cn.size, stride), np.int32)
+        _check(lib().tm_scene_radius_lists(self.h, pc, cn.size, radius, lists.ctypes.data_as(i32p), stride,
+                                           counts.ctypes.data_as(u32p)))
+        return [lists[k, :counts[k]].copy() for k in range(cn.size)]
 
     def generate_hypotheses(self, model, ij_pairs, min_diameter_factor=0.2,
                             max_diameter_factor=1.0, force_up=False, query_limit=200, cap=None):

@@ -891,3 +891,46 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
     return TM_OK;
 }
 
+/* radius_search_inclusive for several centres with the index lists built on the device: membership bits,
+ * per-word prefix counts and an ordered scatter (the kernels of the ball mode above); only counts[k] indices
+ * per centre travel back. */
+extern "C" int tm_scene_radius_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
+                                     int32_t* lists, uint32_t stride, uint32_t* counts) {
+    TM_REQUIRE(s && counts && (centers || n_centers == 0), TM_ERR_INVALID, "tm_scene_radius_lists: null argument");
+    if (n_centers == 0) return TM_OK;
+    for (uint32_t k = 0; k < n_centers; ++k)
+        TM_REQUIRE(centers[k] < s->n, TM_ERR_INVALID, "tm_scene_radius_lists: centre index out of range");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t mwords = (s->n + 63) / 64;
+    TM_FORWARD(s->ed_centres.ensure(n_centers));
+    TM_FORWARD(s->ed_member.ensure((size_t)n_centers * mwords));
+    TM_FORWARD(s->ed_wprefix.ensure((size_t)n_centers * mwords));
+    TM_FORWARD(s->ed_S.ensure(n_centers));
+    TM_FORWARD(s->ed_cpos.ensure(n_centers));
+    TM_HIP_CHECK(hipMemcpyAsync(s->ed_centres.p, centers, (size_t)n_centers * 4, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid_n((s->n + 255) / 256, n_centers);
+    hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, s->ed_centres.p,
+                       radius * radius, mwords, s->ed_member.p, s->ed_cpos.p);
+    hipLaunchKernelGGL(k_ball_prefix, dim3(n_centers), dim3(1024), 0, c->stream, s->ed_member.p, mwords,
+                       s->ed_wprefix.p, s->ed_S.p);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipMemcpyAsync(counts, s->ed_S.p, (size_t)n_centers * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!lists) return TM_OK; /* counts only */
+    uint32_t S_max = 0;
+    for (uint32_t k = 0; k < n_centers; ++k) S_max = std::max(S_max, counts[k]);
+    TM_REQUIRE(stride >= S_max, TM_ERR_CAPACITY, "tm_scene_radius_lists: stride smaller than a neighbourhood");
+    if (S_max == 0) return TM_OK;
+    TM_FORWARD(s->ed_subset.ensure((size_t)n_centers * S_max));
+    hipLaunchKernelGGL(k_ball_list, grid_n, dim3(256), 0, c->stream, s->ed_member.p, s->ed_wprefix.p, s->n, mwords,
+                       S_max, s->ed_subset.p);
+    TM_HIP_CHECK(hipGetLastError());
+    for (uint32_t k = 0; k < n_centers; ++k)
+        if (counts[k])
+            TM_HIP_CHECK(hipMemcpyAsync(lists + (size_t)k * stride, s->ed_subset.p + (size_t)k * S_max,
+                                        (size_t)counts[k] * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
