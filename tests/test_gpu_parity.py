@@ -1,7 +1,7 @@
 """GPU parity tests proper: every call goes through the C ABI (libtm_hip.so) and is compared with
 the CPU oracle on the same seeded inputs. Bar: bit-exact for keys, hashes, table contents, voxel
 indices, inlier counts, correspondences and (here) poses; scores (fp64 sums of fp32 terms,
-order-free fixed-point accumulation on the GPU) to 1e-9 relative."""
+order-free fixed-point accumulation on the GPU) to 1e-9 relative plus 2^-40 per summed term (raw early-drop sums can be tiny)."""
 import os
 
 import numpy as np
@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 DT = 3.0
 SCORE_RTOL = 1e-9
+SCORE_ATOL_PER_TERM = 1e-12  # each term is truncated to 2^-40 fixed point before the integer sum
 
 
 def bits(a):
@@ -251,7 +252,7 @@ def test_early_drop_rule_bit_exact(gpu_small, oracle_small, small_case):
             assert vg[h] == saved
             if saved > 0:
                 assert dg[h] >= 0
-            assert abs(sg[h] - score) <= SCORE_RTOL * max(abs(score), 1e-30)
+            assert abs(sg[h] - score) <= SCORE_RTOL * abs(score) + SCORE_ATOL_PER_TERM * max(1, len(sc))
             n_dropped += dg[h] >= 0
             n_kept += dg[h] < 0
     assert n_dropped > 50 and n_kept > 50  # both outcomes are exercised
@@ -805,7 +806,7 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
                 for h in sel[:12]:
                     sc, mc, score, saved = os_.project(om, poses[h], 0.5, DT, subset=nn, early_out=True)
                     assert cb[h] == len(sc) and vb[h] == saved
-                    assert abs(sb[h] - score) <= SCORE_RTOL * max(abs(score), 1e-30)
+                    assert abs(sb[h] - score) <= SCORE_RTOL * abs(score) + SCORE_ATOL_PER_TERM * max(1, len(sc))
             assert (db >= 0).any() and (db < 0).any()
         finally:
             gs.set_mask(None)
