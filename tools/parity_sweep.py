@@ -95,6 +95,86 @@ def one_case(ctx, seed):
     return "ok (%d model, %d scene, %d hyps, best %d)" % (n_model, n_scene, len(po), int(co.max()))
 
 
+def traits_case(ctx, seed):
+    """projector metrics: cylinder on a small pipe plant / plane2 on a small room, device-resident projection,
+    generation and scoring (culled and exhaustive) against the oracle"""
+    rng = np.random.default_rng(seed)
+    if seed % 2 == 0:
+        K = capi.CYLINDER
+        n_model = int(rng.integers(1500, 5000))
+        model, _ = synth.synth_pipe_section(n_model, seed=seed)
+        sc = synth.synth_pipe_plant(int(rng.integers(20000, 50000)), n_model, seed=seed + 1,
+                                    noise_sigma=float(rng.choice([0.0, 0.002])))
+        S, tm = sc["surfels"], sc["tangent_mask"]
+        on = np.nonzero(sc["pipe_id"] == int(rng.integers(0, 3)))[0]
+        msel = [0, int(np.argmin(np.abs(model[:, 4:7] @ model[0, 4:7])))]
+        a = int(on[rng.integers(len(on))])
+        ssel = [a, int(on[np.argmin(np.abs(S[on, 4:7] @ S[a, 4:7]))])]
+        thr = 0.05
+    else:
+        K = capi.PLANE2
+        n_model = int(rng.integers(800, 3000))
+        model, _ = synth.synth_wall_panel(n_model, seed=seed)
+        sc = synth.synth_indoor(int(rng.integers(30000, 80000)), n_model, seed=seed + 1)
+        S, tm = sc["surfels"], sc["tangent_mask"]
+        on = np.nonzero(sc["wall_id"] == int(rng.integers(0, 3)))[0]
+        msel = [0, int(np.argmax(np.linalg.norm(model[:, 0:3] - model[0, 0:3], axis=1))), n_model // 2]
+        ssel = [int(on[0]), int(on[np.argmax(np.linalg.norm(S[on, 0:3] - S[on[0], 0:3], axis=1))]), int(on[len(on) // 2])]
+        thr = 0.05
+    ms = np.zeros(capi.STATE_FLOATS, np.float32)
+    ms[1] = thr
+    mstate = capi.traits_init_from_samples(K, ms, np.concatenate([model[i] for i in msel]))
+    sstate = capi.traits_init_from_samples(K, ms, np.concatenate([S[i] for i in ssel]))
+    if mstate is None or sstate is None:
+        return "samples rejected"
+    radius = float(mstate[0]) if K == capi.CYLINDER else 0.0
+    gs = capi.Scene(ctx, S, tm)
+    gp = gs.project(K, sstate)
+    su, tmask = gp.download()
+    smp = rng.integers(0, len(S), 300)
+    for i in smp:
+        uvw = tmo.traits_project(K, sstate, S[i, 0:3])
+        assert (uvw is None) == bool(np.isnan(su[i, 0])), "project validity"
+        if uvw is not None:
+            assert np.array_equal(bits(su[i, 0:3]), bits(uvw)), "project"
+    mu, mv = ctx.traits_project_cloud(K, mstate, model)
+    mu = mu[mv == 1]
+    if len(mu) < 100:
+        return "model projected away"
+    res = synth.resolution(mu)
+    subset = np.nonzero(np.linalg.norm(mu[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+    gm = capi.Model(ctx, mu, res)
+    gm.set_metric(K, radius)
+    gm.build_voxels()
+    om = tmo.Model(mu, res)
+    om.set_metric(K, radius)
+    om.build_voxels(threads=8)
+    assert np.array_equal(gm.voxels(), om.voxels()), "voxels"
+    try:
+        gm.build_pairs(subset)
+    except capi.TmError:
+        assert om.build_pairs(subset) != 0
+        return "empty table"
+    assert om.build_pairs(subset) == 0
+    os_ = tmo.Scene(su, tmask)
+    near = tmask * (np.abs(np.nan_to_num(su[:, 2], nan=1e9)) < (thr / radius if radius else thr))
+    pairs = synth.sample_scene_pairs(dict(surfels=np.nan_to_num(su), tangent_mask=near), gm.diameter, 20, 3, seed=seed)
+    if len(pairs) == 0:
+        return "no pairs"
+    pg, vg, total = gp.generate_hypotheses(gm, pairs)
+    po, vo = os_.generate_hypotheses(om, pairs)
+    assert total == len(po) and np.array_equal(vg, vo) and np.array_equal(bits(pg), bits(po)), "generate"
+    if len(po) == 0:
+        return "no hypotheses"
+    poses = po[:300]
+    co, so, _ = os_.score_hypotheses(om, poses, 0.5, 3.0, threads=8)
+    for mode in (capi.SCORE_CULLED, capi.SCORE_BRUTEFORCE):
+        cg, sg = gp.score_hypotheses(gm, poses, 3.0, traits=K, mode=mode)
+        assert np.array_equal(cg, co), "traits counts mode %d" % mode
+        assert np.allclose(sg, so, rtol=1e-9, atol=1e-12), "traits scores"
+    return "ok traits %d (%d hyps, best %d)" % (K, len(po), int(co.max()))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -102,7 +182,7 @@ def main():
     bad = 0
     for k in range(n):
         try:
-            msg = one_case(ctx, seed0 + 7 * k)
+            msg = traits_case(ctx, seed0 + 7 * k) if os.environ.get("TM_SWEEP_TRAITS") else one_case(ctx, seed0 + 7 * k)
         except AssertionError as e:
             bad += 1
             msg = "MISMATCH: %s" % e
