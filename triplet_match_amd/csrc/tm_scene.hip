@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
         bc = make3(C.x, C.y, C.z);
     }
     const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
-    for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kCullChunk) {
+    /* a hypothesis may be split over gridDim.y workgroups that take the culling rounds in turn: the counts
+     * and fixed-point sums are integers, so the parts simply add up (atomics, order-free) */
+    for (uint32_t t0 = blockIdx.y * kCullChunk; t0 < ca.n_tiles; t0 += kCullChunk * gridDim.y) {
         /* level 1: the chunk's 64 super-tiles (64 tiles each), one lane each, wave 0 */
         if (wave == 0) {
             const uint32_t u = (t0 >> 6) + lane;
@@ -314,11 +316,24 @@ __global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.counts[h] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-        a.scores_fx[h] = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
-        a.stat_slots[h] = make_uint4((uint32_t)(tiles_done * 16ull), (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]),
-                                     (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]),
-                                     (s_near[0] + s_near[1]) + (s_near[2] + s_near[3]));
+        const uint32_t c_all = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        const unsigned long long f_all = (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]);
+        const uint4 st = make_uint4((uint32_t)(tiles_done * 16ull), (s_pass[0] + s_pass[1]) + (s_pass[2] + s_pass[3]),
+                                    (s_in[0] + s_in[1]) + (s_in[2] + s_in[3]),
+                                    (s_near[0] + s_near[1]) + (s_near[2] + s_near[3]));
+        if (gridDim.y == 1) {
+            a.counts[h] = c_all;
+            a.scores_fx[h] = f_all;
+            a.stat_slots[h] = st;
+        } else { /* outputs were zeroed by the host */
+            if (c_all) atomicAdd(&a.counts[h], c_all);
+            if (f_all) atomicAdd(&a.scores_fx[h], f_all);
+            uint32_t* sp = reinterpret_cast<uint32_t*>(&a.stat_slots[h]);
+            if (st.x) atomicAdd(sp, st.x);
+            if (st.y) atomicAdd(sp + 1, st.y);
+            if (st.z) atomicAdd(sp + 2, st.z);
+            if (st.w) atomicAdd(sp + 3, st.w);
+        }
     }
 }
 
@@ -697,14 +712,21 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                                s->d_order.p, s->n, s->n_sorted, s->w_active_sorted.p);
             ca.active_sorted = s->w_active_sorted.p;
         }
+        /* split every hypothesis over `parts` workgroups (rounds of 1024 tiles taken in turn): shorter
+         * workgroups even out the tail of the launch; TM_SCORE_PARTS overrides (1 = no split) */
+        uint32_t parts = 2;
+        if (const char* e = getenv("TM_SCORE_PARTS")) parts = (uint32_t)std::max(1, atoi(e));
+        parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (s->n_tiles + kCullChunk - 1) / kCullChunk));
+        if (parts > 1) TM_HIP_CHECK(hipMemsetAsync(s->w_stats.p, 0, n_slots * sizeof(uint4), c->stream));
+        const dim3 cgrid(n_hyp, parts);
         if (l2 && !d_active)
-            hipLaunchKernelGGL((k_score_culled<true, false>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+            hipLaunchKernelGGL((k_score_culled<true, false>), cgrid, dim3(256), 0, c->stream, a, ca);
         else if (l2)
-            hipLaunchKernelGGL((k_score_culled<true, true>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+            hipLaunchKernelGGL((k_score_culled<true, true>), cgrid, dim3(256), 0, c->stream, a, ca);
         else if (!d_active)
-            hipLaunchKernelGGL((k_score_culled<false, false>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+            hipLaunchKernelGGL((k_score_culled<false, false>), cgrid, dim3(256), 0, c->stream, a, ca);
         else
-            hipLaunchKernelGGL((k_score_culled<false, true>), dim3(n_hyp), dim3(256), 0, c->stream, a, ca);
+            hipLaunchKernelGGL((k_score_culled<false, true>), cgrid, dim3(256), 0, c->stream, a, ca);
     } else if (d_active) {
         hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
     } else {
