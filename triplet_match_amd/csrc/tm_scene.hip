@@ -122,7 +122,7 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
  * intrinsic_distance can be small where the Euclidean one is not) only the sphere-vs-box test culls.
  * SUBSET = only the points flagged in ca.active_sorted (sorted order) take part. */
 template <bool L2, bool SUBSET>
-__global__ __launch_bounds__(256) void k_score_culled(score_args a, cull_args ca) {
+__global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args ca) {
     __shared__ uint32_t s_list[4 * kCullChunk]; /* surviving sub-tiles (16 points each) of the round */
     __shared__ uint32_t s_tiles[kCullChunk];    /* surviving tiles of the round */
     __shared__ uint32_t s_n, s_nt;
@@ -714,7 +714,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         }
         /* split every hypothesis over `parts` workgroups (rounds of 1024 tiles taken in turn): shorter
          * workgroups even out the tail of the launch; TM_SCORE_PARTS overrides (1 = no split) */
-        uint32_t parts = 2;
+        uint32_t parts = 3;
         if (const char* e = getenv("TM_SCORE_PARTS")) parts = (uint32_t)std::max(1, atoi(e));
         parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (s->n_tiles + kCullChunk - 1) / kCullChunk));
         if (parts > 1) TM_HIP_CHECK(hipMemsetAsync(s->w_stats.p, 0, n_slots * sizeof(uint4), c->stream));
