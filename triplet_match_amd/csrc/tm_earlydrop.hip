@@ -513,13 +513,21 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     if (lim != 0xFFFFFFFFu) {
         score_args sc = a.sc;
         sc.sref = oref; /* original order */
-        for (uint32_t pos = threadIdx.x; pos <= lim; pos += 256) {
-            if (!((cb[pos >> 6] >> (pos & 63u)) & 1ull)) continue;
-            const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
-                                      : (a.subset ? (uint32_t)a.subset[pos] : pos);
-            const float4 P = a.opos[idx];
-            uint32_t pass = 0;
-            (void)eval_point(sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+        /* one correspondence word per thread and turn: the set bits are spread evenly because the scan
+         * order (ascending scene index) is unrelated to space */
+        const uint32_t w_last = lim >> 6;
+        for (uint32_t w = threadIdx.x; w <= w_last; w += 256) {
+            unsigned long long bitsw = cb[w];
+            if (w == w_last && (lim & 63u) != 63u) bitsw &= (2ull << (lim & 63u)) - 1ull;
+            while (bitsw) {
+                const uint32_t pos = w * 64u + (uint32_t)__builtin_ctzll(bitsw);
+                bitsw &= bitsw - 1ull;
+                const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
+                                          : (a.subset ? (uint32_t)a.subset[pos] : pos);
+                const float4 P = a.opos[idx];
+                uint32_t pass = 0;
+                (void)eval_point(sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) fx += __shfl_down(fx, off);
