@@ -154,3 +154,22 @@ def test_no_device_fails_loudly():
         capi.Context(0)
     assert e.value.code == capi.ERR_NO_DEVICE
     assert "no CPU fallback" in str(e.value)
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """include/tm_hip.h is consumed by a C99 translation unit (-pedantic); without a GPU the library answers
+    TM_ERR_NO_DEVICE with its "no CPU fallback" message instead of computing anything."""
+    import subprocess
+    from triplet_match_amd import build as tm_build
+    tm_build.build()
+    exe = str(tmp_path / "abi_c99")
+    libdir = os.path.join(ROOT, "triplet_match_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_c99.c"), "-o", exe, "-L" + libdir, "-ltm_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([exe]).decode()
+    import torch
+    if not torch.cuda.is_available():
+        assert out.startswith("-6 ") and "no CPU fallback" in out
+    else:
+        assert out.startswith("0 ")
