@@ -173,3 +173,26 @@ def test_header_is_plain_c99_and_links_from_c(tmp_path):
         assert out.startswith("-6 ") and "no CPU fallback" in out
     else:
         assert out.startswith("0 ")
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under triplet_match_amd/ or include/ includes, imports or links the oracle; the shared library has
+    no dependency on it."""
+    import re
+    import subprocess
+    offenders = []
+    for base in ("triplet_match_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r'#include\s*[<"][^>"]*oracle|tm_oracle|libtm_oracle|from oracle|import oracle|tmo_[a-z]', text):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    from triplet_match_amd import build as tm_build
+    lib = tm_build.build()
+    deps = subprocess.check_output(["ldd", lib]).decode()
+    assert "oracle" not in deps
+    syms = subprocess.check_output(["nm", "-D", lib]).decode()
+    assert "tmo_" not in syms
