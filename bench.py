@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--mode", choices=["auto", "brute", "culled"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sub-figures measured after the headline region (profiling passes)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the 96-byte exchange goes "
                          "over gloo (RCCL refuses two ranks on one device); not a measurement")
@@ -144,8 +146,11 @@ def main():
 
     for _ in range(args.warmup):
         step()[1].result()
+    # kernel timing = HIP events recorded on the library's own stream around each scoring launch, and the
+    # kernel's own counters reduced on the device; both are read AFTER the timed region (no host
+    # synchronisation or copy inside it)
     ctx.enable_timing(True)
-    kern_ms, evals, passing, hyps = [], 0, 0, 0
+    hyps = 0
     sync_all()
     t_start = time.perf_counter()
     pending = None
@@ -154,17 +159,17 @@ def main():
         if pending is not None:
             best = pending.result()
         pending = nxt
-        tm_ = ctx.last_score_timing()
-        kern_ms.append(tm_["ms"])
-        evals += tm_["evaluations"]
-        passing += tm_["passing"]
         hyps += n
     if pending is None:
         raise SystemExit("--steps must be at least 1")
     best = pending.result()  # the last exchange completes inside the timed region
     sync_all()
     elapsed = time.perf_counter() - t_start
+    tot = ctx.score_timing_totals()
     ctx.enable_timing(False)
+    if tot["launches"] != args.steps:
+        log("warning: %d timed scoring launches for %d steps" % (tot["launches"], args.steps))
+    evals, passing = tot["evaluations"], tot["passing"]
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cuda_dev)
@@ -177,30 +182,54 @@ def main():
         hyps_all, evals_all = float(hyps), float(evals)
 
     value = hyps_all / elapsed
-    # roofline of the dominant kernel (inlier scoring), rank 0's launches:
-    # algorithmic bytes per launch = 40*E + 32*P + 64*H
-    k_ms = float(np.mean(kern_ms))
-    E, P, Hh = evals / args.steps, passing / args.steps, hyps / args.steps
+    # roofline of the dominant kernel (inlier scoring), rank 0's launches, per launch:
+    #   formula  = BASELINE.md section 3: 40*E + 32*P + 64*H (E = evaluations the kernel performed)
+    #   physical = the bytes those evaluations really request: 12 B scene xyz per evaluation, 1 B brick code
+    #              per in-grid point, 4 B voxel + 12 B model xyz per near point, 16 + 16 B orientation
+    #              records per distance-passing point, 64 B pose per hypothesis
+    L = max(1, tot["launches"])
+    k_ms = tot["ms"] / L
+    E, P, Hh = evals / L, passing / L, hyps / args.steps
+    N_in, N_near = tot["in_grid"] / L, tot["near"] / L
     alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
+    phys_bytes = 12.0 * E + 1.0 * N_in + 16.0 * N_near + 32.0 * P + 64.0 * Hh
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = measured_traffic(args)
+    achieved_phys = phys_bytes / (k_ms * 1e-3) / 1e9
+    pmc = measured_traffic(args)
+    traffic = pmc["hbm_bytes_per_launch"] if pmc else None
     copy_gbs = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
+    frac_formula = achieved / HBM_PEAK_GBS
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # a fraction above 1 means the 40-B price over-charges evaluations that stop at the in-grid
+                # test; such a figure is not evidence, so the physical model takes its place
+                "frac": round(frac_formula if frac_formula <= 1.0 else achieved_phys / HBM_PEAK_GBS, 4),
+                "frac_basis": "baseline_formula_40E+32P+64H" if frac_formula <= 1.0 else "physical_model",
+                "traffic": traffic,
                 "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
+                "in_grid_per_launch": N_in, "near_per_launch": N_near,
                 "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes,
-                "measured_copy_GBs": copy_gbs,
-                "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None}
+                "physical_bytes_per_launch": phys_bytes,
+                "achieved_physical": round(achieved_phys, 1),
+                "frac_physical": round(achieved_phys / HBM_PEAK_GBS, 4),
+                "measured_copy_GBs": copy_gbs}
+    if pmc:  # counters of the profiled build (same sources: the hash is checked), scaled by this run's time
+        roofline["frac_measured_hbm"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["pmc"] = {k: pmc[k] for k in ("source", "l2_fabric_read_requests", "l2_fabric_read_128B",
+                                               "tcp_cache_accesses", "l1_frac_of_peak_at_profiled_ms")
+                           if k in pmc}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp,
                                         DIST_THRES, ACCEPT_PROB)
 
+    if rank == 0 and cpu_baseline is not None and not cpu_baseline["gpu_counts_equal_oracle_on_sample"]:
+        log("FATAL: the GPU's inlier counts differ from the oracle's on the sampled hypotheses; no value is reported")
+        value = None
     if rank == 0:
         out = {
             "metric": "scored RANSAC hypotheses/sec (1M-pt scene); inlier-score Gpoints/sec in gpoints_per_s",
-            "value": round(value, 1), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1) if value is not None else None, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -217,6 +246,10 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+        if value is None:
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -246,19 +279,31 @@ def measured_copy_bandwidth(torch, local_rank):
         return None
 
 
+def source_hash():
+    """SHA-256 over the sources of the scoring kernel: a PMC file is only quoted for the build it profiled."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tm_scene.hip", "tm_score.h", "tm_math.h", "tm_table.h"):
+        h.update(open(os.path.join(ROOT, "triplet_match_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(args):
-    """HBM bytes per scoring launch from the committed PMC passes (profiles/r01/traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied);
-    null when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    """HBM bytes per scoring launch from the committed PMC passes (profiles/r02/traffic.json, written by
+    tools/make_traffic_json.py from separate rocprofv3 --pmc runs of this same command). Null when the
+    workload differs from the profiled one or the kernel sources changed since."""
+    path = os.path.join(ROOT, "profiles", "r02", "traffic.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
         return None
     w = t.get("workload", {})
+    if t.get("source_hash") != source_hash():
+        log("profiles/r02/traffic.json was taken on other kernel sources: roofline.traffic = null")
+        return None
     if (w.get("model_points") == args.model_points and w.get("scene_points") == args.scene_points
             and w.get("hyp_per_batch") == args.hyp_per_batch and w.get("mode") == args.mode):
-        return t.get("traffic_bytes_per_launch")
+        return t
     return None
 
 

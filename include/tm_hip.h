@@ -61,10 +61,17 @@ int tm_device_alloc(tm_ctx* ctx, uint64_t bytes, void** d_ptr);
 int tm_device_free(tm_ctx* ctx, void* d_ptr);
 int tm_memcpy_h2d(tm_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
-/* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline) */
+/* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline). While timing is
+ * on, every scoring launch records an event pair and one row of device counters; nothing is copied to the
+ * host and nothing synchronises until one of the two read-out calls below (they synchronise the stream).
+ * tm_ctx_enable_timing(ctx, 1) opens a new measurement window (the totals start from zero). */
 int tm_ctx_enable_timing(tm_ctx* ctx, int on);
+/* the most recent timed launch */
 int tm_ctx_last_score_timing(tm_ctx* ctx, float* ms, uint64_t* evaluations, uint64_t* passing,
                              uint64_t* hypotheses);
+/* sums over the window's launches (the last 256 at most): totals5 = evaluations, distance-passing,
+ * in-grid, near (in-grid and brick code within reach), hypotheses */
+int tm_ctx_score_timing_totals(tm_ctx* ctx, uint32_t* launches, float* total_ms, uint64_t totals5[5]);
 
 /* ---- scalar descriptor functions, host side ----
  * replace: feature() include/impl/feature.hpp:16-34; discretize() x2 src/discretize.cpp:20-30;

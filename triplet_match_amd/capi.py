@@ -46,6 +46,7 @@ SIGNATURES = {
     "tm_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "tm_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
     "tm_ctx_last_score_timing": (C.c_int, [vp, f32p, u64p, u64p, u64p]),
+    "tm_ctx_score_timing_totals": (C.c_int, [vp, u32p, f32p, u64p]),
     "tm_murmur3_32": (C.c_uint32, [u32p, C.c_int, C.c_uint32]),
     "tm_hash_key": (C.c_uint32, [u32p, C.c_int]),
     "tm_discretize_range": (C.c_uint32, [C.c_float, C.c_float, C.c_float, C.c_uint32]),
@@ -255,6 +256,15 @@ class Context:
         _check(lib().tm_ctx_last_score_timing(self.h, C.byref(ms), C.byref(ev), C.byref(ps),
                                               C.byref(hy)))
         return dict(ms=ms.value, evaluations=ev.value, passing=ps.value, hypotheses=hy.value)
+
+    def score_timing_totals(self):
+        """Sums over the scoring launches since enable_timing(True): kernel ms (HIP events on the library's
+        stream) and the kernels' own counters. Synchronises the stream."""
+        n, ms = C.c_uint32(0), C.c_float(0)
+        tot = (C.c_uint64 * 5)()
+        _check(lib().tm_ctx_score_timing_totals(self.h, C.byref(n), C.byref(ms), tot))
+        return dict(launches=n.value, ms=ms.value, evaluations=tot[0], passing=tot[1], in_grid=tot[2],
+                    near=tot[3], hypotheses=tot[4])
 
     def alloc(self, nbytes):
         p = vp()

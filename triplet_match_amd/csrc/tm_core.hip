@@ -87,7 +87,7 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TM_HIP_CHECK(hipEventCreate(&c->ev0));
     TM_HIP_CHECK(hipEventCreate(&c->ev1));
-    TM_FORWARD(c->stats.alloc(16));
+    TM_FORWARD(c->stats.alloc((size_t)kTimedRing * kTimedWords));
     c->ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
     c->debug_stats = getenv("TM_DEBUG_STATS") != nullptr;
     {
@@ -115,6 +115,7 @@ int tm_ctx_destroy(tm_ctx* c) {
     c->stats.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TM_OK;
@@ -154,16 +155,73 @@ int tm_memcpy_d2h(tm_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
 
 int tm_ctx_enable_timing(tm_ctx* c, int on) {
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    if (on && c->ev_ring.empty()) {
+        TM_HIP_CHECK(hipSetDevice(c->device));
+        c->ev_ring.resize(2 * (size_t)kTimedRing, nullptr);
+        for (hipEvent_t& e : c->ev_ring) TM_HIP_CHECK(hipEventCreate(&e));
+    }
+    if (on) c->n_timed = 0; /* a new measurement window */
     c->timing = on != 0;
     return TM_OK;
 }
+
+}  // extern "C"
+
+/* reads the rows [first, n_timed) of the ring (at most the last kTimedRing launches) */
+int tmx::read_timed(tm_ctx* c, uint64_t first, score_timing* sum, uint32_t* launches) {
+    *sum = score_timing();
+    *launches = 0;
+    if (c->n_timed == 0) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> rows((size_t)kTimedRing * kTimedWords);
+    TM_HIP_CHECK(hipMemcpy(rows.data(), c->stats.p, rows.size() * 8, hipMemcpyDeviceToHost));
+    if (c->n_timed - first > (uint64_t)kTimedRing) first = c->n_timed - kTimedRing;
+    for (uint64_t k = first; k < c->n_timed; ++k) {
+        const uint32_t row = (uint32_t)(k % kTimedRing);
+        float ms = 0.f;
+        TM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev_ring[2 * row], c->ev_ring[2 * row + 1]));
+        const unsigned long long* r = rows.data() + (size_t)row * kTimedWords;
+        sum->ms += ms;
+        sum->evaluations += c->timed_evals_host[row] != ~0ull ? c->timed_evals_host[row] : r[0];
+        sum->passing += r[1];
+        sum->in_grid += r[2];
+        sum->near += r[3];
+        sum->hypotheses += c->timed_hyp[row];
+        ++*launches;
+    }
+    return TM_OK;
+}
+
+extern "C" {
+
 int tm_ctx_last_score_timing(tm_ctx* c, float* ms, uint64_t* evaluations, uint64_t* passing,
                              uint64_t* hypotheses) {
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
-    if (ms) *ms = c->last.ms;
-    if (evaluations) *evaluations = c->last.evaluations;
-    if (passing) *passing = c->last.passing;
-    if (hypotheses) *hypotheses = c->last.hypotheses;
+    score_timing t;
+    uint32_t n = 0;
+    TM_FORWARD(read_timed(c, c->n_timed ? c->n_timed - 1 : 0, &t, &n));
+    if (ms) *ms = t.ms;
+    if (evaluations) *evaluations = t.evaluations;
+    if (passing) *passing = t.passing;
+    if (hypotheses) *hypotheses = t.hypotheses;
+    return TM_OK;
+}
+
+int tm_ctx_score_timing_totals(tm_ctx* c, uint32_t* launches, float* total_ms, uint64_t totals5[5]) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    score_timing t;
+    uint32_t n = 0;
+    TM_FORWARD(read_timed(c, 0, &t, &n));
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = t.ms;
+    if (totals5) {
+        totals5[0] = t.evaluations;
+        totals5[1] = t.passing;
+        totals5[2] = t.in_grid;
+        totals5[3] = t.near;
+        totals5[4] = t.hypotheses;
+    }
     return TM_OK;
 }
 

@@ -68,8 +68,14 @@ struct dbuf {
 
 struct score_timing {
     float ms = 0.f;
-    uint64_t evaluations = 0, passing = 0, hypotheses = 0;
+    uint64_t evaluations = 0, passing = 0, hypotheses = 0, in_grid = 0, near = 0;
 };
+
+/* Timed scoring launches are recorded without touching the host: an event pair and one row of device
+ * counters per launch (ring of kTimedRing); tm_ctx_last_score_timing / tm_ctx_score_timing_totals
+ * synchronise and read them when asked. */
+constexpr int kTimedRing = 256;
+constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, 4 spare */
 
 }  // namespace tmx
 
@@ -80,7 +86,10 @@ struct tm_ctx {
     int ablate = 0;          /* TM_ABLATE: timing experiments only */
     bool debug_stats = false; /* TM_DEBUG_STATS: per-launch stage counts on stderr */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    tmx::score_timing last;
+    std::vector<hipEvent_t> ev_ring;      /* 2 * kTimedRing, created on first use */
+    uint64_t n_timed = 0;                 /* timed launches since tm_ctx_enable_timing(ctx, 1) */
+    uint64_t timed_hyp[tmx::kTimedRing];  /* per ring row: hypotheses of the launch */
+    uint64_t timed_evals_host[tmx::kTimedRing]; /* per ring row: evaluations known on the host (exhaustive kernel), else ~0 */
     tmx::dbuf<unsigned char> scratch;   /* rocprim temp storage */
     tmx::dbuf<unsigned long long> stats; /* device counters */
 };
@@ -164,6 +173,7 @@ struct tm_scene {
     tmx::dbuf<float4> tiles;      /* per tile: centre xyz, radius (negative = empty) */
     tmx::dbuf<float4> supers;     /* per super-tile (64 tiles = 4096 points): bounding sphere */
     tmx::dbuf<float4> subs;       /* per quarter tile (16 points): bounding sphere */
+    tmx::dbuf<float4> chunks;     /* per chunk (512 points = 8 tiles): bounding sphere (grouped scoring) */
     uint32_t n_sorted = 0;        /* padded point count (multiple of the brute-force tile) */
     uint32_t n_tiles = 0;         /* n_sorted / 64 */
     float coord_max = 0.f;        /* max |coordinate| over the finite points */
@@ -175,6 +185,9 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
     tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
+    tmx::dbuf<unsigned short> w_masks; /* grouped scoring: hypothesis mask per (group, chunk) */
+    tmx::dbuf<uint32_t> w_items;       /* grouped scoring: slots with a non-zero mask, + the count */
+    tmx::dbuf<float2> w_aux;           /* grouped scoring: per hypothesis (rnorm, abs_eps) */
     /* early-drop path (tm_earlydrop.hip) */
     tmx::dbuf<int32_t> ed_subset, ed_dropped;
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
@@ -189,6 +202,8 @@ struct tm_scene {
 
 namespace tmx {
 int scratch_ensure(tm_ctx* ctx, size_t bytes);
+/* timed scoring launches [first, n_timed): synchronises the stream, sums events and device counters */
+int read_timed(tm_ctx* ctx, uint64_t first, score_timing* sum, uint32_t* launches);
 /* false once the context was destroyed or the process is exiting: destroy calls then free host memory only */
 bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */

@@ -117,6 +117,34 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
     return true;
 }
 
+/* tile_hits in two steps, so that a caller can put several brick-code loads in flight before it needs
+ * the first: tile_probe does the arithmetic, tile_decide takes the loaded code. Same result. */
+struct tile_probe_t {
+    bool hit;       /* the sphere reaches the voxel box */
+    bool need;      /* the distance-field test applies (centre inside the grid) */
+    uint32_t brick; /* brick of the centre (0 when !need) */
+    float lim;      /* reject when code > lim */
+};
+__device__ __forceinline__ tile_probe_t tile_probe(const score_args& a, const pose12& T, float rnorm, float abs_eps,
+                                                   float ca_tcode, float ca_inv_q, float4 tb) {
+    tile_probe_t r;
+    f3 c = xform_point(T, make3(tb.x, tb.y, tb.z));
+    float rho = tb.w * rnorm * 1.0001f + abs_eps;
+    float vx = a.g.sx * c.x + a.g.tx, vy = a.g.sy * c.y + a.g.ty, vz = a.g.sz * c.z + a.g.tz;
+    float mx = a.g.sx * rho + 0.05f, my = a.g.sy * rho + 0.05f, mz = a.g.sz * rho + 0.05f;
+    r.hit = (tb.w >= 0.f) & (vx + mx > -1.f) & (vx - mx < a.g.fex) & (vy + my > -1.f) & (vy - my < a.g.fey) &
+            (vz + mz > -1.f) & (vz - mz < a.g.fez);
+    r.need = r.hit & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez);
+    const uint32_t ix = r.need ? (uint32_t)(int)vx : 0u, iy = r.need ? (uint32_t)(int)vy : 0u,
+                   iz = r.need ? (uint32_t)(int)vz : 0u;
+    r.brick = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
+    r.lim = ca_tcode + rho * ca_inv_q * 1.0001f;
+    return r;
+}
+__device__ __forceinline__ bool tile_decide(const tile_probe_t& r, uint32_t code) {
+    return r.hit & !(r.need & ((float)code > r.lim));
+}
+
 /* L2 = the model's metric is the 3-D Euclidean one (identity / plane): distance-field tile test, brick
  * near-filter and the squared-distance comparison apply. Otherwise (plane2 / cylinder: the traits'
  * intrinsic_distance can be small where the Euclidean one is not) only the sphere-vs-box test culls.
@@ -220,6 +248,10 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 const bool have = e < n;
                 sidx[k] = (have ? s_list[e] : s_list[i]) * 16u + (lane & 15u);
                 const float* sp = a.spos3 + 3u * (size_t)sidx[k]; /* 12 B per point: 12 lines per tile, not 16 */
+                if (a.ablate >= 8) { /* timing experiment: no per-point loads (one broadcast sphere per 16 lanes) */
+                    const float4 sb = ca.subs[sidx[k] >> 4];
+                    P[k] = make_float4(sb.x + 1e-4f * (float)(lane & 3u), sb.y + 1e-4f * (float)((lane >> 2) & 3u), sb.z, 0.f);
+                } else
                 P[k] = make_float4(sp[0], sp[1], sp[2], 0.f);
                 in[k] = have;
                 if (SUBSET) in[k] = in[k] & (ca.active_sorted[sidx[k]] != 0);
@@ -248,6 +280,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 n_in += in[k] ? 1u : 0u;
                 n_near += near[k] ? 1u : 0u;
                 lin[k] = near[k] ? lin[k] : 0u;
+                if (a.ablate == 7 || a.ablate == 9) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
             }
             if (a.ablate == 3) { cnt += near[0] + near[1] + near[2] + near[3]; continue; }
             /* stage 2: voxel gathers */
@@ -334,6 +367,367 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
             if (st.z) atomicAdd(sp + 2, st.z);
             if (st.w) atomicAdd(sp + 3, st.w);
         }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped scoring: the hypotheses of one scene sample pair all map the first sample onto a model point,
+ * so they reach the same neighbourhood of the scene (the reference's `nn`, include/impl/scene.hpp:273).
+ * Instead of letting every hypothesis cull the whole scene and load its points for itself, groups of
+ * kGroupHyps consecutive hypotheses share the work:
+ *   k_group_cull   one thread per (group, 512-point chunk): which of the group's hypotheses can the
+ *                  chunk's bounding sphere reach at all -> 16-bit mask per (group, chunk)
+ *   rocprim select the (group, chunk) slots with a non-zero mask -> work items
+ *   k_score_items  persistent waves; an item = one chunk staged ONCE into the wave's private LDS
+ *                  (coalesced 16-B loads) and evaluated for every hypothesis of the mask: quarter-tile
+ *                  test by a ballot, surviving quarters compacted, then the same four-chain evaluation
+ *                  as k_score_culled with the points read from LDS.
+ * Everything skipped is skipped by the same conservative sphere tests as before, the sums are integers,
+ * so counts and fixed-point scores are identical to k_score_culled / k_score_brute.
+ * ---------------------------------------------------------------------------------------------- */
+constexpr int kGroupHyps = 16;
+constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
+
+struct group_args {
+    const float4* chunks;   /* bounding sphere per 512 sorted points */
+    uint32_t n_chunks;
+    uint32_t n_groups;
+    unsigned short* masks;  /* [group][chunk] */
+    const uint32_t* items;  /* slots with a non-zero mask */
+    const uint32_t* n_items;
+    const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
+};
+
+struct nonzero_mask {
+    __host__ __device__ bool operator()(unsigned short m) const { return m != 0; }
+};
+
+/* per hypothesis: Frobenius norm of the rotation block and the absolute rounding slack of the sphere tests */
+__global__ __launch_bounds__(256) void k_pose_aux(const float* __restrict__ poses, uint32_t n_hyp, float coord_max,
+                                                  float2* __restrict__ aux) {
+    const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n_hyp) return;
+    const pose12 T = load_pose(poses + (size_t)h * 16);
+    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                              T.r22 * T.r22);
+    aux[h] = make_float2(rnorm, 1e-6f * (3.f * rnorm * coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f));
+}
+
+__global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, group_args ga) {
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t group = blockIdx.y;
+    const bool live = chunk < ga.n_chunks;
+    float4 sb = make_float4(0.f, 0.f, 0.f, -1.f), ss = sb;
+    if (live) {
+        sb = ga.chunks[chunk];
+        ss = ca.supers[chunk >> 3];
+    }
+    uint32_t m = 0;
+    for (uint32_t g = 0; g < (uint32_t)kGroupHyps; ++g) {
+        const uint32_t h = group * kGroupHyps + g; /* uniform: the pose comes through scalar loads */
+        if (h >= a.n_hyp) break;
+        const pose12 T = load_pose(a.poses + (size_t)h * 16);
+        const float2 ax = ga.aux[h];
+        const float rnorm = ax.x, abs_eps = ax.y;
+        bool hit = sphere_hits_box(a, T, rnorm, abs_eps, ss);
+        if (hit) hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
+        m |= hit ? (1u << g) : 0u;
+    }
+    if (live) ga.masks[(size_t)group * ga.n_chunks + chunk] = (unsigned short)m;
+}
+
+/* sum over the 16 lanes of a DPP row; lane 15 of every row ends up with the row's total */
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); /* row_shr:8 */
+    return v;
+}
+
+__device__ __forceinline__ pose12 lds_pose(const float4* p, float* rnorm = nullptr, float* abs_eps = nullptr) {
+    const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    if (rnorm) *rnorm = c0.w; /* the staging code keeps the two sphere-test constants in the unused bottom row */
+    if (abs_eps) *abs_eps = c1.w;
+    pose12 T;
+    T.r00 = c0.x; T.r10 = c0.y; T.r20 = c0.z;
+    T.r01 = c1.x; T.r11 = c1.y; T.r21 = c1.z;
+    T.r02 = c2.x; T.r12 = c2.y; T.r22 = c2.z;
+    T.tx = c3.x; T.ty = c3.y; T.tz = c3.z;
+    return T;
+}
+
+template <bool L2, int NC>
+__global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args ca, group_args ga) {
+    __shared__ float s_pts[4][kChunkPts * 3];                 /* the item's 512 points, packed xyz */
+    __shared__ float4 s_pose[4][kGroupHyps * 4];              /* the group's poses, column-major 4x4 */
+    __shared__ unsigned short s_ent[4][kGroupHyps * 32];      /* surviving (hypothesis << 5 | quarter) */
+    __shared__ uint32_t s_cnt[4][kGroupHyps];
+    __shared__ unsigned long long s_fx[4][kGroupHyps];
+    __shared__ uint32_t s_st[4][4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_items = *ga.n_items;
+    /* XCD-aware split (speed only): blocks b and b + 8 share an L2; consecutive items belong to the same
+     * group of hypotheses, whose voxel neighbourhoods overlap: give each XCD a contiguous range of items */
+    const uint32_t xcd = blockIdx.x & 7u, waves_per_xcd = (gridDim.x >> 3) * 4u;
+    const uint32_t wave_in_xcd = (blockIdx.x >> 3) * 4u + wave;
+    const uint32_t lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3);
+    const uint32_t hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1u)) >> 3);
+    uint32_t evals = 0, pass = 0, n_in = 0, n_near = 0;
+    float* pts = s_pts[wave];
+    float4* poses = s_pose[wave];
+    unsigned short* ent = s_ent[wave];
+    if (lane < (uint32_t)kGroupHyps) {
+        s_cnt[wave][lane] = 0u;
+        s_fx[wave][lane] = 0ull;
+    }
+    for (uint32_t it = lo + wave_in_xcd; it < hi; it += waves_per_xcd) {
+        const uint32_t slot = ga.items[it];
+        const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
+        uint32_t m = ga.masks[slot];
+        /* stage the chunk (1536 floats = six float4 per lane, contiguous) and the group's poses */
+        {
+            const float4* src = reinterpret_cast<const float4*>(a.spos3 + (size_t)chunk * (kChunkPts * 3));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* earlier reads of the LDS arrays are done */
+            __builtin_amdgcn_wave_barrier();
+            const float4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + lane], v3 = src[192 + lane],
+                         v4 = src[256 + lane], v5 = src[320 + lane];
+            const uint32_t hp = min(group * kGroupHyps + (lane >> 2), a.n_hyp - 1u);
+            float4 pv = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + (lane & 3u)];
+            const float2 ax = ga.aux[hp];
+            if ((lane & 3u) == 0u) pv.w = ax.x;
+            if ((lane & 3u) == 1u) pv.w = ax.y;
+            float4* dst = reinterpret_cast<float4*>(pts);
+            dst[lane] = v0;
+            dst[64 + lane] = v1;
+            dst[128 + lane] = v2;
+            dst[192 + lane] = v3;
+            dst[256 + lane] = v4;
+            dst[320 + lane] = v5;
+            poses[lane] = pv;
+        }
+        const float4 qs = ca.subs[(size_t)chunk * 32u + (lane & 31u)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* quarter-tile tests, two hypotheses per round (lanes 0-31 / 32-63): the level-3 test of
+         * k_score_culled; survivors are appended to the entry list */
+        uint32_t hm = 0; /* lane q < 32: which hypotheses of the group reach quarter-tile q */
+        {
+            /* eight rounds, two hypotheses each (lanes 0-31 / 32-63): the level-3 test of k_score_culled.
+             * All eight probes first, then the eight brick-code loads together, then the decisions */
+            tile_probe_t pr[kGroupHyps / 2];
+            uint32_t code[kGroupHyps / 2];
+#pragma unroll
+            for (int r = 0; r < kGroupHyps / 2; ++r) {
+                const uint32_t g = 2u * r + (lane >> 5);
+                float rnorm, abs_eps;
+                const pose12 T = lds_pose(poses + 4u * g, &rnorm, &abs_eps);
+                if (L2) {
+                    pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
+                } else {
+                    pr[r].hit = sphere_hits_box(a, T, rnorm, abs_eps, qs);
+                    pr[r].need = false;
+                    pr[r].brick = 0u;
+                    pr[r].lim = 0.f;
+                }
+                pr[r].hit = pr[r].hit & (((m >> g) & 1u) != 0u);
+                pr[r].need = pr[r].need & pr[r].hit;
+                if (!pr[r].need) pr[r].brick = 0u;
+                __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
+            }
+#pragma unroll
+            for (int r = 0; r < kGroupHyps / 2; ++r) code[r] = L2 ? (uint32_t)a.bcode[pr[r].brick] : 0u;
+            const uint32_t ql = lane & 31u;
+#pragma unroll
+            for (int r = 0; r < kGroupHyps / 2; ++r) {
+                const unsigned long long qm = __ballot(tile_decide(pr[r], code[r]));
+                hm |= ((uint32_t)(qm >> ql) & 1u) << (2 * r);
+                hm |= ((uint32_t)(qm >> (32u + ql)) & 1u) << (2 * r + 1);
+            }
+        }
+        /* entry list in quarter-major order: the lane groups of one gather instruction then hold the same
+         * scene points under consecutive hypotheses of the group. Consecutive hypotheses of a sample pair
+         * come from neighbouring model pairs (the table is sorted), i.e. nearly the same pose: they land in
+         * the same voxel lines, and this order lets them share those lines inside the instruction and L1
+         * instead of fetching them again microseconds later, when L2 has already turned over */
+        if (lane >= 32u) hm = 0u;
+        const uint32_t mine = (uint32_t)__popc(hm);
+        uint32_t incl = mine; /* inclusive prefix sum over the lanes */
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off) incl += t;
+        }
+        const uint32_t n = __shfl(incl, 31);
+        {
+            uint32_t o = incl - mine, b = hm;
+            while (b) {
+                const uint32_t g = (uint32_t)__builtin_ctz(b);
+                b &= b - 1u;
+                ent[o++] = (unsigned short)((g << 5) | lane);
+            }
+        }
+        if (n == 0u) continue;
+        if (a.ablate == 10) continue; /* timing experiment: staging and culling only */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        evals += n * 16u / 64u + ((lane < (n * 16u) % 64u) ? 1u : 0u); /* sums to 16 n over the wave */
+        for (uint32_t i = 0; i < n; i += 4u * NC) {
+            f3 q[NC];
+            uint32_t pidx[NC], gk[NC], lin[NC], mi[NC], brick[NC], code[NC];
+            bool near[NC], in[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const uint32_t e = i + 4u * k + (lane >> 4);
+                in[k] = e < n;
+                const uint32_t en = ent[in[k] ? e : i];
+                gk[k] = en >> 5;
+                pidx[k] = (en & 31u) * 16u + (lane & 15u);
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const pose12 T = lds_pose(poses + 4u * gk[k]);
+                const float* sp = pts + 3u * pidx[k];
+                q[k] = xform_point(T, make3(sp[0], sp[1], sp[2]));
+                float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
+                in[k] = in[k] & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
+                        (vz < a.g.fez);
+                uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
+                         iz = in[k] ? (uint32_t)(int)vz : 0u;
+                brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
+                lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
+                code[k] = L2 ? (uint32_t)a.bcode[brick[k]] : 0u;
+                __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                near[k] = in[k] & (code[k] <= a.code_max);
+                n_in += in[k] ? 1u : 0u;
+                n_near += near[k] ? 1u : 0u;
+                lin[k] = near[k] ? lin[k] : 0u;
+                if (a.ablate == 7) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) mi[k] = a.vox[lin[k]];
+            bool ok[NC];
+            bool any_ok = false;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const float* mp = a.mpos3 + 3u * (size_t)mi[k];
+                if (L2) {
+                    float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
+                    float d2 = (dx * dx + dy * dy) + dz * dz;
+                    ok[k] = near[k] & (d2 <= a.d2max);
+                } else {
+                    float dist = traits_distance(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
+                    ok[k] = near[k] & !(dist > a.dmax);
+                }
+                any_ok |= ok[k];
+            }
+            if (a.ablate == 1) { pass += any_ok ? 1u : 0u; continue; } /* timing experiment: no orientation stage */
+            if (__ballot(any_ok)) {
+#pragma unroll
+                for (int k0 = 0; k0 < NC; k0 += 2) {
+                    float4 sr[2], mr[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (ok[k0 + j]) {
+                            sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[k0 + j]];
+                            mr[j] = a.mref[mi[k0 + j]];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        /* 2^40 fixed-point term split as hi * 2^20 + lo, the match flag rides above lo:
+                         * two dwords to add up over the 16 lanes of the entry */
+                        uint32_t w_lo = 0u, w_hi = 0u;
+                        if (ok[k0 + j]) {
+                            ++pass;
+                            if (sr[j].w == mr[j].w) {
+                                const pose12 T = lds_pose(poses + 4u * gk[k0 + j]);
+                                f3 r = xform_dir(T, make3(sr[j].x, sr[j].y, sr[j].z));
+                                float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
+                                const unsigned long long t = (unsigned long long)(long long)((double)term * kFx);
+                                w_lo = (uint32_t)(t & 0xFFFFFull) | (1u << 24);
+                                w_hi = (uint32_t)(t >> 20);
+                            }
+                        }
+                        if (__ballot(w_lo != 0u)) {
+                            w_lo = row16_sum(w_lo);
+                            w_hi = row16_sum(w_hi);
+                            if ((lane & 15u) == 15u && w_lo != 0u) {
+                                atomicAdd(&s_cnt[wave][gk[k0 + j]], w_lo >> 24);
+                                atomicAdd(&s_fx[wave][gk[k0 + j]],
+                                          ((unsigned long long)w_hi << 20) + (unsigned long long)(w_lo & 0xFFFFFFu));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        /* flush the item's sums: one pair of atomics per hypothesis with correspondences */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < (uint32_t)kGroupHyps) {
+            const uint32_t c = s_cnt[wave][lane];
+            if (c && a.ablate != 11) {
+                const uint32_t h = group * kGroupHyps + lane;
+                atomicAdd(&a.counts[h], c);
+                atomicAdd(&a.scores_fx[h], s_fx[wave][lane]);
+                s_cnt[wave][lane] = 0u;
+                s_fx[wave][lane] = 0ull;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        evals += __shfl_down(evals, off);
+        pass += __shfl_down(pass, off);
+        n_in += __shfl_down(n_in, off);
+        n_near += __shfl_down(n_near, off);
+    }
+    if (lane == 0) {
+        s_st[wave][0] = evals;
+        s_st[wave][1] = pass;
+        s_st[wave][2] = n_in;
+        s_st[wave][3] = n_near;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.stat_slots[blockIdx.x] = make_uint4((s_st[0][0] + s_st[1][0]) + (s_st[2][0] + s_st[3][0]),
+                                              (s_st[0][1] + s_st[1][1]) + (s_st[2][1] + s_st[3][1]),
+                                              (s_st[0][2] + s_st[1][2]) + (s_st[2][2] + s_st[3][2]),
+                                              (s_st[0][3] + s_st[1][3]) + (s_st[2][3] + s_st[3][3]));
+}
+
+/* sums the per-workgroup stat slots of one scoring launch into that launch's row of device counters
+ * (one workgroup, plain stores: nothing for the host to wait for inside a timed loop) */
+__global__ __launch_bounds__(1024) void k_stats_reduce(const uint4* __restrict__ slots, uint32_t n_slots,
+                                                       unsigned long long* __restrict__ row) {
+    __shared__ unsigned long long s_acc[16][4];
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 1024) {
+        const uint4 v = slots[i];
+        acc[0] += v.x; /* evaluations */
+        acc[1] += v.y; /* distance-passing */
+        acc[2] += v.z; /* in-grid */
+        acc[3] += v.w; /* near */
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_acc[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        unsigned long long r = 0;
+        for (int w = 0; w < 16; ++w) r += s_acc[w][threadIdx.x];
+        row[threadIdx.x] = r;
     }
 }
 
@@ -688,9 +1082,11 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     dim3 grid(tiles, (n_hyp + hpb - 1) / hpb);
     TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
     const size_t n_slots = culled ? (size_t)n_hyp : (size_t)grid.x * grid.y;
+    size_t n_stat_slots = n_slots; /* slots the launched kernel actually writes */
     TM_FORWARD(s->w_stats.ensure(n_slots));
     a.stat_slots = s->w_stats.p;
-    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    const uint32_t trow = (uint32_t)(c->n_timed % kTimedRing);
+    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev_ring[2 * trow], c->stream));
     if (culled) {
         cull_args ca;
         ca.tiles = s->tiles.p;
@@ -712,6 +1108,66 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                                s->d_order.p, s->n, s->n_sorted, s->w_active_sorted.p);
             ca.active_sorted = s->w_active_sorted.p;
         }
+        bool grouped = l2 && !d_active && !d_centers;
+        if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
+        if (grouped) {
+            /* groups of kGroupHyps consecutive hypotheses share the scene chunks they reach */
+            group_args ga;
+            ga.chunks = s->chunks.p;
+            ga.n_chunks = s->n_sorted / kChunkPts;
+            ga.n_groups = (n_hyp + kGroupHyps - 1) / kGroupHyps;
+            TM_REQUIRE(ga.n_groups <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
+            const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
+            TM_REQUIRE(n_slots_g < 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "groups x chunks exceeds 32 bits");
+            TM_FORWARD(s->w_masks.ensure(n_slots_g));
+            TM_FORWARD(s->w_items.ensure(n_slots_g + 1));
+            TM_FORWARD(s->w_aux.ensure(n_hyp));
+            ga.aux = s->w_aux.p;
+            hipLaunchKernelGGL(k_pose_aux, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, d_poses, n_hyp,
+                               s->coord_max, s->w_aux.p);
+            ga.masks = s->w_masks.p;
+            ga.items = s->w_items.p;
+            ga.n_items = s->w_items.p + n_slots_g;
+            hipLaunchKernelGGL(k_group_cull, dim3((ga.n_chunks + 255) / 256, ga.n_groups), dim3(256), 0, c->stream,
+                               a, ca, ga);
+            size_t tmp = 0;
+            rocprim::counting_iterator<uint32_t> slots(0u);
+            auto flags = rocprim::make_transform_iterator(s->w_masks.p, nonzero_mask());
+            TM_HIP_CHECK(rocprim::select(nullptr, tmp, slots, flags, s->w_items.p, s->w_items.p + n_slots_g,
+                                         n_slots_g, c->stream));
+            TM_FORWARD(scratch_ensure(c, tmp));
+            TM_HIP_CHECK(rocprim::select(c->scratch.p, tmp, slots, flags, s->w_items.p, s->w_items.p + n_slots_g,
+                                         n_slots_g, c->stream));
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            /* persistent waves with a static share of the items each: the grid must be exactly what is
+             * resident at once, or the surplus workgroups run their share after everyone else */
+            auto kern = k_score_items<true, 4>;
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
+            if (per_cu < 1) per_cu = 1;
+            uint32_t wgs = (uint32_t)cus * (uint32_t)per_cu;
+            if (const char* e = getenv("TM_SCORE_ITEM_WGS")) wgs = (uint32_t)std::max(8, atoi(e));
+            wgs &= ~7u;
+            TM_FORWARD(s->w_stats.ensure(std::max<size_t>(n_slots, wgs)));
+            a.stat_slots = s->w_stats.p;
+            n_stat_slots = wgs;
+            if (c->debug_stats)
+                fprintf(stderr, "[tm] grouped: %u persistent workgroups (%d per CU)\n", wgs, per_cu);
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, a, ca, ga);
+            if (c->debug_stats && getenv("TM_DEBUG_ITEMS")) {
+                std::vector<unsigned short> hm(n_slots_g);
+                TM_HIP_CHECK(hipMemcpyAsync(hm.data(), s->w_masks.p, n_slots_g * 2, hipMemcpyDeviceToHost, c->stream));
+                TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+                unsigned long long items = 0, steps = 0;
+                for (unsigned short v : hm) {
+                    items += v != 0;
+                    steps += (unsigned)__builtin_popcount(v);
+                }
+                fprintf(stderr, "[tm] grouped: %u groups x %u chunks, %llu items, %llu (item, hypothesis) steps\n",
+                        ga.n_groups, ga.n_chunks, items, steps);
+            }
+        } else {
         /* split every hypothesis over `parts` workgroups (rounds of 1024 tiles taken in turn): shorter
          * workgroups even out the tail of the launch; TM_SCORE_PARTS overrides (1 = no split) */
         uint32_t parts = 3;
@@ -727,36 +1183,32 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             hipLaunchKernelGGL((k_score_culled<false, false>), cgrid, dim3(256), 0, c->stream, a, ca);
         else
             hipLaunchKernelGGL((k_score_culled<false, true>), cgrid, dim3(256), 0, c->stream, a, ca);
+        }
     } else if (d_active) {
         hipLaunchKernelGGL(k_score_brute<true>, grid, dim3(256), 0, c->stream, a);
     } else {
         hipLaunchKernelGGL(k_score_brute<false>, grid, dim3(256), 0, c->stream, a);
     }
     TM_HIP_CHECK(hipGetLastError());
-    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    if (c->timing) TM_HIP_CHECK(hipEventRecord(c->ev_ring[2 * trow + 1], c->stream));
     hipLaunchKernelGGL(k_finalize_scores, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream,
                        s->w_scores_fx.p, n_hyp, 1.0 / kFx, (double)m->n, d_scores);
     TM_HIP_CHECK(hipGetLastError());
-    if (c->timing) {
-        std::vector<uint4> slots(n_slots);
-        TM_HIP_CHECK(hipMemcpyAsync(slots.data(), s->w_stats.p, n_slots * sizeof(uint4), hipMemcpyDeviceToHost,
-                                    c->stream));
-        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-        unsigned long long h_stats[4] = {0, 0, 0, 0};
-        for (const uint4& v : slots) {
-            h_stats[1] += v.x;
-            h_stats[0] += v.y;
-            h_stats[2] += v.z;
-            h_stats[3] += v.w;
+    if (c->timing) { /* no host synchronisation here: the counters stay on the device until asked for */
+        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, c->stream, s->w_stats.p, (uint32_t)n_stat_slots,
+                           c->stats.p + (size_t)trow * kTimedWords);
+        TM_HIP_CHECK(hipGetLastError());
+        c->timed_hyp[trow] = n_hyp;
+        c->timed_evals_host[trow] = culled ? ~0ull : (uint64_t)n_hyp * n_active;
+        ++c->n_timed;
+        if (c->debug_stats) {
+            score_timing t;
+            uint32_t nl = 0;
+            TM_FORWARD(read_timed(c, c->n_timed - 1, &t, &nl));
+            fprintf(stderr, "[tm] score: evals %llu in_grid %llu near %llu passing %llu ms %.3f\n",
+                    (unsigned long long)t.evaluations, (unsigned long long)t.in_grid, (unsigned long long)t.near,
+                    (unsigned long long)t.passing, t.ms);
         }
-        float ms = 0.f;
-        TM_HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last.ms = ms;
-        c->last.evaluations = culled ? (uint64_t)h_stats[1] : (uint64_t)n_hyp * n_active;
-        c->last.passing = h_stats[0];
-        c->last.hypotheses = n_hyp;
-        if (c->debug_stats)
-            fprintf(stderr, "[tm] score: evals %llu in_grid %llu near %llu passing %llu ms %.3f\n", (unsigned long long)c->last.evaluations, h_stats[2], h_stats[3], h_stats[0], ms);
     }
     return TM_OK;
 }
@@ -926,6 +1378,10 @@ int tm_scene_destroy(tm_scene* s) {
     s->tiles.release();
     s->supers.release();
     s->subs.release();
+    s->chunks.release();
+    s->w_masks.release();
+    s->w_aux.release();
+    s->w_items.release();
     s->w_poses.release();
     s->w_counts.release();
     s->w_scores_fx.release();

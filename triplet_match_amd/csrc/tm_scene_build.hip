@@ -17,7 +17,8 @@
  *                      NaN in x so that they fail the in-grid test; counts the live points
  *   k_scene_tiles      bounding sphere of every 64 consecutive sorted points (one wave per tile)
  *   k_scene_subs       bounding spheres of the four 16-point quarters of every tile
- *   k_scene_supers     bounding sphere of every 4096 consecutive sorted points (one block each)
+ *   k_scene_supers     bounding sphere of every 4096 consecutive sorted points (one block each), and of
+ *                      every 512 (the chunks of the grouped scoring kernel)
  *
  * The order does not depend on mask_, so tm_scene_set_mask re-runs only the last four steps. Inlier
  * counts and fixed-point scores are independent of the order of the points, and the spheres are
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(256) void k_scene_subs(const float4* __restrict__ s
 }
 
 __global__ __launch_bounds__(256) void k_scene_supers(const float4* __restrict__ spos, uint32_t n_pad,
-                                                      float4* __restrict__ supers) {
+                                                      uint32_t span, float4* __restrict__ supers) {
     __shared__ double s_lo[3][4], s_hi[3][4], s_r[4];
     __shared__ int s_live[4];
-    const uint32_t k0 = blockIdx.x * 4096u, k1 = min(k0 + 4096u, n_pad);
+    const uint32_t k0 = blockIdx.x * span, k1 = min(k0 + span, n_pad);
     const double big = 1e300;
     double lo[3] = {big, big, big}, hi[3] = {-big, -big, -big};
     int live = 0;
@@ -363,6 +364,7 @@ int scene_build(tm_scene* s, bool resort) {
     TM_FORWARD(s->tiles.ensure(n_tiles));
     TM_FORWARD(s->supers.ensure(n_super));
     TM_FORWARD(s->subs.ensure((size_t)n_tiles * 4));
+    TM_FORWARD(s->chunks.ensure(n_pad / 512));
     scene_bounds* bnd = reinterpret_cast<scene_bounds*>(s->d_bounds.p);
     hipLaunchKernelGGL(k_scene_original, grid_n, blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p, s->d_mask.p, n,
                        s->opos.p, s->otan.p, s->oref.p);
@@ -414,7 +416,8 @@ int scene_build(tm_scene* s, bool resort) {
                        s->d_mask.p, s->d_order.p, n, n_pad, s->spos.p, s->spos3.p, s->sref.p, bnd);
     hipLaunchKernelGGL(k_scene_tiles, dim3((n_tiles + 3) / 4), blk, 0, c->stream, s->spos.p, n_tiles, s->tiles.p);
     hipLaunchKernelGGL(k_scene_subs, dim3((n_tiles + 3) / 4), blk, 0, c->stream, s->spos.p, n_tiles, s->subs.p);
-    hipLaunchKernelGGL(k_scene_supers, dim3(n_super), blk, 0, c->stream, s->spos.p, n_pad, s->supers.p);
+    hipLaunchKernelGGL(k_scene_supers, dim3(n_super), blk, 0, c->stream, s->spos.p, n_pad, 4096u, s->supers.p);
+    hipLaunchKernelGGL(k_scene_supers, dim3(n_pad / 512), blk, 0, c->stream, s->spos.p, n_pad, 512u, s->chunks.p);
     TM_HIP_CHECK(hipGetLastError());
     scene_bounds h;
     TM_HIP_CHECK(hipMemcpyAsync(&h, bnd, sizeof h, hipMemcpyDeviceToHost, c->stream));
