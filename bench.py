@@ -184,15 +184,18 @@ def main():
     value = hyps_all / elapsed
     # roofline of the dominant kernel (inlier scoring), rank 0's launches, per launch:
     #   formula  = BASELINE.md section 3: 40*E + 32*P + 64*H (E = evaluations the kernel performed)
-    #   physical = the bytes those evaluations really request: 12 B scene xyz per evaluation, 1 B brick code
-    #              per in-grid point, 4 B voxel + 12 B model xyz per near point, 16 + 16 B orientation
-    #              records per distance-passing point, 64 B pose per hypothesis
+    #   physical = the bytes those evaluations really request: scene xyz (12 B per evaluation; the grouped
+    #              kernel stages 512-point chunks of 6 KiB + 1 KiB of poses and spheres once per item instead),
+    #              1 B brick code per in-grid point, 4 B voxel + 12 B model xyz per near point, 16 + 16 B
+    #              orientation records per distance-passing point, 64 B pose per hypothesis
     L = max(1, tot["launches"])
     k_ms = tot["ms"] / L
     E, P, Hh = evals / L, passing / L, hyps / args.steps
     N_in, N_near = tot["in_grid"] / L, tot["near"] / L
     alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
-    phys_bytes = 12.0 * E + 1.0 * N_in + 16.0 * N_near + 32.0 * P + 64.0 * Hh
+    N_items = tot["staged_chunks"] / L
+    scene_bytes = (6144.0 + 1408.0) * N_items if N_items else 12.0 * E
+    phys_bytes = scene_bytes + 1.0 * N_in + 16.0 * N_near + 32.0 * P + 64.0 * Hh
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     achieved_phys = phys_bytes / (k_ms * 1e-3) / 1e9
     pmc = measured_traffic(args)
@@ -206,7 +209,7 @@ def main():
                 "frac_basis": "baseline_formula_40E+32P+64H" if frac_formula <= 1.0 else "physical_model",
                 "traffic": traffic,
                 "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
-                "in_grid_per_launch": N_in, "near_per_launch": N_near,
+                "in_grid_per_launch": N_in, "near_per_launch": N_near, "staged_chunks_per_launch": N_items,
                 "passing_per_launch": P, "algorithmic_bytes_per_launch": alg_bytes,
                 "physical_bytes_per_launch": phys_bytes,
                 "achieved_physical": round(achieved_phys, 1),

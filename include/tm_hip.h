@@ -69,9 +69,10 @@ int tm_ctx_enable_timing(tm_ctx* ctx, int on);
 /* the most recent timed launch */
 int tm_ctx_last_score_timing(tm_ctx* ctx, float* ms, uint64_t* evaluations, uint64_t* passing,
                              uint64_t* hypotheses);
-/* sums over the window's launches (the last 256 at most): totals5 = evaluations, distance-passing,
- * in-grid, near (in-grid and brick code within reach), hypotheses */
-int tm_ctx_score_timing_totals(tm_ctx* ctx, uint32_t* launches, float* total_ms, uint64_t totals5[5]);
+/* sums over the window's launches (the last 256 at most): totals6 = evaluations, distance-passing,
+ * in-grid, near (in-grid and brick code within reach), hypotheses, 512-point scene chunks staged into LDS
+ * (grouped kernel; 0 for the others) */
+int tm_ctx_score_timing_totals(tm_ctx* ctx, uint32_t* launches, float* total_ms, uint64_t totals6[6]);
 
 /* ---- scalar descriptor functions, host side ----
  * replace: feature() include/impl/feature.hpp:16-34; discretize() x2 src/discretize.cpp:20-30;

@@ -15,7 +15,5 @@ for f in glob.glob(sys.argv[1]+"/*/*_counter_collection.csv"):
 print("   "+"  ".join("%s=%.3g"%(c,sum(v)/len(v)) for (k,c),v in sorted(agg.items())))
 PY
 }
-run g4_u16 TM_X=1
-run g4_u32 TM_SCORE_U32=1
-run g4_u16_noorient TM_ABLATE=1
-run g4_u16_vox1mb TM_ABLATE=7
+run g5 TM_X=1
+run g5_noeval TM_ABLATE=10

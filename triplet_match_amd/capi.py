@@ -261,10 +261,10 @@ class Context:
         """Sums over the scoring launches since enable_timing(True): kernel ms (HIP events on the library's
         stream) and the kernels' own counters. Synchronises the stream."""
         n, ms = C.c_uint32(0), C.c_float(0)
-        tot = (C.c_uint64 * 5)()
+        tot = (C.c_uint64 * 6)()
         _check(lib().tm_ctx_score_timing_totals(self.h, C.byref(n), C.byref(ms), tot))
         return dict(launches=n.value, ms=ms.value, evaluations=tot[0], passing=tot[1], in_grid=tot[2],
-                    near=tot[3], hypotheses=tot[4])
+                    near=tot[3], hypotheses=tot[4], staged_chunks=tot[5])
 
     def alloc(self, nbytes):
         p = vp()

@@ -187,6 +187,7 @@ int tmx::read_timed(tm_ctx* c, uint64_t first, score_timing* sum, uint32_t* laun
         sum->passing += r[1];
         sum->in_grid += r[2];
         sum->near += r[3];
+        sum->items += r[4];
         sum->hypotheses += c->timed_hyp[row];
         ++*launches;
     }
@@ -208,19 +209,20 @@ int tm_ctx_last_score_timing(tm_ctx* c, float* ms, uint64_t* evaluations, uint64
     return TM_OK;
 }
 
-int tm_ctx_score_timing_totals(tm_ctx* c, uint32_t* launches, float* total_ms, uint64_t totals5[5]) {
+int tm_ctx_score_timing_totals(tm_ctx* c, uint32_t* launches, float* total_ms, uint64_t totals6[6]) {
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     score_timing t;
     uint32_t n = 0;
     TM_FORWARD(read_timed(c, 0, &t, &n));
     if (launches) *launches = n;
     if (total_ms) *total_ms = t.ms;
-    if (totals5) {
-        totals5[0] = t.evaluations;
-        totals5[1] = t.passing;
-        totals5[2] = t.in_grid;
-        totals5[3] = t.near;
-        totals5[4] = t.hypotheses;
+    if (totals6) {
+        totals6[0] = t.evaluations;
+        totals6[1] = t.passing;
+        totals6[2] = t.in_grid;
+        totals6[3] = t.near;
+        totals6[4] = t.hypotheses;
+        totals6[5] = t.items;
     }
     return TM_OK;
 }

@@ -68,14 +68,14 @@ struct dbuf {
 
 struct score_timing {
     float ms = 0.f;
-    uint64_t evaluations = 0, passing = 0, hypotheses = 0, in_grid = 0, near = 0;
+    uint64_t evaluations = 0, passing = 0, hypotheses = 0, in_grid = 0, near = 0, items = 0;
 };
 
 /* Timed scoring launches are recorded without touching the host: an event pair and one row of device
  * counters per launch (ring of kTimedRing); tm_ctx_last_score_timing / tm_ctx_score_timing_totals
  * synchronise and read them when asked. */
 constexpr int kTimedRing = 256;
-constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, 4 spare */
+constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, staged items, 3 spare */
 
 }  // namespace tmx
 

@@ -387,6 +387,8 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
  * ---------------------------------------------------------------------------------------------- */
 constexpr int kGroupHyps = 16;
 constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
+constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs; five
+                                 waves = 96 VGPRs spill 100 bytes per lane and lose: 18.3 ms against 14.8) */
 
 struct group_args {
     const float4* chunks;   /* bounding sphere per 512 sorted points */
@@ -446,26 +448,20 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ pose12 lds_pose(const float4* p, float* rnorm = nullptr, float* abs_eps = nullptr) {
-    const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
-    if (rnorm) *rnorm = c0.w; /* the staging code keeps the two sphere-test constants in the unused bottom row */
-    if (abs_eps) *abs_eps = c1.w;
+/* pose as staged in LDS: three float4 = the rotation columns with the translation in the w components */
+__device__ __forceinline__ pose12 lds_pose(const float4* p) {
+    const float4 c0 = p[0], c1 = p[1], c2 = p[2];
     pose12 T;
-    T.r00 = c0.x; T.r10 = c0.y; T.r20 = c0.z;
-    T.r01 = c1.x; T.r11 = c1.y; T.r21 = c1.z;
-    T.r02 = c2.x; T.r12 = c2.y; T.r22 = c2.z;
-    T.tx = c3.x; T.ty = c3.y; T.tz = c3.z;
+    T.r00 = c0.x; T.r10 = c0.y; T.r20 = c0.z; T.tx = c0.w;
+    T.r01 = c1.x; T.r11 = c1.y; T.r21 = c1.z; T.ty = c1.w;
+    T.r02 = c2.x; T.r12 = c2.y; T.r22 = c2.z; T.tz = c2.w;
     return T;
 }
 
 template <bool L2, int NC>
-__global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args ca, group_args ga) {
-    __shared__ float s_pts[4][kChunkPts * 3];                 /* the item's 512 points, packed xyz */
-    __shared__ float4 s_pose[4][kGroupHyps * 4];              /* the group's poses, column-major 4x4 */
-    __shared__ unsigned short s_ent[4][kGroupHyps * 32];      /* surviving (hypothesis << 5 | quarter) */
-    __shared__ uint32_t s_cnt[4][kGroupHyps];
-    __shared__ unsigned long long s_fx[4][kGroupHyps];
-    __shared__ uint32_t s_st[4][4];
+__global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, cull_args ca, group_args ga) {
+    /* 8 KiB of LDS per wave, private to it: no workgroup barrier inside the loop */
+    __shared__ __align__(16) unsigned char s_raw[4][8192];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n_items = *ga.n_items;
     /* XCD-aware split (speed only): blocks b and b + 8 share an L2; consecutive items belong to the same
@@ -475,13 +471,12 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
     const uint32_t lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3);
     const uint32_t hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1u)) >> 3);
     uint32_t evals = 0, pass = 0, n_in = 0, n_near = 0;
-    float* pts = s_pts[wave];
-    float4* poses = s_pose[wave];
-    unsigned short* ent = s_ent[wave];
-    if (lane < (uint32_t)kGroupHyps) {
-        s_cnt[wave][lane] = 0u;
-        s_fx[wave][lane] = 0ull;
-    }
+    float* pts = reinterpret_cast<float*>(s_raw[wave]);                           /* 512 x packed xyz: 6144 B */
+    float4* poses = reinterpret_cast<float4*>(s_raw[wave] + 6144);                /* 16 poses x 3 float4: 768 B */
+    float2* auxl = reinterpret_cast<float2*>(s_raw[wave] + 6912);                 /* 16 x (rnorm, abs_eps): 128 B */
+    unsigned short* ent = reinterpret_cast<unsigned short*>(s_raw[wave] + 7040);  /* <= 512 entries: 1024 B */
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(s_raw[wave] + 8064); /* count << 52 | sum: 128 B */
+    if (lane < (uint32_t)kGroupHyps) acc[lane] = 0ull;
     for (uint32_t it = lo + wave_in_xcd; it < hi; it += waves_per_xcd) {
         const uint32_t slot = ga.items[it];
         const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
@@ -493,11 +488,12 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
             __builtin_amdgcn_wave_barrier();
             const float4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + lane], v3 = src[192 + lane],
                          v4 = src[256 + lane], v5 = src[320 + lane];
-            const uint32_t hp = min(group * kGroupHyps + (lane >> 2), a.n_hyp - 1u);
-            float4 pv = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + (lane & 3u)];
-            const float2 ax = ga.aux[hp];
-            if ((lane & 3u) == 0u) pv.w = ax.x;
-            if ((lane & 3u) == 1u) pv.w = ax.y;
+            /* lanes 0..47: column c of pose l / 3, its w replaced by the translation component c */
+            const uint32_t pl = min(lane, 47u);
+            const uint32_t hp = min(group * kGroupHyps + pl / 3u, a.n_hyp - 1u), pc = pl % 3u;
+            float4 pv = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + pc];
+            pv.w = a.poses[(size_t)hp * 16 + 12u + pc];
+            const float2 ax = ga.aux[min(group * kGroupHyps + (lane & 15u), a.n_hyp - 1u)];
             float4* dst = reinterpret_cast<float4*>(pts);
             dst[lane] = v0;
             dst[64 + lane] = v1;
@@ -505,7 +501,8 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
             dst[192 + lane] = v3;
             dst[256 + lane] = v4;
             dst[320 + lane] = v5;
-            poses[lane] = pv;
+            if (lane < 48u) poses[lane] = pv;
+            if (lane < 16u) auxl[lane] = ax;
         }
         const float4 qs = ca.subs[(size_t)chunk * 32u + (lane & 31u)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -522,8 +519,9 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
 #pragma unroll
             for (int r = 0; r < kGroupHyps / 2; ++r) {
                 const uint32_t g = 2u * r + (lane >> 5);
-                float rnorm, abs_eps;
-                const pose12 T = lds_pose(poses + 4u * g, &rnorm, &abs_eps);
+                const pose12 T = lds_pose(poses + 3u * g);
+                const float2 ax = auxl[g];
+                const float rnorm = ax.x, abs_eps = ax.y;
                 if (L2) {
                     pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
                 } else {
@@ -589,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const pose12 T = lds_pose(poses + 4u * gk[k]);
+                const pose12 T = lds_pose(poses + 3u * gk[k]);
                 const float* sp = pts + 3u * pidx[k];
                 q[k] = xform_point(T, make3(sp[0], sp[1], sp[2]));
                 float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
@@ -647,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
                         if (ok[k0 + j]) {
                             ++pass;
                             if (sr[j].w == mr[j].w) {
-                                const pose12 T = lds_pose(poses + 4u * gk[k0 + j]);
+                                const pose12 T = lds_pose(poses + 3u * gk[k0 + j]);
                                 f3 r = xform_dir(T, make3(sr[j].x, sr[j].y, sr[j].z));
                                 float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
                                 const unsigned long long t = (unsigned long long)(long long)((double)term * kFx);
@@ -659,9 +657,9 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
                             w_lo = row16_sum(w_lo);
                             w_hi = row16_sum(w_hi);
                             if ((lane & 15u) == 15u && w_lo != 0u) {
-                                atomicAdd(&s_cnt[wave][gk[k0 + j]], w_lo >> 24);
-                                atomicAdd(&s_fx[wave][gk[k0 + j]],
-                                          ((unsigned long long)w_hi << 20) + (unsigned long long)(w_lo & 0xFFFFFFu));
+                                atomicAdd(&acc[gk[k0 + j]],
+                                          ((unsigned long long)(w_lo >> 24) << 52) +
+                                              ((unsigned long long)w_hi << 20) + (unsigned long long)(w_lo & 0xFFFFFFu));
                             }
                         }
                     }
@@ -673,13 +671,12 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < (uint32_t)kGroupHyps) {
-            const uint32_t c = s_cnt[wave][lane];
-            if (c && a.ablate != 11) {
+            const unsigned long long v = acc[lane];
+            if (v && a.ablate != 11) {
                 const uint32_t h = group * kGroupHyps + lane;
-                atomicAdd(&a.counts[h], c);
-                atomicAdd(&a.scores_fx[h], s_fx[wave][lane]);
-                s_cnt[wave][lane] = 0u;
-                s_fx[wave][lane] = 0ull;
+                atomicAdd(&a.counts[h], (uint32_t)(v >> 52));
+                atomicAdd(&a.scores_fx[h], v & 0xFFFFFFFFFFFFFull);
+                acc[lane] = 0ull;
             }
         }
     }
@@ -689,6 +686,8 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
         n_in += __shfl_down(n_in, off);
         n_near += __shfl_down(n_near, off);
     }
+    __syncthreads();
+    uint32_t(*s_st)[4] = reinterpret_cast<uint32_t(*)[4]>(s_raw[0]); /* the loop is over: reuse wave 0's area */
     if (lane == 0) {
         s_st[wave][0] = evals;
         s_st[wave][1] = pass;
@@ -706,6 +705,7 @@ __global__ __launch_bounds__(256, 4) void k_score_items(score_args a, cull_args 
 /* sums the per-workgroup stat slots of one scoring launch into that launch's row of device counters
  * (one workgroup, plain stores: nothing for the host to wait for inside a timed loop) */
 __global__ __launch_bounds__(1024) void k_stats_reduce(const uint4* __restrict__ slots, uint32_t n_slots,
+                                                       const uint32_t* __restrict__ n_items,
                                                        unsigned long long* __restrict__ row) {
     __shared__ unsigned long long s_acc[16][4];
     unsigned long long acc[4] = {0, 0, 0, 0};
@@ -729,6 +729,7 @@ __global__ __launch_bounds__(1024) void k_stats_reduce(const uint4* __restrict__
         for (int w = 0; w < 16; ++w) r += s_acc[w][threadIdx.x];
         row[threadIdx.x] = r;
     }
+    if (threadIdx.x == 4) row[4] = n_items ? *n_items : 0u; /* grouped kernel: chunks staged into LDS */
 }
 
 /* subset flags (original order) -> sorted order of the scoring arrays */
@@ -1083,6 +1084,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
     const size_t n_slots = culled ? (size_t)n_hyp : (size_t)grid.x * grid.y;
     size_t n_stat_slots = n_slots; /* slots the launched kernel actually writes */
+    const uint32_t* d_n_items = nullptr; /* grouped kernel: device count of staged (group, chunk) items */
     TM_FORWARD(s->w_stats.ensure(n_slots));
     a.stat_slots = s->w_stats.p;
     const uint32_t trow = (uint32_t)(c->n_timed % kTimedRing);
@@ -1108,7 +1110,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                                s->d_order.p, s->n, s->n_sorted, s->w_active_sorted.p);
             ca.active_sorted = s->w_active_sorted.p;
         }
-        bool grouped = l2 && !d_active && !d_centers;
+        bool grouped = !d_active && !d_centers;
         if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
         if (grouped) {
             /* groups of kGroupHyps consecutive hypotheses share the scene chunks they reach */
@@ -1128,6 +1130,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.masks = s->w_masks.p;
             ga.items = s->w_items.p;
             ga.n_items = s->w_items.p + n_slots_g;
+            d_n_items = ga.n_items;
             hipLaunchKernelGGL(k_group_cull, dim3((ga.n_chunks + 255) / 256, ga.n_groups), dim3(256), 0, c->stream,
                                a, ca, ga);
             size_t tmp = 0;
@@ -1142,7 +1145,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
             /* persistent waves with a static share of the items each: the grid must be exactly what is
              * resident at once, or the surplus workgroups run their share after everyone else */
-            auto kern = k_score_items<true, 4>;
+            auto kern = l2 ? k_score_items<true, 4> : k_score_items<false, 4>;
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
@@ -1196,6 +1199,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_HIP_CHECK(hipGetLastError());
     if (c->timing) { /* no host synchronisation here: the counters stay on the device until asked for */
         hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, c->stream, s->w_stats.p, (uint32_t)n_stat_slots,
+                           d_n_items,
                            c->stats.p + (size_t)trow * kTimedWords);
         TM_HIP_CHECK(hipGetLastError());
         c->timed_hyp[trow] = n_hyp;
