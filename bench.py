@@ -130,13 +130,41 @@ def main():
 
     cuda_dev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
 
+    # the library's own RCCL communicator (C ABI: tm_comm_create / tm_best_reduce). torch.distributed only
+    # carries the 128-byte unique id to the other ranks, the barriers and the timing reduction.
+    comm = None
+    if not args.rehearse_on_one_gpu:
+        uid = None
+        if world > 1:
+            t = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=cuda_dev)
+            if rank == 0:
+                t = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device=cuda_dev)
+            dist.broadcast(t, src=0)
+            uid = bytes(t.cpu().numpy().tobytes())
+        comm = capi.Comm(ctx, rank, world, uid)
+    d_best = ctx.alloc(96)
+
+    class _Done:
+        def __init__(self, rec):
+            self._rec = rec
+
+        def result(self):
+            return self._rec
+
     def step():
         n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
         gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
-        best = ctx.best_of_batch(d_counts, d_scores, d_poses, n, id_offset=rank, id_stride=world)
-        # one 96-byte-per-rank RCCL all-gather + deterministic argmax (tm_best_select); started here, awaited
-        # after the next batch has been launched, so the exchange overlaps that batch's kernels
-        return n, tmd.allgather_best_async(best, device=cuda_dev)
+        # local argmax on the device with ids that do not depend on the number of ranks (global sample pair
+        # index * query_limit + entry), then ONE ncclAllGather of the 96-byte records on the library's stream
+        # and the deterministic selection (tm_best_reduce): no host hop for the payload
+        ctx.best_of_batch_prov(d_counts, d_scores, d_poses, d_prov, n, d_best, pair_offset=rank, pair_stride=world,
+                               query_limit=200)
+        if comm is not None:
+            return n, _Done(comm.best_reduce(d_best, 1)[0])
+        # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device): the same records over gloo
+        rec = capi.BestRecord()
+        ctx.d2h(np.frombuffer(rec, dtype=np.uint8), d_best)
+        return n, tmd.allgather_best_async(rec, device=cuda_dev)
 
     def sync_all():
         if world > 1:

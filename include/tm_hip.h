@@ -272,8 +272,37 @@ typedef struct tm_best_record {
 int tm_best_of_batch(tm_ctx* ctx, const uint32_t* d_counts, const double* d_scores,
                      const float* d_poses16, uint32_t n_hyp, uint32_t id_offset, uint32_t id_stride,
                      tm_best_record* best);
-/* deterministic selection among records (host); used after the RCCL all-gather */
+/* deterministic selection among records (host) */
 int tm_best_select(const tm_best_record* records, uint32_t n, tm_best_record* best);
+
+/* ---- multi-GPU: one process per GPU, one RCCL collective per batch (new functionality) ----
+ * The reference's only reduction is fut.get() + std::sort over its worker threads
+ * (include/impl/scene.hpp:168-195). Here every rank holds a replica of scene / model / table, the sample
+ * pairs (bench, multi-model search) or the first-point chunks of find_parallel (scene<Point>) are dealt to
+ * the ranks, and the 96-byte records meet in ONE ncclAllGather over xGMI on the context's stream followed
+ * by the deterministic selection. RCCL is bound at run time (dlopen librccl.so.1); without it these calls
+ * return TM_ERR_UNSUPPORTED. Bootstrap: rank 0 calls tm_comm_get_unique_id and hands the 128 bytes to the
+ * other ranks by whatever channel the application has (MPI_Bcast, a file, torch.distributed). */
+typedef struct tm_comm tm_comm;
+#define TM_COMM_ID_BYTES 128
+int tm_comm_get_unique_id(unsigned char id[TM_COMM_ID_BYTES]);
+/* collective: every rank calls it with the same id. id may be null for world == 1 (no RCCL state). */
+int tm_comm_create(tm_ctx* ctx, int rank, int world, const unsigned char id[TM_COMM_ID_BYTES], tm_comm** comm);
+int tm_comm_destroy(tm_comm* comm);
+int tm_comm_rank(const tm_comm* comm);
+int tm_comm_world(const tm_comm* comm);
+/* local argmax with ids that do not depend on the number of ranks: hypothesis id = global sample pair
+ * index * query_limit + entry within the pair, global pair = pair_offset + local pair * pair_stride
+ * (d_provenance4 as written by tm_generate_hypotheses_dev). The record stays on the device (d_best). */
+int tm_best_of_batch_prov(tm_ctx* ctx, const uint32_t* d_counts, const double* d_scores, const float* d_poses16,
+                          const uint32_t* d_provenance4, uint32_t n_hyp, uint32_t pair_offset,
+                          uint32_t pair_stride, uint32_t query_limit, tm_best_record* d_best);
+/* collective: d_local = this rank's n_models records ON THE DEVICE (no host hop); best = the n_models
+ * global winners (host), identical on every rank. comm may be null (single process). */
+int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models,
+                   tm_best_record* best);
+/* collective all-gather of host records (find_parallel's per-chunk candidates): all[r * n + k] */
+int tm_comm_allgather_records(tm_comm* comm, const tm_best_record* local, uint32_t n, tm_best_record* all);
 
 /* ---- traits projector math (host side; replaces the statics of the include/<kind>_traits headers) ---- */
 int   tm_traits_init_from_samples(int kind, const float* model_state, const float* samples,

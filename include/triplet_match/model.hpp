@@ -42,10 +42,12 @@ public:
     model(const model&) = delete;
     model& operator=(const model&) = delete;
 
-    /* apply the curvature half of the subset filter, `pc_min / pc_max < 0.2` on curvature(k, idx)
-     * (include/impl/model.hpp:68-71,96-99). The reference always applies it (k = 30); it is opt-in here
-     * because tangents from other edge detectors need not satisfy it. */
+    /* The curvature half of the subset filter, `pc_min / pc_max < 0.2` on curvature(k, idx)
+     * (include/impl/model.hpp:68-71,96-99), is applied by default with the reference's k = 30
+     * (detail::curvature_k, include/impl/scene.hpp:24), like the reference does. disable_curvature_filter()
+     * opts out (tangents from another edge detector need not satisfy it). */
     void enable_curvature_filter(uint32_t k = 30) { curvature_k_ = k; }
+    void disable_curvature_filter() { curvature_k_ = 0; }
 
     void init(const sample_parameters& sample_params) { init(subset_t(), sample_params); }
 
@@ -138,7 +140,7 @@ protected:
     mat4f_t to_voxel_;
     feature_bounds_t bounds_;
     uint64_t pair_count_ = 0;
-    uint32_t curvature_k_ = 0;
+    uint32_t curvature_k_ = 30;
     std::vector<entry_t> last_query_;
 };
 

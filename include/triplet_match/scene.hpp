@@ -162,6 +162,19 @@ struct hip_backend {
     void set_mask(const std::vector<int32_t>& mask) { check(tm_scene_set_mask(s, mask.data()), "tm_scene_set_mask"); }
 };
 
+/* search.hpp Exchange over the C ABI's RCCL communicator */
+struct hip_exchange {
+    tm_comm* c;
+    int rank() const { return tm_comm_rank(c); }
+    int world() const { return tm_comm_world(c); }
+    void allgather(const search::chunk_record* local, uint32_t n, search::chunk_record* all) const {
+        static_assert(sizeof(search::chunk_record) == sizeof(tm_best_record), "record layouts must agree");
+        check(tm_comm_allgather_records(c, reinterpret_cast<const tm_best_record*>(local), n,
+                                        reinterpret_cast<tm_best_record*>(all)),
+              "tm_comm_allgather_records");
+    }
+};
+
 }  // namespace detail
 
 template <typename Point>
@@ -195,8 +208,21 @@ public:
     /* the curvature-ratio half of tangent_mask_ (include/impl/scene.hpp:50) is a "next" row; supply one
      * flag per point to apply it */
     void set_curvature_ok(const std::vector<uint8_t>& ok) { curvature_ok_ = ok; }
-    /* curvature half of tangent_mask_ computed like the reference (kNN-k, ratio < 0.2); opt-in */
+    /* curvature half of tangent_mask_ (kNN-k, pc_min / pc_max < 0.2, include/impl/scene.hpp:49-52): on by
+     * default with the reference's k = 30; disable_curvature_filter() opts out */
     void enable_curvature_filter(uint32_t k = 30) { curvature_k_ = k; }
+    void disable_curvature_filter() { curvature_k_ = 0; }
+    /* Multi-GPU search: one process per GPU, every process holds the same scene and model and calls
+     * find_all_parallel with the same arguments; the first-point chunks of every round are dealt to the ranks
+     * and one RCCL all-gather of 96-byte records per round brings their candidates together (search.hpp).
+     * Every rank returns the same matches, and the same matches as a single process. */
+    void set_communicator(tm_comm* comm) { comm_ = comm; }
+    /* the device copy of the scene is kept between find_all_parallel calls; call this after changing the
+     * cloud's points in place */
+    void invalidate() {
+        if (h_) tm_scene_destroy(h_);
+        h_ = nullptr;
+    }
     void set_workers(uint32_t w) { workers_ = w; }
     /* detail::early_drop of the reference (include/impl/scene.hpp:25) is true; switching it off scores
      * every hypothesis to the end and enables the batched GPU path (16 first points per launch) */
@@ -220,10 +246,15 @@ public:
             }
             tangent_mask[i] = t ? 1 : 0;
         }
-        if (h_) tm_scene_destroy(h_);
-        h_ = nullptr;
-        detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
-                      "tm_scene_create");
+        /* the prepared scene (56 MB upload + sort for 1M points) is reused while cloud size and tangent mask
+         * are unchanged; find_all resets mask_ itself */
+        if (h_ && (cached_n_ != n || cached_tmask_ != tangent_mask)) invalidate();
+        if (!h_) {
+            detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
+                          "tm_scene_create");
+            cached_n_ = n;
+            cached_tmask_ = tangent_mask;
+        }
         detail::hip_backend<Point> be;
         be.s = h_;
         be.m = m.handle();
@@ -243,7 +274,13 @@ public:
         be.p.verbose = verbose_;
         stats_ = search::stats_t();
         be.p.stats = &stats_;
-        auto found = search::find_all(be, tangent_mask, be.p);
+        std::vector<search::candidate_t> found;
+        if (comm_ && tm_comm_world(comm_) > 1) {
+            detail::hip_exchange hx{comm_};
+            found = search::find_all(be, tangent_mask, be.p, hx);
+        } else {
+            found = search::find_all(be, tangent_mask, be.p);
+        }
         std::vector<match_t> results;
         for (auto& c : found) {
             match_t r;
@@ -281,7 +318,10 @@ protected:
     tm_scene* h_ = nullptr;
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
-    uint32_t curvature_k_ = 0;
+    uint32_t curvature_k_ = 30;
+    tm_comm* comm_ = nullptr;
+    uint32_t cached_n_ = 0;
+    std::vector<int32_t> cached_tmask_;
     bool early_drop_ = true;
     bool verbose_ = false;
     search::stats_t stats_;

@@ -50,6 +50,31 @@ struct stats_t {
            mask = 0, total = 0;
 };
 
+/* What one chunk of first points (one worker of the reference, include/impl/scene.hpp:156-166) hands to
+ * the arbitration: whether it found a sufficient hypothesis, how many first points it considered (they
+ * are marked in fp_mask_, :160-162) and the candidate's pose after ICP. 96 bytes, the layout of the C
+ * ABI's tm_best_record, so that tm_comm_allgather_records can carry it between ranks. */
+struct chunk_record {
+    uint32_t considered = 0;
+    uint32_t found = 0; /* 1 = pose is a candidate */
+    double reserved = 0.0;
+    float pose[16] = {0};
+    uint32_t pad[4] = {0, 0, 0, 0};
+};
+static_assert(sizeof(chunk_record) == 96, "chunk_record must match tm_best_record");
+
+/* Exchange concept (multi-GPU search, one process per GPU, every rank holds a replica of scene and model):
+ *   int rank(); int world();
+ *   void allgather(const chunk_record* local, uint32_t n, chunk_record* all);  // all[r * n + k]
+ * single_rank is the trivial one. */
+struct single_rank {
+    int rank() const { return 0; }
+    int world() const { return 1; }
+    void allgather(const chunk_record* local, uint32_t n, chunk_record* all) const {
+        for (uint32_t k = 0; k < n; ++k) all[k] = local[k];
+    }
+};
+
 struct params_t {
     float dist_thres = 3.f;
     float accept_prob = 0.5f; /* model_match_factor */
@@ -332,11 +357,12 @@ inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p)
 }
 
 /* find_parallel, include/impl/scene.hpp:108-240 */
-template <class Backend>
+template <class Backend, class Exchange>
 inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uint32_t>& tangent_indices,
                                               uint32_t n_scene, std::vector<int32_t>& mask,
                                               std::vector<int32_t>& fp_mask,
-                                              const std::vector<int32_t>& tangent_mask, const params_t& p) {
+                                              const std::vector<int32_t>& tangent_mask, const params_t& p,
+                                              Exchange& ex) {
     const uint32_t n_model = be.model_point_count();
     const uint32_t n_model_all = be.model_size();
     const uint32_t min_points = (uint32_t)((1.f * p.accept_prob) * (float)n_model);      /* :114 */
@@ -365,6 +391,46 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     uint64_t batch = outer_bound / concurrency;
     if (outer_bound % concurrency > 0) ++batch;
     std::vector<candidate_t> cands;
+    if (ex.world() > 1) {
+        /* Several ranks: the chunks are independent of one another inside a round (a chunk reads fp_mask_
+         * only at its own first points, :268, and nothing else changes before the arbitration), so chunk c
+         * goes to rank c mod world. Every rank searches and refines its chunks, ONE all-gather of 96-byte
+         * chunk records follows, and every rank rebuilds all candidates (finish_find of the exchanged pose)
+         * in chunk order: the arbitration below then sees the same list on every rank, and the same list as
+         * a single rank would, whatever the number of ranks. */
+        const uint32_t world = (uint32_t)ex.world(), rank = (uint32_t)ex.rank();
+        const uint32_t n_chunks = (uint32_t)((outer.size() + batch - 1) / batch);
+        const uint32_t per_rank = (n_chunks + world - 1) / world;
+        std::vector<chunk_record> local(per_rank), all((size_t)per_rank * world);
+        std::vector<std::vector<uint32_t>> chunks(n_chunks);
+        for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+            const uint64_t c0 = (uint64_t)ci * batch;
+            chunks[ci].assign(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
+        }
+        for (uint32_t ci = rank; ci < n_chunks; ci += world) {
+            auto res = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, p);
+            chunk_record& r = local[ci / world];
+            r.considered = res.second;
+            if (!res.first.empty()) { /* at most one per chunk: the first sufficient hypothesis */
+                const candidate_t refined = icp(be, res.first[0], p);
+                r.found = 1;
+                for (int k = 0; k < 16; ++k) r.pose[k] = refined.transform.m[k];
+            }
+        }
+        ex.allgather(local.data(), per_rank, all.data());
+        const float dt = p.max_icp_iterations == 0 ? p.dist_thres : 2.f * p.dist_thres; /* what icp() extracts with */
+        for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+            const chunk_record& r = all[(size_t)(ci % world) * per_rank + ci / world];
+            for (uint32_t k = 0, seen = 0; k < chunks[ci].size() && seen < r.considered; ++k, ++seen)
+                fp_mask[chunks[ci][k]] = 1; /* :160-162 */
+            if (!r.found) continue;
+            pose_t T;
+            for (int k = 0; k < 16; ++k) T.m[k] = r.pose[k];
+            candidate_t c;
+            be.extract(T, dt, c);
+            cands.push_back(std::move(c));
+        }
+    } else
     for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) { /* chunks, :156-166 (run one after another) */
         std::vector<uint32_t> chunk(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
         auto res = find_in_subset(be, chunk, mask, fp_mask, tangent_mask, p);
@@ -413,9 +479,9 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
 
 /* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
  * inverts them (:92). */
-template <class Backend>
+template <class Backend, class Exchange>
 inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>& tangent_mask,
-                                         const params_t& p) {
+                                         const params_t& p, Exchange& ex) {
     const uint32_t n = be.scene_size();
     std::vector<int32_t> mask(n, 0), fp_mask(n, 0);
     std::vector<uint32_t> tangent_indices;
@@ -426,7 +492,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     be.set_mask(mask);
     std::vector<candidate_t> results;
     for (;;) {
-        auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p);
+        auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p, ex);
         if (matches.empty()) break;
         for (auto& mt : matches) {
             for (uint32_t idx : mt.scene_corrs) mask[idx] = 1; /* :88-90 */
@@ -436,6 +502,13 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
         be.set_mask(mask);
     }
     return results;
+}
+
+template <class Backend>
+inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>& tangent_mask,
+                                         const params_t& p) {
+    single_rank ex;
+    return find_all(be, tangent_mask, p, ex);
 }
 
 }  // namespace search

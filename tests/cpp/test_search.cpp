@@ -6,6 +6,8 @@
  */
 #include <cstdio>
 #include <fstream>
+#include <thread>
+#include <unistd.h>
 
 #include "../../oracle/tm_oracle.h"
 #include "triplet_match/scene.hpp"
@@ -100,6 +102,44 @@ struct oracle_backend {
     }
 };
 
+/* Exchange over a shared directory, for the multi-process CPU test of the rank-sharded search (the product
+ * exchange is RCCL through tm_comm_allgather_records): every all-gather writes <dir>/x<seq>_r<rank>.bin
+ * (atomic rename) and waits for the files of the other ranks. */
+struct file_exchange {
+    std::string dir;
+    int rank_, world_;
+    uint32_t seq = 0;
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    void allgather(const search::chunk_record* local, uint32_t n, search::chunk_record* all) {
+        char name[512], tmp[512];
+        snprintf(name, sizeof name, "%s/x%u_r%d.bin", dir.c_str(), seq, rank_);
+        snprintf(tmp, sizeof tmp, "%s.tmp", name);
+        {
+            std::ofstream o(tmp, std::ios::binary);
+            o.write((const char*)&n, 4);
+            o.write((const char*)local, (std::streamsize)n * sizeof(search::chunk_record));
+        }
+        rename(tmp, name);
+        for (int r = 0; r < world_; ++r) {
+            snprintf(name, sizeof name, "%s/x%u_r%d.bin", dir.c_str(), seq, r);
+            for (int tries = 0;; ++tries) {
+                std::ifstream in(name, std::ios::binary);
+                uint32_t m = 0;
+                if (in.good() && in.read((char*)&m, 4) && m == n &&
+                    in.read((char*)(all + (size_t)r * n), (std::streamsize)n * sizeof(search::chunk_record)))
+                    break;
+                if (tries > 60000) {
+                    fprintf(stderr, "file_exchange: rank %d never wrote %s\n", r, name);
+                    exit(5);
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        }
+        ++seq;
+    }
+};
+
 static pointcloud<P>::Ptr read_cloud(std::ifstream& in) {
     uint32_t n = 0;
     in.read((char*)&n, 4);
@@ -119,6 +159,8 @@ static void dump(const char* tag, const std::vector<search::candidate_t>& r) {
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
     const bool both = std::string(argv[2]) == "both" || std::string(argv[2]) == "both_noearlydrop";
+    /* "sharded <dir> <rank> <world>": this process is one rank of a rank-sharded search over the oracle */
+    const bool sharded = std::string(argv[2]) == "sharded" && argc >= 6;
     const bool no_early_drop = std::string(argv[2]) == "both_noearlydrop" || std::string(argv[2]) == "oracle_noearlydrop";
     std::ifstream in(argv[1], std::ios::binary);
     auto mcloud = read_cloud(in);
@@ -132,11 +174,23 @@ int main(int argc, char** argv) {
     if (!in.good()) return 3;
 
     const float angle_step = 10.f * (float)M_PI / 180.f;
+    /* the reference's masks (include/impl/model.hpp:96-99, include/impl/scene.hpp:49-52): |tangent| > 0.7
+     * and pc_min / pc_max < 0.2 on curvature(30, i); the curvature comes from the oracle here */
+    std::vector<float> mcurv(5 * mcloud->size()), scurv(5 * scloud->size());
+    tmo_cloud_curvature(mcloud->points[0].raw(), (uint32_t)mcloud->size(), 30, mcurv.data(), 8);
+    tmo_cloud_curvature(scloud->points[0].raw(), (uint32_t)scloud->size(), 30, scurv.data(), 8);
     std::vector<uint32_t> subset;
     for (uint32_t i = 0; i < mcloud->size(); ++i)
-        if (tangent(mcloud->points[i]).norm() > 0.7f) subset.push_back(i);
+        if (tangent(mcloud->points[i]).norm() > 0.7f && (mcurv[5 * (size_t)i + 3] / mcurv[5 * (size_t)i + 4]) < 0.2f)
+            subset.push_back(i);
     std::vector<int32_t> tmask(scloud->size());
-    for (uint32_t i = 0; i < scloud->size(); ++i) tmask[i] = tangent(scloud->points[i]).norm() > 0.7f ? 1 : 0;
+    uint32_t n_tmask = 0;
+    for (uint32_t i = 0; i < scloud->size(); ++i) {
+        tmask[i] = (tangent(scloud->points[i]).norm() > 0.7f &&
+                    (scurv[5 * (size_t)i + 3] / scurv[5 * (size_t)i + 4]) < 0.2f) ? 1 : 0;
+        n_tmask += (uint32_t)tmask[i];
+    }
+    printf("masks (tangent and curvature ratio): model subset %zu, scene tangent_mask %u\n", subset.size(), n_tmask);
 
     search::params_t p;
     p.dist_thres = 3.f;
@@ -155,8 +209,24 @@ int main(int argc, char** argv) {
     ob.n_t = (uint32_t)subset.size();
     ob.p = p;
     ob.tmask = tmask;
-    auto ro = search::find_all(ob, tmask, p);
+    std::vector<search::candidate_t> ro;
+    if (sharded) {
+        file_exchange fx{argv[3], atoi(argv[4]), atoi(argv[5])};
+        ro = search::find_all(ob, tmask, p, fx);
+    } else {
+        ro = search::find_all(ob, tmask, p);
+    }
     dump("oracle backend", ro);
+    for (const auto& c : ro) { /* fingerprint of the whole result, for the sharded == single-process test */
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](const void* d, size_t n) {
+            for (size_t k = 0; k < n; ++k) h = (h ^ ((const unsigned char*)d)[k]) * 1099511628211ull;
+        };
+        mix(c.transform.m, 64);
+        mix(c.scene_corrs.data(), c.scene_corrs.size() * 4);
+        mix(c.model_corrs.data(), c.model_corrs.size() * 4);
+        printf("   fingerprint %016llx\n", h);
+    }
     int failures = 0;
     if (ro.empty()) {
         printf("FAIL no candidate found by the host logic over the oracle\n");
@@ -189,7 +259,11 @@ int main(int argc, char** argv) {
         mcloud->set_resolution(res);
         model<P> gm(mcloud, dp);
         sample_parameters sp;
-        gm.init(sp);
+        gm.init(sp); /* default = the reference's subset filter, curvature on the GPU */
+        if (gm.point_count() != subset.size()) {
+            printf("FAIL model<P>::init subset (%u) differs from the oracle's masks (%zu)\n", gm.point_count(), subset.size());
+            ++failures;
+        }
         tm_scene* gs = nullptr;
         detail::check(tm_scene_create(gm.context(), scloud->points[0].raw(), (uint32_t)scloud->size(), tmask.data(), &gs),
                       "tm_scene_create");

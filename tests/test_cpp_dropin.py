@@ -66,6 +66,34 @@ def test_host_orchestration_over_oracle_backend(tmp_path):
     assert r.returncode == 0 and "PASSED" in r.stdout
 
 
+def _result_lines(text):
+    return [ln for ln in text.splitlines() if ln.startswith("oracle backend") or ln.startswith("   corrs")
+            or ln.startswith("   fingerprint")]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_sharded_search_equals_single_process(tmp_path, world):
+    """Multi-GPU find_all_parallel: the first-point chunks of every round are dealt to the
+    ranks, ONE all-gather of 96-byte chunk records per round, every rank arbitrates the same candidate list.
+    Here `world` processes over the CPU oracle backend exchange through a directory; each must print exactly
+    what the single-process search prints (poses, correspondences: fingerprints)."""
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "case.bin"))
+    single = subprocess.run([exe, fx, "oracle"], capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0 and "PASSED" in single.stdout
+    xdir = tmp_path / ("x%d" % world)
+    xdir.mkdir()
+    procs = [subprocess.Popen([exe, fx, "sharded", str(xdir), str(r), str(world)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    want = _result_lines(single.stdout)
+    assert len(want) >= 3
+    for p, (out, err) in zip(procs, outs):
+        print(out[-1500:], err[-500:])
+        assert p.returncode == 0 and "PASSED" in out
+        assert _result_lines(out) == want
+
+
 @pytest.mark.gpu
 def test_host_orchestration_hip_equals_oracle(tmp_path):
     exe = _compile("test_search", _oracle_link())

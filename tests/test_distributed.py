@@ -45,7 +45,8 @@ def _worker(rank, world, port, out_dir):
     if len(poses):
         order = sorted(range(len(poses)), key=lambda i: (-int(counts[i]), -scores[i], i))
         b = order[0]
-        rec = tmd.make_record(counts[b], tmd.global_hyp_id(b, rank, world), scores[b], poses[b])
+        rec = tmd.make_record(counts[b], tmd.canonical_hyp_id(int(prov[b][0]), int(prov[b][3]), rank, world),
+                              scores[b], poses[b])
     else:
         rec = tmd.empty_record()
     best = tmd.allgather_best(rec)
@@ -73,8 +74,37 @@ def test_two_rank_gloo_shard_and_best_reduce(tmp_path):
     exp = sorted(locals_, key=lambda r: (-r[0], -r[2], r[1]))[0]
     assert b0[0] == exp[0] and b0[1] == exp[1] and b0[2] == exp[2]
     assert b0[0] > 600  # a planted instance was found by one of the shards
-    # ids are global: rank r owns ids r, r + 2, ...
-    assert int(b0[1]) % 2 in (0, 1) and int(locals_[0][1]) % 2 == 0 and int(locals_[1][1]) % 2 == 1
+    # ids are canonical: global pair index * 200 + entry, and rank r owns the global pairs r, r + 2, ...
+    assert (int(locals_[0][1]) // 200) % 2 == 0 and (int(locals_[1][1]) // 200) % 2 == 1
+
+
+def test_winner_among_ties_does_not_depend_on_world_size():
+    """Hypothesis ids come from provenance (global sample pair, entry), so the tie-break (count desc, score
+    desc, id asc) picks the same hypothesis for 1, 2 and 4 ranks. Synthetic table with many exact ties."""
+    sys.path.insert(0, ROOT)
+    from triplet_match_amd import capi
+    from triplet_match_amd import dist as tmd
+    rng = np.random.default_rng(3)
+    n_pairs = 23
+    entries = rng.integers(1, 9, size=n_pairs)  # hypotheses per sample pair
+    counts = [rng.integers(5, 8, size=e) for e in entries]  # few distinct values: ties everywhere
+    scores = [np.round(rng.random(e), 1) for e in entries]
+    winners = []
+    for world in (1, 2, 4):
+        recs = []
+        for rank in range(world):
+            best = None
+            for lp, p in enumerate(range(rank, n_pairs, world)):  # shard_pairs order
+                for e in range(entries[p]):
+                    hid = tmd.canonical_hyp_id(lp, e, rank, world)
+                    assert hid == p * 200 + e
+                    key = (-int(counts[p][e]), -float(scores[p][e]), hid)
+                    if best is None or key < best[0]:
+                        best = (key, tmd.make_record(counts[p][e], hid, scores[p][e], np.arange(16) + hid))
+            recs.append(best[1] if best else tmd.empty_record())
+        w = capi.best_select(recs)
+        winners.append((w.inlier_count, w.score, w.hyp_id, tuple(w.pose)))
+    assert winners[0] == winners[1] == winners[2]
 
 
 def test_shard_is_a_partition():
@@ -132,13 +162,14 @@ def _worker_multi(rank, world, port, out_dir, n_models):
         assert m.build_pairs(sub) == 0
         pairs = synth.sample_scene_pairs(dict(surfels=surf, tangent_mask=tmask), m.diameter, 12, 3, seed=13)
         shard = tmd.shard_pairs_2d(pairs, rank, world, n_models)
-        poses, _ = s.generate_hypotheses(m, shard)
+        poses, prov = s.generate_hypotheses(m, shard)
         if len(poses) == 0:
             recs.append(tmd.empty_record())
             continue
         counts, scores, _ = s.score_hypotheses(m, poses, 0.5, 3.0, threads=2)
         b = sorted(range(len(poses)), key=lambda i: (-int(counts[i]), -scores[i], i))[0]
-        recs.append(tmd.make_record(counts[b], tmd.global_hyp_id_2d(b, rank, world, n_models), scores[b], poses[b]))
+        recs.append(tmd.make_record(counts[b], tmd.canonical_hyp_id_2d(int(prov[b][0]), int(prov[b][3]), rank, world,
+                                                                    n_models), scores[b], poses[b]))
     best = tmd.allgather_best_many(recs)
     out = np.array([[b.inlier_count, b.hyp_id, b.score] for b in best], dtype=np.float64)
     loc = np.array([[r.inlier_count, r.hyp_id, r.score] for r in recs], dtype=np.float64)

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtm_hip.so")
-SOURCES = ["tm_core.hip", "tm_model.hip", "tm_scene.hip", "tm_scene_build.hip", "tm_traits.hip", "tm_earlydrop.hip"]
+SOURCES = ["tm_core.hip", "tm_model.hip", "tm_scene.hip", "tm_scene_build.hip", "tm_traits.hip", "tm_earlydrop.hip", "tm_comm.hip"]
 HEADERS = ["tm_math.h", "tm_internal.h", "tm_table.h", "tm_traits_math.h", "tm_score.h",
            os.path.join("..", "..", "include", "tm_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

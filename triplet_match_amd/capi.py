@@ -106,6 +106,14 @@ SIGNATURES = {
     "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(BestRecord)]),
     "tm_best_select": (C.c_int, [C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
+    "tm_comm_get_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "tm_comm_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(vp)]),
+    "tm_comm_destroy": (C.c_int, [vp]),
+    "tm_comm_rank": (C.c_int, [vp]),
+    "tm_comm_world": (C.c_int, [vp]),
+    "tm_best_of_batch_prov": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
+    "tm_best_reduce": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(BestRecord)]),
+    "tm_comm_allgather_records": (C.c_int, [vp, C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
     "tm_traits_init_from_samples": (C.c_int, [C.c_int, f32p, f32p, f32p]),
     "tm_traits_project": (C.c_int, [C.c_int, f32p, f32p, f32p]),
     "tm_traits_unproject": (None, [C.c_int, f32p, f32p, f32p]),
@@ -322,6 +330,13 @@ class Context:
                                       id_stride, C.byref(rec)))
         return rec
 
+    def best_of_batch_prov(self, d_counts, d_scores, d_poses, d_prov, n_hyp, d_best, pair_offset=0, pair_stride=1,
+                           query_limit=200):
+        """Local argmax with canonical ids (global pair index * query_limit + entry); the record is written
+        to the device buffer d_best (96 bytes) and stays there for Comm.best_reduce."""
+        _check(lib().tm_best_of_batch_prov(self.h, d_counts, d_scores, d_poses, d_prov, n_hyp, pair_offset,
+                                           pair_stride, query_limit, d_best))
+
     def traits_project_cloud(self, kind, state, surfels):
         st, pst = _f(state)
         s, ps = _f(np.asarray(surfels).reshape(-1, 12))
@@ -361,6 +376,51 @@ def cl_icp_correlation(ctx, scene4, model4, idx_scene, idx_model, centroid_scene
     _check(lib().tm_cl_icp_correlation(ctx.h, ps, s.shape[0], pm, m.shape[0], pa, pb, a.size, pcs, pcm,
                                        cov.ctypes.data_as(f64p)))
     return cov
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes rank 0 creates and hands to the other ranks (any channel) before Comm(...)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().tm_comm_get_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of the C ABI (tm_comm): one per process / GPU. Collective constructor."""
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+        self.ctx = ctx
+        self.h = vp()
+        idp = None
+        if unique_id is not None:
+            assert len(unique_id) == COMM_ID_BYTES
+            idp = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().tm_comm_create(ctx.h, rank, world, idp, C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tm_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def best_reduce(self, d_local, n_models=1):
+        """d_local: device pointer to this rank's n_models records. Returns the global winners (host)."""
+        out = (BestRecord * n_models)()
+        _check(lib().tm_best_reduce(self.ctx.h, self.h, d_local, n_models, out))
+        return [BestRecord.from_buffer_copy(bytes(out[k])) for k in range(n_models)]
+
+    def allgather_records(self, records):
+        n = len(records)
+        loc = (BestRecord * n)(*records)
+        out = (BestRecord * (n * self.world))()
+        _check(lib().tm_comm_allgather_records(self.h, loc, n, out))
+        return [BestRecord.from_buffer_copy(bytes(out[k])) for k in range(n * self.world)]
 
 
 def best_select(records):

@@ -5,7 +5,12 @@ scene sample pairs are dealt round-robin to the ranks, every rank generates and 
 hypotheses, and ONE small collective per batch exchanges the 96-byte best records (all-gather over
 torch.distributed: backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests). The argmax
 itself is tm_best_select (C ABI): count desc, score desc, hypothesis id asc — deterministic and
-independent of the number of ranks because ids are global (rank + k * world).
+independent of the number of ranks because a hypothesis' id comes from its provenance, not from where it
+was scored: id = global sample pair index * query_limit + entry within the pair (canonical_hyp_id).
+
+On the GPUs the exchange itself is the C ABI's tm_best_reduce (one ncclAllGather of device-resident
+records on the library's stream, capi.Comm); the torch.distributed functions below carry the same
+records over gloo in the CPU tests and in the one-GPU rehearsal of bench.py.
 """
 import ctypes as C
 
@@ -22,8 +27,19 @@ def shard_pairs(pairs, rank, world):
     return np.ascontiguousarray(pairs[rank::world])
 
 
-def global_hyp_id(local_index, rank, world):
-    return rank + local_index * world
+QUERY_LIMIT = 200  # include/impl/scene.hpp:19
+
+
+def global_pair_index(local_pair, rank, world):
+    """shard_pairs deals global pair p to rank p % world at local position p // world."""
+    return rank + local_pair * world
+
+
+def canonical_hyp_id(local_pair, entry, rank, world, query_limit=QUERY_LIMIT):
+    """Id of the hypothesis built from entry `entry` (visit order inside its sample pair) of this rank's
+    local pair `local_pair`: the same number whatever the number of ranks (the provenance rows written by
+    generate_hypotheses are (local pair, m_i, m_j, entry))."""
+    return global_pair_index(local_pair, rank, world) * query_limit + entry
 
 
 def record_to_bytes(rec):
@@ -118,9 +134,10 @@ def shard_pairs_2d(pairs, rank, world, n_models):
     return np.ascontiguousarray(pairs[shard::wp])
 
 
-def global_hyp_id_2d(local_index, rank, world, n_models):
+def canonical_hyp_id_2d(local_pair, entry, rank, world, n_models, query_limit=QUERY_LIMIT):
+    """canonical_hyp_id inside this rank's model group (pairs are sharded over its Wp pair shards)."""
     _, wp, _, shard = grid_2d(rank, world, n_models)
-    return shard + local_index * wp
+    return (shard + local_pair * wp) * query_limit + entry
 
 
 def allgather_best_many(recs, device=None, group=None):
