@@ -356,6 +356,48 @@ inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p)
     return out;
 }
 
+/* The arbitration of find_parallel, include/impl/scene.hpp:193-237: candidates sorted by their number of
+ * correspondences (descending, stable), then accepted greedily: a candidate keeps only the scene points no
+ * accepted candidate holds yet, and is accepted when at least min_points of those are tangent points and
+ * at least min_points_all in total; a rejected candidate gives its points back (used_copy, :203). */
+inline std::vector<candidate_t> arbitrate(std::vector<candidate_t> cands, uint32_t n_scene_points,
+                                          const std::vector<int32_t>& tangent_mask, uint32_t min_points,
+                                          uint32_t min_points_all, bool verbose = false) {
+    std::stable_sort(cands.begin(), cands.end(), [](const candidate_t& a, const candidate_t& b) {
+        return a.scene_corrs.size() > b.scene_corrs.size(); /* :193-195 */
+    });
+    std::vector<candidate_t> result;
+    std::vector<unsigned char> used(n_scene_points, 0); /* the reference's std::set<uint32_t> used, :198 */
+    std::vector<uint32_t> newly;
+    for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
+        candidate_t out;
+        out.transform = cand.transform;
+        out.signed_score = cand.signed_score;
+        newly.clear(); /* what this candidate adds to `used`; undone if it is rejected (used_copy, :203) */
+        for (size_t k = 0; k < cand.scene_corrs.size(); ++k) {
+            const uint32_t idx = cand.scene_corrs[k];
+            if (!used[idx]) {
+                out.scene_corrs.push_back(idx);
+                out.model_corrs.push_back(cand.model_corrs[k]);
+                used[idx] = 1;
+                newly.push_back(idx);
+            }
+        }
+        uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
+        for (uint32_t idx : out.scene_corrs)
+            if (tangent_mask[idx]) ++score;
+        if (verbose)
+            fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
+                    cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
+        if (score < min_points || score_all < min_points_all) { /* :227 */
+            for (uint32_t idx : newly) used[idx] = 0;
+            continue;
+        }
+        result.push_back(std::move(out));
+    }
+    return result;
+}
+
 /* find_parallel, include/impl/scene.hpp:108-240 */
 template <class Backend, class Exchange>
 inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uint32_t>& tangent_indices,
@@ -442,39 +484,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         for (auto& mt : res.first) cands.push_back(icp(be, mt, p)); /* :169-171 */
     }
     TM_TIMED(arbitration);
-    std::stable_sort(cands.begin(), cands.end(), [](const candidate_t& a, const candidate_t& b) {
-        return a.scene_corrs.size() > b.scene_corrs.size(); /* :193-195 */
-    });
-    std::vector<candidate_t> result;
-    std::vector<unsigned char> used(be.scene_size(), 0); /* the reference's std::set<uint32_t> used, :198 */
-    std::vector<uint32_t> newly;
-    for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
-        candidate_t out;
-        out.transform = cand.transform;
-        out.signed_score = cand.signed_score;
-        newly.clear(); /* what this candidate adds to `used`; undone if it is rejected (used_copy, :203) */
-        for (size_t k = 0; k < cand.scene_corrs.size(); ++k) {
-            const uint32_t idx = cand.scene_corrs[k];
-            if (!used[idx]) {
-                out.scene_corrs.push_back(idx);
-                out.model_corrs.push_back(cand.model_corrs[k]);
-                used[idx] = 1;
-                newly.push_back(idx);
-            }
-        }
-        uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
-        for (uint32_t idx : out.scene_corrs)
-            if (tangent_mask[idx]) ++score;
-        if (p.verbose)
-            fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
-                    cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
-        if (score < min_points || score_all < min_points_all) { /* :227 */
-            for (uint32_t idx : newly) used[idx] = 0;
-            continue;
-        }
-        result.push_back(std::move(out));
-    }
-    return result;
+    return arbitrate(std::move(cands), be.scene_size(), tangent_mask, min_points, min_points_all, p.verbose);
 }
 
 /* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
