@@ -326,6 +326,9 @@ int tm_traits_project_cloud(tm_ctx* ctx, int kind, const float* state, const flo
  * include/impl/plane2_traits.hpp:70-84): one pass over the cloud in HBM, then the identity kernels run
  * on the result with the model's metric (tm_model_set_metric). */
 int tm_scene_create_projected(tm_scene* src, int traits_kind, const float* state, tm_scene** out);
+/* points of the scene that take part in scoring: finite (for a projected scene: project() did not return
+ * nullopt) and not masked */
+uint64_t tm_scene_live_count(const tm_scene* scene);
 /* the surfels of a scene as the kernels see them (uvw surfels for a projected scene) and its tangent_mask */
 int tm_scene_download(const tm_scene* scene, float* surfels, int32_t* tangent_mask);
 

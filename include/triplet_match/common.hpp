@@ -143,6 +143,7 @@ struct alignas(16) PointSurfel {
     vec3f_t getVector3fMap() const { return {x, y, z}; }
     vec3f_t getNormalVector3fMap() const { return {normal_x, normal_y, normal_z}; }
     const float* raw() const { return &x; }
+    float* raw() { return &x; }
 };
 static_assert(sizeof(PointSurfel) == 48, "PointSurfel must be the 48-byte PCL layout");
 

@@ -8,6 +8,7 @@
 #define TRIPLET_MATCH_SCENE_HPP_
 
 #include "model.hpp"
+#include "projected_search.hpp"
 #include "search.hpp"
 
 namespace triplet_match {
@@ -23,6 +24,7 @@ struct hip_backend {
     const pointcloud<Point>* mcloud;
     uint32_t n_t;
     float diam;
+    int traits_kind = TM_TRAITS_IDENTITY; /* the model's metric (tm_model_set_metric) */
     search::params_t p;
     std::vector<uint32_t> sc_scratch, mc_scratch; /* extract output buffers */
 
@@ -136,7 +138,7 @@ struct hip_backend {
                                                  dropped.data(), saved.data()),
                   "tm_score_hypotheses_early_drop");
         } else {
-            check(tm_score_hypotheses(s, m, TM_TRAITS_IDENTITY, &poses[0].m[0], n, subset.data(),
+            check(tm_score_hypotheses(s, m, traits_kind, &poses[0].m[0], n, subset.data(),
                                       (uint32_t)subset.size(), p.dist_thres, TM_SCORE_AUTO, counts.data(),
                                       scores.data()),
                   "tm_score_hypotheses");
@@ -235,26 +237,8 @@ public:
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
                                            float early_out_factor, const sample_parameters& sample_params,
                                            uint32_t max_icp_iterations) {
-        const uint32_t n = (uint32_t)cloud_->size();
-        std::vector<int32_t> tangent_mask(n, 0);
-        for (uint32_t i = 0; i < n; ++i) {
-            bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
-            if (t && !curvature_ok_.empty() && !curvature_ok_[i]) t = false;
-            if (t && curvature_k_) {
-                curvature_info_t ci = cloud_->curvature(curvature_k_, i); /* :49-50 */
-                if (!((ci.pc_min / ci.pc_max) < 0.2f)) t = false;
-            }
-            tangent_mask[i] = t ? 1 : 0;
-        }
-        /* the prepared scene (56 MB upload + sort for 1M points) is reused while cloud size and tangent mask
-         * are unchanged; find_all resets mask_ itself */
-        if (h_ && (cached_n_ != n || cached_tmask_ != tangent_mask)) invalidate();
-        if (!h_) {
-            detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
-                          "tm_scene_create");
-            cached_n_ = n;
-            cached_tmask_ = tangent_mask;
-        }
+        std::vector<int32_t> tangent_mask;
+        ensure_scene(tangent_mask);
         detail::hip_backend<Point> be;
         be.s = h_;
         be.m = m.handle();
@@ -262,18 +246,8 @@ public:
         be.mcloud = m.cloud().get();
         be.n_t = m.point_count();
         be.diam = m.diameter();
-        be.p.dist_thres = dist_thres;
-        be.p.accept_prob = model_match_factor;
-        be.p.early_out_factor = early_out_factor;
-        be.p.min_diameter_factor = sample_params.min_diameter_factor;
-        be.p.max_diameter_factor = sample_params.max_diameter_factor;
-        be.p.force_up = sample_params.force_up;
-        be.p.max_icp_iterations = max_icp_iterations;
-        be.p.workers = workers_;
-        be.p.early_drop = early_drop_;
-        be.p.verbose = verbose_;
         stats_ = search::stats_t();
-        be.p.stats = &stats_;
+        fill_params(be.p, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
         std::vector<search::candidate_t> found;
         if (comm_ && tm_comm_world(comm_) > 1) {
             detail::hip_exchange hx{comm_};
@@ -294,6 +268,147 @@ public:
         return results;
     }
 
+    /* One match of a projected search: `match` lives in uvw space (transform = uvw model -> uvw scene,
+     * scene_corrs = indices into this scene's cloud, model_corrs = indices into the ORIGINAL model cloud);
+     * `projector` is the scene projector it was found under. A model point x appears in the scene at
+     * Traits::unproject(projector, match.transform * Traits::project(model projector, x)). */
+    template <typename Traits>
+    struct projected_match_t {
+        match_t match;
+        typename Traits::const_handle_t projector;
+    };
+
+    /* The traits search (projected_search.hpp): projector candidates from Traits::sample_count scene points,
+     * Traits::init_from_samples, the scene mapped into uvw space on the device, the identity search there,
+     * masking, next projector. max_icp_iterations refines in uvw space with a rigid fit; leave it 0 for the
+     * cylinder (its u coordinate wraps around). */
+    template <typename Traits>
+    std::vector<projected_match_t<Traits>> find_all_parallel(projected_model<Traits, Point>& pm, float dist_thres,
+                                                             float model_match_factor, float early_out_factor,
+                                                             const sample_parameters& sample_params,
+                                                             uint32_t max_icp_iterations,
+                                                             const projector_search& ps = projector_search()) {
+        std::vector<int32_t> base_tmask;
+        ensure_scene(base_tmask);
+        const uint32_t n = (uint32_t)cloud_->size();
+        model<Point>& um = pm.uvw_model();
+        const uint32_t n_model = (uint32_t)um.cloud()->size();
+        std::vector<int32_t> mask(n, 0);
+        detail::check(tm_scene_set_mask(h_, mask.data()), "tm_scene_set_mask");
+        std::vector<uint32_t> free_pts; /* finite points no accepted match holds */
+        for (uint32_t i = 0; i < n; ++i)
+            if (cloud_->points[i].getVector3fMap().allFinite() && cloud_->points[i].getNormalVector3fMap().allFinite())
+                free_pts.push_back(i);
+        std::mt19937 rng((uint32_t)ps.seed);
+        std::vector<int32_t> nb; /* neighbourhood of the first sample */
+        const uint32_t min_tangent = (uint32_t)(model_match_factor * (float)um.point_count()); /* = min_points, :114 */
+        std::vector<projected_match_t<Traits>> results;
+        uint32_t searches = 0, idle = 0;
+        stats_ = search::stats_t();
+        for (uint32_t draw = 0; draw < ps.max_draws && searches < ps.max_searches && idle < ps.max_idle_searches; ++draw) {
+            if (free_pts.size() < (size_t)Traits::sample_count) break;
+            /* the first sample anywhere among the unexplained points, the others in its neighbourhood
+             * (radius = the model's diameter, the radius_search_inclusive of the search itself, :273): three
+             * independent points of a room almost never share a wall, three neighbours often do */
+            uint32_t idx[Traits::sample_count];
+            bool ok = true;
+            idx[0] = free_pts[rng() % (uint32_t)free_pts.size()];
+            if (Traits::sample_count > 1) {
+                uint32_t cnt = 0;
+                nb.resize(n);
+                detail::check(tm_scene_radius_subset(h_, idx[0], um.diameter(), nb.data(), n, &cnt), "tm_scene_radius_subset");
+                if (cnt < (uint32_t)Traits::sample_count) continue;
+                for (int k = 1; k < Traits::sample_count; ++k) {
+                    idx[k] = (uint32_t)nb[rng() % cnt];
+                    for (int q = 0; q < k; ++q) ok = ok && idx[q] != idx[k];
+                    ok = ok && !mask[idx[k]] && cloud_->points[idx[k]].getNormalVector3fMap().allFinite();
+                }
+            }
+            if (!ok) continue;
+            float flat[12 * Traits::sample_count], ms[TM_STATE_FLOATS] = {0}, st[TM_STATE_FLOATS] = {0};
+            for (int k = 0; k < Traits::sample_count; ++k) memcpy(flat + 12 * k, cloud_->points[idx[k]].raw(), 48);
+            pm.handle()->pack(ms);
+            if (tm_traits_init_from_samples(Traits::kind, ms, flat, st)) continue; /* nullptr in the reference */
+            auto handle = std::make_shared<typename Traits::state_t>();
+            handle->unpack(st);
+            if (Traits::kind == TM_TRAITS_CYLINDER &&
+                !(std::fabs(handle->radius - pm.handle()->radius) <= ps.radius_tolerance * pm.handle()->radius))
+                continue;
+            tm_scene* proj = nullptr;
+            detail::check(tm_scene_set_mask(h_, mask.data()), "tm_scene_set_mask");
+            detail::check(tm_scene_create_projected(h_, Traits::kind, st, &proj), "tm_scene_create_projected");
+            struct guard {
+                tm_scene* s;
+                ~guard() { tm_scene_destroy(s); }
+            } g{proj};
+            if ((float)tm_scene_live_count(proj) < model_match_factor * (float)n_model) continue;
+            /* the uvw scene as the kernels see it */
+            auto uvw = cloud_t::empty();
+            uvw->points.resize(n);
+            std::vector<int32_t> tmask(n);
+            detail::check(tm_scene_download(proj, uvw->points[0].raw(), tmask.data()), "tm_scene_download");
+            if (ps.on_surface_samples && pm.handle()->threshold > 0.f) {
+                const float band = Traits::kind == TM_TRAITS_CYLINDER && pm.handle()->radius > 0.f
+                                       ? pm.handle()->threshold / pm.handle()->radius /* w = height / radius */
+                                       : pm.handle()->threshold;
+                for (uint32_t i = 0; i < n; ++i)
+                    if (tmask[i] && !(std::fabs(uvw->points[i].z) <= band)) tmask[i] = 0;
+            }
+            {   /* a surface with fewer tangent points than the arbitration demands as inliers cannot hold a match */
+                uint32_t n_tan = 0;
+                for (uint32_t i = 0; i < n; ++i) n_tan += (tmask[i] && !mask[i]) ? 1u : 0u;
+                if (n_tan < min_tangent) continue;
+            }
+            ++searches;
+            detail::hip_backend<Point> be;
+            be.s = proj;
+            be.m = um.handle();
+            be.scloud = uvw.get();
+            be.mcloud = um.cloud().get();
+            be.n_t = um.point_count();
+            be.diam = um.diameter();
+            be.traits_kind = Traits::kind;
+            fill_params(be.p, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
+            be.p.min_tangent_inliers = min_tangent;
+            std::vector<search::candidate_t> found;
+            if (comm_ && tm_comm_world(comm_) > 1) {
+                detail::hip_exchange hx{comm_};
+                found = search::find_all(be, tmask, be.p, hx, &mask);
+            } else {
+                search::single_rank one;
+                found = search::find_all(be, tmask, be.p, one, &mask);
+            }
+            if (ps.verbose)
+                fprintf(stderr, "[projected search] draw %u: projector searched (%llu points project), %zu match(es)\n", draw,
+                        (unsigned long long)tm_scene_live_count(proj), found.size());
+            if (found.empty()) {
+                ++idle;
+                continue;
+            }
+            idle = 0;
+            for (auto& c : found) {
+                projected_match_t<Traits> r;
+                memcpy(r.match.transform.m, c.transform.m, 64);
+                r.match.transform = r.match.transform.inverse(); /* uvw model -> uvw scene, as :92 */
+                r.match.signed_score = c.signed_score;
+                for (uint32_t i : c.scene_corrs) mask[i] = 1;
+                r.match.scene_corrs = std::move(c.scene_corrs);
+                r.match.model_corrs.reserve(c.model_corrs.size());
+                for (uint32_t k : c.model_corrs) r.match.model_corrs.push_back(pm.original_index(k));
+                r.projector = handle;
+                results.push_back(std::move(r));
+            }
+            size_t w = 0;
+            for (uint32_t i : free_pts)
+                if (!mask[i]) free_pts[w++] = i;
+            free_pts.resize(w);
+        }
+        last_projector_searches_ = searches;
+        return results;
+    }
+    /* projectors that got a full search in the last projected find_all_parallel */
+    uint32_t last_projector_searches() const { return last_projector_searches_; }
+
     /* include/impl/scene.hpp:512-531 (instantiate_all == false returns an empty cloud there too) */
     typename cloud_t::Ptr instantiate(model<Point>& m, const match_t& match, bool instantiate_all = false) {
         typename cloud_t::Ptr inst = cloud_t::empty();
@@ -313,9 +428,48 @@ public:
     tm_scene* handle() const { return h_; }
 
 protected:
+    /* tangent_mask_ (include/impl/scene.hpp:46-54) and the device copy of the scene: the prepared scene (56 MB
+     * upload + sort for 1M points) is reused while cloud size and tangent mask are unchanged; the searches
+     * reset mask_ themselves */
+    void ensure_scene(std::vector<int32_t>& tangent_mask) {
+        const uint32_t n = (uint32_t)cloud_->size();
+        tangent_mask.assign(n, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
+            if (t && !curvature_ok_.empty() && !curvature_ok_[i]) t = false;
+            if (t && curvature_k_) {
+                curvature_info_t ci = cloud_->curvature(curvature_k_, i); /* :49-50 */
+                if (!((ci.pc_min / ci.pc_max) < 0.2f)) t = false;
+            }
+            tangent_mask[i] = t ? 1 : 0;
+        }
+        if (h_ && (cached_n_ != n || cached_tmask_ != tangent_mask)) invalidate();
+        if (!h_) {
+            detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
+                          "tm_scene_create");
+            cached_n_ = n;
+            cached_tmask_ = tangent_mask;
+        }
+    }
+    void fill_params(search::params_t& p, float dist_thres, float model_match_factor, float early_out_factor,
+                     const sample_parameters& sample_params, uint32_t max_icp_iterations) {
+        p.dist_thres = dist_thres;
+        p.accept_prob = model_match_factor;
+        p.early_out_factor = early_out_factor;
+        p.min_diameter_factor = sample_params.min_diameter_factor;
+        p.max_diameter_factor = sample_params.max_diameter_factor;
+        p.force_up = sample_params.force_up;
+        p.max_icp_iterations = max_icp_iterations;
+        p.workers = workers_;
+        p.early_drop = early_drop_;
+        p.verbose = verbose_;
+        p.stats = &stats_;
+    }
+
     typename cloud_t::Ptr cloud_;
     std::shared_ptr<detail::context_holder> ctx_;
     tm_scene* h_ = nullptr;
+    uint32_t last_projector_searches_ = 0;
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
     uint32_t curvature_k_ = 30;

@@ -85,6 +85,14 @@ struct params_t {
     uint32_t workers = 7;
     uint64_t seed = 13;
     bool early_drop = true; /* detail::early_drop, :25 */
+    /* Projected searches only (0 = the reference's rule): a hypothesis becomes THE candidate of its chunk
+     * (:330-338) only if, besides #corrs > accept_prob * |model cloud|, at least this many of the scene's
+     * tangent points are correspondences. On a projector's surface (a pipe, a wall) plain points match plain
+     * points under any in-surface pose, so the count alone is reached by almost every hypothesis and the
+     * first of them would be taken; the arbitration would then reject it for lack of tangent inliers
+     * (min_points, :114,227) and the round would end empty. The driver sets this to that same min_points;
+     * among the hypotheses of one scoring call that qualify, the one with most tangent inliers is taken. */
+    uint32_t min_tangent_inliers = 0;
     bool verbose = false;   /* progress lines on stderr (the reference prints pdebug lines) */
     stats_t* stats = nullptr;
 };
@@ -237,6 +245,32 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
      * early-drop rule applied per hypothesis on that neighbourhood's scan order when p.early_drop);
      * scanning the results in visit order gives the same first sufficient hypothesis as the
      * one-first-point-at-a-time loop below. */
+    /* first hypothesis in visit order that is sufficient (:330-338); projected searches: the sufficient one
+     * with most tangent inliers, at least min_tangent_inliers */
+    std::vector<int32_t> tangent_subset;
+    if (p.min_tangent_inliers)
+        for (uint32_t i = 0; i < (uint32_t)tangent_mask.size(); ++i)
+            if (tangent_mask[i] && !mask[i]) tangent_subset.push_back((int32_t)i);
+    auto first_sufficient = [&](const std::vector<pose_t>& ps, const std::vector<uint32_t>& cs,
+                                const std::vector<double>& ss) -> long {
+        std::vector<uint32_t> cand;
+        for (size_t h = 0; h < ps.size(); ++h)
+            if (ss[h] > 0.0 && (float)cs[h] > sufficient) {
+                if (!p.min_tangent_inliers) return (long)h;
+                cand.push_back((uint32_t)h);
+            }
+        if (cand.empty() || tangent_subset.empty()) return -1;
+        std::vector<pose_t> cp(cand.size());
+        for (size_t k = 0; k < cand.size(); ++k) cp[k] = ps[cand[k]];
+        std::vector<uint32_t> tc;
+        std::vector<double> ts;
+        be.score(cp, tangent_subset, false, tc, ts); /* correspondences among the tangent points alone */
+        long best = -1; /* the sufficient hypothesis with most tangent inliers (first of equals) */
+        uint32_t best_tc = 0;
+        for (size_t k = 0; k < cand.size(); ++k)
+            if (tc[k] >= p.min_tangent_inliers && (best < 0 || tc[k] > best_tc)) best = (long)cand[k], best_tc = tc[k];
+        return best;
+    };
     const bool batched = be.supports_batched();
     std::vector<uint32_t> batch_ij, pair_of_hyp, centers;
     auto flush_batch = [&]() {
@@ -250,11 +284,8 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             centers.resize(poses.size());
             for (size_t h = 0; h < poses.size(); ++h) centers[h] = batch_ij[2 * (size_t)pair_of_hyp[h]];
             be.score_ball(poses, centers, be.model_diameter(), p.early_drop, counts, scores);
-            for (size_t h = 0; h < poses.size(); ++h)
-                if (scores[h] > 0.0 && (float)counts[h] > sufficient) {
-                    best_ts.push_back(poses[h]);
-                    break;
-                }
+            const long h = first_sufficient(poses, counts, scores);
+            if (h >= 0) best_ts.push_back(poses[(size_t)h]);
         }
         batch_ij.clear();
     };
@@ -312,13 +343,9 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         be.generate(ij, poses); /* :304-319, visit order */
         if (poses.empty()) continue;
         be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
-        for (size_t h = 0; h < poses.size(); ++h) {
-            /* :330-338: score > best_score(=0) and #corrs > accept_prob * |model cloud| */
-            if (scores[h] > 0.0 && (float)counts[h] > sufficient) {
-                best_ts.push_back(poses[h]);
-                break;
-            }
-        }
+        /* :330-338: score > best_score(=0) and #corrs > accept_prob * |model cloud| */
+        const long h = first_sufficient(poses, counts, scores);
+        if (h >= 0) best_ts.push_back(poses[(size_t)h]);
     }
     if (batched) flush_batch();
     std::vector<candidate_t> matches;
@@ -491,9 +518,13 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
  * inverts them (:92). */
 template <class Backend, class Exchange>
 inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>& tangent_mask,
-                                         const params_t& p, Exchange& ex) {
+                                         const params_t& p, Exchange& ex,
+                                         const std::vector<int32_t>* initial_mask = nullptr) {
     const uint32_t n = be.scene_size();
+    /* mask_ starts empty in the reference (:41-44); the projected searches of one scene pass the points
+     * earlier projectors have already explained */
     std::vector<int32_t> mask(n, 0), fp_mask(n, 0);
+    if (initial_mask) mask = *initial_mask;
     std::vector<uint32_t> tangent_indices;
     for (uint32_t i = 0; i < n; ++i)
         if (tangent_mask[i]) tangent_indices.push_back(i);

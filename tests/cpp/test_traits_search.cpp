@@ -1,0 +1,121 @@
+/*
+ * test_traits_search.cpp — scene<Point>::find_all_parallel<Traits> end to end (GPU): the projectors come from
+ * scene points the driver draws itself (no hand-picked samples), the model's projector from
+ * fit_model_projector. usage: test_traits_search <fixture> <cylinder|plane2> <threshold>
+ * fixture = u32 n_model, surfels; u32 n_scene, surfels; i32 instance_id[n_scene]; u32 n_instances
+ * Passes when every reported match lies on a planted instance and at least `need` instances are found.
+ */
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <string>
+
+#include "triplet_match/cylinder_traits.hpp"
+#include "triplet_match/plane2_traits.hpp"
+#include "triplet_match/scene.hpp"
+
+using namespace triplet_match;
+typedef PointSurfel P;
+
+static pointcloud<P>::Ptr read_cloud(std::ifstream& in) {
+    uint32_t n = 0;
+    in.read((char*)&n, 4);
+    auto c = pointcloud<P>::empty();
+    c->points.resize(n);
+    in.read((char*)c->points.data(), (std::streamsize)n * 48);
+    return c;
+}
+
+template <typename Traits>
+static int run(pointcloud<P>::Ptr mcloud, pointcloud<P>::Ptr scloud, const std::vector<int32_t>& inst, uint32_t n_inst,
+               float threshold, uint32_t icp, uint32_t need) {
+    int failures = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    auto mh = fit_model_projector<Traits, P>(*mcloud, threshold);
+    if (!mh) {
+        printf("FAIL no model projector\n");
+        return 1;
+    }
+    discretization_params dp;
+    dp.distance_step_count = 20.f;
+    dp.angle_step = 10.f * (float)M_PI / 180.f;
+    projected_model<Traits, P> pm(mcloud, mh, dp);
+    sample_parameters sp;
+    pm.init(sp);
+    auto t1 = std::chrono::steady_clock::now();
+    printf("model: %zu points, %.1f %% project, tangent subset %u, radius %.4f threshold %.4f (%.2f s)\n", mcloud->size(),
+           100.f * pm.valid_fraction(), pm.uvw_model().point_count(), mh->radius, mh->threshold,
+           std::chrono::duration<double>(t1 - t0).count());
+    scene<P> s(scloud);
+    s.disable_curvature_filter(); /* the base scene's own tangent mask plays no role in a projected search */
+    s.set_early_drop(false);
+    s.set_verbose(getenv("TM_SEARCH_VERBOSE") != nullptr);
+    projector_search ps;
+    ps.max_idle_searches = 16;
+    ps.max_searches = 64;
+    ps.verbose = getenv("TM_SEARCH_VERBOSE") != nullptr;
+    auto matches = s.template find_all_parallel<Traits>(pm, 3.0f, 0.5f, 0.9f, sp, icp, ps);
+    auto t2 = std::chrono::steady_clock::now();
+    printf("find_all_parallel<traits>: %zu matches from %u searched projectors in %.2f s\n", matches.size(),
+           s.last_projector_searches(), std::chrono::duration<double>(t2 - t1).count());
+    std::vector<uint32_t> inst_size(n_inst, 0);
+    for (int32_t v : inst)
+        if (v >= 0) ++inst_size[v];
+    std::map<int, int> found;
+    uint32_t decoys = 0;
+    for (const auto& m : matches) {
+        std::map<int, uint32_t> hist;
+        for (uint32_t i : m.match.scene_corrs) ++hist[inst[i]];
+        int best = -1;
+        uint32_t cnt = 0;
+        for (auto& kv : hist)
+            if (kv.first >= 0 && kv.second > cnt) best = kv.first, cnt = kv.second;
+        const double on_target = m.match.scene_corrs.empty() ? 0.0 : (double)cnt / (double)m.match.scene_corrs.size();
+        const double covered = best >= 0 ? (double)cnt / (double)inst_size[best] : 0.0;
+        printf("   match: %zu correspondences, %.1f %% on planted instance %d (%.1f %% of it), score %.4f\n",
+               m.match.scene_corrs.size(), 100.0 * on_target, best, 100.0 * covered, m.match.signed_score);
+        if (best >= 0 && on_target > 0.8 && covered > 0.5) {
+            ++found[best];
+        } else if (best < 0 || on_target < 0.2) {
+            /* a decoy (door frame, second seam) that meets the reference's acceptance thresholds (:227) */
+            printf("   note: a match outside the planted instances\n");
+            ++decoys;
+        } else {
+            printf("FAIL a misaligned match on a planted instance\n");
+            ++failures;
+        }
+    }
+    if (decoys > n_inst) {
+        printf("FAIL more decoy matches than planted instances\n");
+        ++failures;
+    }
+    if (found.size() < need) {
+        printf("FAIL only %zu of %u planted instances found (need %u)\n", found.size(), n_inst, need);
+        ++failures;
+    }
+    for (auto& kv : found)
+        if (kv.second > 1) {
+            printf("FAIL instance %d reported %d times\n", kv.first, kv.second);
+            ++failures;
+        }
+    printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
+    return failures ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::ifstream in(argv[1], std::ios::binary);
+    auto mcloud = read_cloud(in);
+    auto scloud = read_cloud(in);
+    std::vector<int32_t> inst(scloud->size());
+    in.read((char*)inst.data(), (std::streamsize)inst.size() * 4);
+    uint32_t n_inst = 0;
+    in.read((char*)&n_inst, 4);
+    if (!in.good()) return 3;
+    const float threshold = (float)atof(argv[3]);
+    const uint32_t need = argc > 4 ? (uint32_t)atoi(argv[4]) : n_inst;
+    if (std::string(argv[2]) == "cylinder") return run<cylinder_traits<P>>(mcloud, scloud, inst, n_inst, threshold, 0, need);
+    if (std::string(argv[2]) == "plane2") return run<plane2_traits<P>>(mcloud, scloud, inst, n_inst, threshold, 0, need);
+    return 2;
+}

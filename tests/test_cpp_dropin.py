@@ -140,3 +140,45 @@ def test_batched_search_equals_one_at_a_time(tmp_path):
     r = subprocess.run([exe, fx, "both_noearlydrop"], capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
+
+
+def _traits_fixture(path, model, scene):
+    with open(path, "wb") as f:
+        f.write(np.uint32(model.shape[0]).tobytes())
+        f.write(np.ascontiguousarray(model, np.float32).tobytes())
+        f.write(np.uint32(scene["surfels"].shape[0]).tobytes())
+        f.write(np.ascontiguousarray(scene["surfels"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(scene["instance_id"], np.int32).tobytes())
+        f.write(np.uint32(len(scene["instances"])).tobytes())
+    return path
+
+
+def test_traits_search_driver_compiles():
+    _compile("test_traits_search")
+
+
+@pytest.mark.gpu
+def test_traits_search_cylinder_pipe_plant_500k(tmp_path):
+    """BASELINE configs[2] through the product's traits search driver (scene<Point>::find_all_parallel<
+    cylinder_traits>): 500k-pt pipe plant, three planted sections on the pipes of the model's radius; the
+    projectors come from scene points the driver draws itself."""
+    exe = _compile("test_traits_search")
+    model, _ = synth.synth_pipe_section(50_000, seed=3)
+    sc = synth.synth_pipe_plant(500_000, 50_000, seed=4)
+    fx = _traits_fixture(str(tmp_path / "pipes.bin"), model, sc)
+    r = subprocess.run([exe, fx, "cylinder", "0.05"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASSED" in r.stdout
+
+
+@pytest.mark.gpu
+def test_traits_search_plane2_indoor_1m(tmp_path):
+    """BASELINE configs[3] through scene<Point>::find_all_parallel<plane2_traits>: 1M-pt indoor scan, one
+    planted panel on each of three walls."""
+    exe = _compile("test_traits_search")
+    model, _ = synth.synth_wall_panel(15_000, seed=5)
+    sc = synth.synth_indoor(1_000_000, 15_000, seed=6)
+    fx = _traits_fixture(str(tmp_path / "indoor.bin"), model, sc)
+    r = subprocess.run([exe, fx, "plane2", "0.05"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASSED" in r.stdout

@@ -105,6 +105,7 @@ SIGNATURES = {
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
     "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(BestRecord)]),
+    "tm_scene_live_count": (C.c_uint64, [vp]),
     "tm_best_select": (C.c_int, [C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
     "tm_comm_get_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "tm_comm_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(vp)]),

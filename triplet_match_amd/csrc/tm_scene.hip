@@ -1430,6 +1430,7 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
 }
 
 uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
+uint64_t tm_scene_live_count(const tm_scene* s) { return s ? s->n_live : 0; }
 
 int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) {
     TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
@@ -1588,8 +1589,9 @@ int tm_score_hypotheses_ball_dev(tm_scene* s, tm_model* m, const float* d_poses1
     TM_REQUIRE(d_poses16 && d_centers && d_counts && d_scores, TM_ERR_INVALID,
                "tm_score_hypotheses_ball_dev: null argument");
     TM_FORWARD(check_pair(s, m));
-    TM_REQUIRE(m->metric_kind <= TM_TRAITS_PLANE && m->voxels_ready, TM_ERR_UNSUPPORTED,
-               "ball-restricted scoring needs a built model with a 3-D L2 metric");
+    /* any metric: the ball is the reference's radius_search_inclusive on the cloud the scene holds (uvw
+     * points for a projected scene); the non-Euclidean metrics take the sphere-culled instantiation */
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
     TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
     return score_device(s, m, m->metric_kind, d_poses16, n_hyp, nullptr, count_active(s), dist_thres,
                         TM_SCORE_CULLED, d_counts, d_scores, d_centers, radius);
