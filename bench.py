@@ -249,10 +249,18 @@ def main():
                                                "tcp_cache_accesses", "l1_frac_of_peak_at_profiled_ms")
                            if k in pmc}
 
+    # sub-figures measured after the headline region (rank 0, N = 1): the reference's default inner loop
+    # (project_ on the neighbourhood of the first sample point, with the early-drop rule) on the same batch,
+    # and the whole drop-in search scene<Point>::find_all_parallel on the same clouds
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_hyp, DIST_THRES,
+                            ACCEPT_PROB)
+
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp,
-                                        DIST_THRES, ACCEPT_PROB)
+                                        DIST_THRES, ACCEPT_PROB, pairs=pairs, d_prov=d_prov)
 
     if rank == 0 and cpu_baseline is not None and not cpu_baseline["gpu_counts_equal_oracle_on_sample"]:
         log("FATAL: the GPU's inlier counts differ from the oracle's on the sampled hypotheses; no value is reported")
@@ -272,6 +280,7 @@ def main():
             "best": {"inlier_count": int(best.inlier_count), "hyp_id": int(best.hyp_id)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "extras": extras,
         }
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
@@ -338,8 +347,71 @@ def measured_traffic(args):
     return None
 
 
+def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_hyp, dist_thres, accept_prob):
+    """(1) early_drop_ball: the batch scored the way find_in_subset scores (include/impl/scene.hpp:273,326,
+    492-506): every hypothesis on nn = radius_search_inclusive(model diameter, its first sample point) with
+    the early-drop rule, through tm_score_hypotheses_early_drop_ball (host poses in, host results out: the
+    PCIe copies are inside this figure). (2) e2e: tools/e2e_demo.cpp = model<Point>::init +
+    scene<Point>::find_all_parallel (early-drop on, 10 ICP iterations, reference-default masks) on the same
+    clouds, compiled here with g++ against libtm_hip.so."""
+    import subprocess
+    out = {}
+    try:
+        poses = np.zeros((n_hyp, 16), np.float32)
+        prov = np.zeros((n_hyp, 4), np.uint32)
+        ctx.d2h(poses, d_poses)
+        ctx.d2h(prov, d_prov)
+        centers = np.ascontiguousarray(pairs[prov[:, 0], 0], dtype=np.uint32)
+        gs.score_hypotheses_early_drop_ball(gm, poses[:4096], centers[:4096], gm.diameter, dist_thres, accept_prob)
+        t0 = time.perf_counter()
+        cnt, _, dropped, saved = gs.score_hypotheses_early_drop_ball(gm, poses, centers, gm.diameter, dist_thres,
+                                                                    accept_prob)
+        dt = time.perf_counter() - t0
+        out["early_drop_ball"] = {"value": round(n_hyp / dt, 1), "unit": "hypotheses/s", "ms": round(dt * 1e3, 3),
+                                  "hypotheses": int(n_hyp), "dropped_fraction": round(float((dropped >= 0).mean()), 4),
+                                  "max_inliers": int(cnt.max()),
+                                  "note": "project_ on nn(first point, model diameter) with early drop; PCIe-inclusive"}
+    except Exception as exc:  # sub-figures never fail the bench
+        log("extras: early_drop_ball not measured: %s" % exc)
+    try:
+        fx = "/tmp/tm_bench_c2_%d.bin" % os.getpid()
+        with open(fx, "wb") as f:
+            f.write(np.uint32(model.shape[0]).tobytes())
+            f.write(model.tobytes())
+            f.write(np.uint32(scene["surfels"].shape[0]).tobytes())
+            f.write(scene["surfels"].tobytes())
+            f.write(np.float32(res).tobytes())
+            f.write(np.uint32(len(scene["poses_scene_to_model"])).tobytes())
+            for T in scene["poses_scene_to_model"]:
+                from triplet_match_amd import synth
+                f.write(synth.pose_colmajor(T).tobytes())
+        exe = "/tmp/tm_e2e_demo_%d" % os.getpid()
+        libdir = os.path.join(ROOT, "triplet_match_amd")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "e2e_demo.cpp"), "-o", exe, "-L" + libdir, "-ltm_hip",
+                               "-Wl,-rpath," + libdir])
+        r = subprocess.run([exe, fx, "1", "10"], capture_output=True, text=True, timeout=300)
+        os.unlink(fx)
+        os.unlink(exe)
+        import re
+        m1 = re.search(r"model init ([0-9.]+) s; find_all_parallel\(early_drop=1, icp=10\) ([0-9.]+) s -> (\d+) matches", r.stdout)
+        m2 = re.search(r"second call ([0-9.]+) s -> (\d+) matches", r.stdout)
+        if m1:
+            out["e2e_find_all_parallel"] = {
+                "model_init_s": float(m1.group(1)), "find_all_parallel_s": float(m1.group(2)),
+                "matches": int(m1.group(3)), "planted": int(len(scene["poses_scene_to_model"])),
+                "second_call_s": float(m2.group(1)) if m2 else None,
+                "note": "drop-in scene<Point>::find_all_parallel, early drop on, 10 ICP iterations, curvature masks on; "
+                        "second call = the same search again with the prepared scene kept on the device"}
+        else:
+            log("extras: e2e demo output not understood:\n" + r.stdout[-800:] + r.stderr[-800:])
+    except Exception as exc:
+        log("extras: e2e not measured: %s" % exc)
+    return out or None
+
+
 def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp, dist_thres,
-                     accept_prob):
+                     accept_prob, pairs=None, d_prov=None):
     """Times the oracle's project_ (the CPU restatement of the reference path, kind "port") on a
     bounded sample of the same hypothesis batch, threads = hardware_concurrency() - 1 as the
     reference does (include/impl/scene.hpp:146). The voxel table is imported from the GPU build
@@ -371,7 +443,27 @@ def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts
     parity = bool(np.array_equal(counts[sel], c_full))
     if not parity:
         log("ERROR: GPU inlier counts differ from the oracle on the CPU-baseline sample")
+    # like for like with what the GPU's culling leaves: the reference's own inner loop scores on
+    # nn = radius_search_inclusive(model diameter, first sample point), with the early-drop rule
+    ref_shaped = None
+    if pairs is not None and d_prov is not None:
+        prov = np.zeros((n_hyp, 4), np.uint32)
+        ctx.d2h(prov, d_prov)
+        centers = pairs[prov[:, 0], 0]
+        uniq = np.unique(centers)[:8]
+        n_ref, t_ref = 0, 0.0
+        for c in uniq:
+            hyps = np.nonzero(centers == c)[0][:threads * 4]
+            nn = os_.radius_subset(int(c), om.diameter)
+            t0 = time.perf_counter()
+            os_.score_hypotheses(om, poses[hyps], accept_prob, dist_thres, subset=nn, early_drop=True, threads=threads)
+            t_ref += time.perf_counter() - t0
+            n_ref += len(hyps)
+        if t_ref > 0:
+            ref_shaped = {"value": round(n_ref / t_ref, 2), "unit": "hypotheses/s", "hypotheses": int(n_ref),
+                          "note": "project_ on nn(first point, model diameter) with early drop, %d first points" % len(uniq)}
     return {"value": round(k / t_full, 2), "unit": "hypotheses/s", "cores": threads, "kind": "port",
+            "reference_shaped_ball_early_drop": ref_shaped,
             "sample": "%d of the %d hypotheses of one batch, full pass over the %d-pt scene (early drop off), %.1fs"
                       % (k, n_hyp, scene["surfels"].shape[0], t_full),
             "gpoints_per_s": round(ev_full / t_full / 1e9, 4),

@@ -123,6 +123,12 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,
                     float distance_step_count, float angle_step, tm_model** model);
 int tm_model_destroy(tm_model* model);
+/* init(subset, ...) of the reference takes the bounding box, hence diameter(), the distance window of the
+ * pairs and the voxel grid, over the finite points of the subset it is handed
+ * (include/impl/model.hpp:17-38); an empty subset stands for the whole cloud. Call before
+ * tm_model_build_voxels when the caller's subset is not empty; (NULL, 0) restores the default.
+ * The voxel NN itself always searches the whole cloud (:88). */
+int tm_model_set_grid_subset(tm_model* model, const uint32_t* subset, uint32_t n_subset);
 /* init() part A, include/impl/model.hpp:34-66,81-94: bbox, diameter, to_voxel, voxel NN grid */
 int tm_model_build_voxels(tm_model* model);
 /* init() part B, include/impl/model.hpp:96-149: `subset` is subset_ after the tangent/curvature

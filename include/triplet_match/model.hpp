@@ -75,6 +75,9 @@ public:
             subset_.push_back(idx);
         }
         s_params_ = sample_params;
+        /* bounding box, diameter and grid over the caller's subset (:17-38); empty = the whole cloud */
+        detail::check(tm_model_set_grid_subset(h_, subset.empty() ? nullptr : subset.data(), (uint32_t)subset.size()),
+                      "tm_model_set_grid_subset");
         detail::check(tm_model_build_voxels(h_), "tm_model_build_voxels");
         detail::check(tm_model_build_pairs(h_, subset_.data(), (uint32_t)subset_.size(),
                                            sample_params.min_diameter_factor, sample_params.max_diameter_factor),

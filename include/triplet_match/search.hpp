@@ -11,7 +11,7 @@
  * (SURVEY.md Appendix A, Q10):
  *   - RNG: std::mt19937 seeded with 13 (the reference's `deterministic` branch, :123,245); draws are
  *     `rng() % k` in a partial Fisher-Yates shuffle (range-v3's view::sample / action::shuffle are
- *     unpinned);
+ *     unpinned); the shuffle of a neighbourhood is run lazily, as far as the inner loop consumes it;
  *   - workers: the reference splits the outer sample over hardware_concurrency()-1 threads and each
  *     returns its own first sufficient hypothesis; `workers` is an explicit parameter here (default 7);
  *   - radius_search_inclusive(diameter, p1): membership d2 <= r*r, ascending index order.
@@ -235,7 +235,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     uint32_t cons = 0;
     const uint32_t n_model_all = be.model_size();
     const float sufficient = p.accept_prob * (float)n_model_all; /* :331, size_t > float in float */
-    std::vector<int32_t> nn;
+    std::vector<int32_t> nn, inner0;
     std::vector<uint32_t> ij;
     std::vector<pose_t> poses;
     std::vector<uint32_t> counts;
@@ -308,20 +308,25 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         uint64_t inner_bound = (uint64_t)(-std::log(1.0 - match_probability) / prob); /* :277 */
         inner_bound = std::max(inner_bound, min_sample_count);
         inner_bound = std::min<uint64_t>(inner_bound, nn.size());
-        std::vector<int32_t> inner0(nn.begin(), nn.end());
-        {
-            TM_TIMED(shuffle);
-            detail::partial_shuffle(inner0, inner0.size(), rng); /* :285 */
-        }
         if (!best_ts.empty()) continue; /* the reference keeps looping without effect once a candidate
                                            exists (best_ts.empty() gates :331; early-out is unreachable,
-                                           SURVEY Q8): skip the dead work, keep `cons` and the rng stream */
-        /* the valid samples of this first point, up to inner_bound + 1 (:305, :350) */
+                                           SURVEY Q8): skip the dead work, keep `cons` */
+        /* The shuffled neighbourhood (:285) is consumed from the front until inner_bound + 1 valid samples
+         * are found (:305, :350), so the Fisher-Yates shuffle is run lazily: position k is drawn when the loop
+         * reaches it. Same distribution as shuffling everything first; the number of draws per first point is
+         * what this definition fixes (range-v3's action::shuffle is unpinned). */
         ij.clear();
         uint32_t valid_samples = 0;
         {
         TM_TIMED(sample);
-        for (int32_t j : inner0) {
+        inner0.assign(nn.begin(), nn.end()); /* a copy is shuffled (:284-285): project_ scans nn in its own order */
+        const size_t n_nn = inner0.size();
+        for (size_t k = 0; k < n_nn; ++k) {
+            if (k + 1 < n_nn) {
+                const size_t r = k + (size_t)(rng() % (uint32_t)(n_nn - k));
+                std::swap(inner0[k], inner0[r]);
+            }
+            const int32_t j = inner0[k];
             if (!tangent_mask[j] || mask[j] || i == (uint32_t)j) continue; /* :290 */
             if (!be.pair_is_valid_sample(i, (uint32_t)j)) continue;         /* :293-302 */
             ij.push_back(i);

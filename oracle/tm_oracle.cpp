@@ -384,6 +384,7 @@ struct tmo_model {
     int margin = 5;
     float to_voxel[16];
     std::vector<uint32_t> voxels;
+    std::vector<uint32_t> grid_subset; /* subset handed to init(): bbox / diameter / grid over it; empty = all */
     std::vector<uint32_t> subset;
     float bmin[4], bmax[4];
     uint64_t valid_count = 0;
@@ -405,7 +406,10 @@ int model_setup_grid(tmo_model* m) {
     float mx[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(),
                    std::numeric_limits<float>::lowest()};
     uint32_t kept = 0;
-    for (uint32_t i = 0; i < m->n; ++i) {
+    /* :17-22: an empty subset stands for the whole cloud; :33-37: bbox over the (finite) subset */
+    const uint32_t n_sel = m->grid_subset.empty() ? m->n : (uint32_t)m->grid_subset.size();
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        const uint32_t i = m->grid_subset.empty() ? k : m->grid_subset[k];
         const float* s = c + (size_t)i * 12;
         if (!(finite3(s_pos(s)) && finite3(s_nrm(s)) && finite3(s_tgt(s)))) continue; /* :24-30 */
         ++kept;
@@ -656,6 +660,11 @@ static int build_voxels_impl(tmo_model* m, int threads, bool brute) {
     });
     m->voxels_ready = true;
     return 0;
+}
+int tmo_model_set_grid_subset(tmo_model* m, const uint32_t* subset, uint32_t n) {
+    m->grid_subset.assign(subset, subset + n);
+    m->voxels_ready = false;
+    return model_setup_grid(m);
 }
 int tmo_model_build_voxels(tmo_model* m, int threads) { return build_voxels_impl(m, threads, false); }
 int tmo_model_build_voxels_bruteforce(tmo_model* m, int threads) {

@@ -61,6 +61,8 @@ tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step);
 void     tmo_model_destroy(tmo_model* m);
 /* voxel NN grid; accelerated exact search (bucket grid + ring expansion). returns 0 ok */
+/* include/impl/model.hpp:17-38: bbox / diameter / voxel grid over the finite points of init()'s subset */
+int      tmo_model_set_grid_subset(tmo_model* m, const uint32_t* subset, uint32_t n);
 int      tmo_model_build_voxels(tmo_model* m, int threads);
 /* same result by exhaustive O(V*M) scan — for cross-checking the accelerated build on tiny inputs */
 int      tmo_model_build_voxels_bruteforce(tmo_model* m, int threads);

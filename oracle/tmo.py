@@ -66,6 +66,8 @@ def lib():
         L.tmo_model_create.restype = C.c_void_p
         L.tmo_model_create.argtypes = [f32p, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.tmo_model_destroy.argtypes = [C.c_void_p]
+        L.tmo_model_set_grid_subset.restype = C.c_int
+        L.tmo_model_set_grid_subset.argtypes = [C.c_void_p, u32p, C.c_uint32]
         L.tmo_model_build_voxels.restype = C.c_int
         L.tmo_model_build_voxels.argtypes = [C.c_void_p, C.c_int]
         L.tmo_model_build_voxels_bruteforce.restype = C.c_int
@@ -244,6 +246,12 @@ class Model:
         if getattr(self, "h", None):
             lib().tmo_model_destroy(self.h)
             self.h = None
+
+    def set_grid_subset(self, subset):
+        sb, ps = _u(subset)
+        rc = lib().tmo_model_set_grid_subset(self.h, ps, sb.size)
+        if rc:
+            raise RuntimeError("tmo_model_set_grid_subset rc=%d" % rc)
 
     def build_voxels(self, threads=8, brute=False):
         fn = lib().tmo_model_build_voxels_bruteforce if brute else lib().tmo_model_build_voxels

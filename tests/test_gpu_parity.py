@@ -76,6 +76,29 @@ def test_voxel_grid_bit_exact(gpu_small, oracle_small):
         assert g.voxel_query(p) == o.voxel_query(p)
 
 
+def test_grid_over_the_callers_subset(gpu_ctx, small_case):
+    """init(subset, ...) with a non-empty subset: bounding box, diameter and voxel grid are taken over the
+    finite points of THAT subset (include/impl/model.hpp:17-38), the voxel NN still over the whole cloud."""
+    model, res = small_case["model"], small_case["resolution"]
+    sub = np.nonzero(model[:, 0] < np.median(model[:, 0]))[0].astype(np.uint32)
+    g = capi.Model(gpu_ctx, model, res)
+    o = tmo.Model(model, res)
+    full_diam = g.diameter
+    g.set_grid_subset(sub)
+    o.set_grid_subset(sub)
+    assert g.diameter < full_diam and g.diameter == o.diameter
+    g.build_voxels()
+    o.build_voxels(threads=8)
+    eg, tg = g.grid()
+    eo, to = o.grid()
+    assert np.array_equal(eg, eo) and np.array_equal(bits(tg), bits(to))
+    vg = g.voxels()
+    assert np.array_equal(vg, o.voxels())
+    assert (~np.isin(vg, sub)).any()  # nearest points outside the subset do appear: whole-cloud NN
+    g.set_grid_subset(None)  # back to the default
+    assert g.diameter == full_diam
+
+
 def test_voxel_grid_with_ties_and_degenerate_axis(gpu_ctx):
     """planar cloud (one axis has range 0 -> scale 1, ext 1) with duplicated points (ties)."""
     rng = np.random.default_rng(5)

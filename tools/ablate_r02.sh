@@ -15,5 +15,7 @@ for f in glob.glob(sys.argv[1]+"/*/*_counter_collection.csv"):
 print("   "+"  ".join("%s=%.3g"%(c,sum(v)/len(v)) for (k,c),v in sorted(agg.items())))
 PY
 }
-run g5 TM_X=1
-run g5_noeval TM_ABLATE=10
+run base TM_X=1
+run f64term TM_ABLATE=21
+run base2 TM_X=1
+run f64term2 TM_ABLATE=21

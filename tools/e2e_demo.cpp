@@ -57,6 +57,12 @@ int main(int argc, char** argv) {
                st.radius, st.shuffle, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask,
                st.total, std::chrono::duration<double>(t2 - t1).count() - st.total);
     }
+    {   /* the same search again: the prepared scene stays on the device between calls */
+        auto t3 = std::chrono::steady_clock::now();
+        auto again = s.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
+        auto t4 = std::chrono::steady_clock::now();
+        printf("second call %.3f s -> %zu matches\n", std::chrono::duration<double>(t4 - t3).count(), again.size());
+    }
     for (const auto& mt : matches) {
         double best = 1e30;
         for (const auto& t : truth) {

@@ -12,7 +12,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob(out + "/pass*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "k_score" in k or "k_ed_" in k or "k_gen" in k:
+        if "k_score" in k or "k_ed_" in k or "k_gen" in k or "k_voxel" in k or "k_pairs" in k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 res = {}
 for (k, c), v in sorted(agg.items()):

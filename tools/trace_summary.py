@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-kernel totals, GPU-busy time and span of a rocprofv3 --kernel-trace CSV directory.
+usage: tools/trace_summary.py <dir> [first-kernel-substring]
+With a substring the span starts at the first dispatch whose name contains it (to leave model init out)."""
+import collections
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+start_at = sys.argv[2] if len(sys.argv) > 2 else None
+rows = []
+for f in glob.glob(d + "/*/*_kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+rows.sort()
+if start_at:
+    k0 = next((i for i, r in enumerate(rows) if start_at in r[2]), 0)
+    rows = rows[k0:]
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n in rows:
+    if "rocprim" in n:
+        n = "rocprim::" + n.split("detail::")[-1][:40]
+    agg[n][0] += 1
+    agg[n][1] += e - s
+busy = sum(v[1] for v in agg.values())
+span = rows[-1][1] - rows[0][0] if rows else 0
+print("%-56s %8s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
+    print("%-56s %8d %12.1f %12.1f %7.2f" % (n[:56], c, t / 1e3, t / 1e3 / c, 100.0 * t / max(busy, 1)))
+print("span %.1f ms, busy %.1f ms (%.2f of the span), %d dispatches" % (span / 1e6, busy / 1e6, busy / max(span, 1), len(rows)))

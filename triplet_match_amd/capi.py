@@ -65,6 +65,7 @@ SIGNATURES = {
     "tm_model_create": (C.c_int, [vp, f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(vp)]),
     "tm_model_destroy": (C.c_int, [vp]),
+    "tm_model_set_grid_subset": (C.c_int, [vp, u32p, C.c_uint32]),
     "tm_model_build_voxels": (C.c_int, [vp]),
     "tm_model_build_pairs": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_float]),
     "tm_model_set_metric": (C.c_int, [vp, C.c_int, C.c_float]),
@@ -452,6 +453,14 @@ class Model:
 
     def __del__(self):
         self.close()
+
+    def set_grid_subset(self, subset=None):
+        """bounding box / diameter / grid over these points (include/impl/model.hpp:17-38); None = whole cloud"""
+        if subset is None or len(subset) == 0:
+            _check(lib().tm_model_set_grid_subset(self.h, None, 0))
+        else:
+            sb, ps = _u(subset)
+            _check(lib().tm_model_set_grid_subset(self.h, ps, sb.size))
 
     def build_voxels(self):
         _check(lib().tm_model_build_voxels(self.h))

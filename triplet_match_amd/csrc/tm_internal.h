@@ -134,6 +134,7 @@ struct tm_model {
     tmx::dbuf<unsigned char> brick_code; /* floor(sqrt(min d2) / brick_q), clamped to 255 */
     int bdim[3] = {0, 0, 0}; /* super-bricks (16^3 voxels = 64 bricks) per axis, see brick_of() */
     float brick_q = 0.f;
+    std::vector<uint32_t> grid_subset; /* points the bounding box / diameter / grid are taken over; empty = all */
     /* pair table */
     std::vector<uint32_t> subset;
     float bmin[4], bmax[4];
@@ -185,7 +186,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_u32a, w_u32b, w_u32c;
     tmx::dbuf<uint4> w_stats;
     tmx::dbuf<uint2> w_pairs;
-    tmx::dbuf<unsigned short> w_masks; /* grouped scoring: hypothesis mask per (group, chunk) */
+    tmx::dbuf<uint32_t> w_masks;       /* grouped scoring: hypothesis mask per (group, chunk) */
     tmx::dbuf<uint32_t> w_items;       /* grouped scoring: slots with a non-zero mask, + the count */
     tmx::dbuf<float2> w_aux;           /* grouped scoring: per hypothesis (rnorm, abs_eps) */
     /* early-drop path (tm_earlydrop.hip) */

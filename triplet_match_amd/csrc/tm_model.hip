@@ -621,7 +621,11 @@ static int setup_grid(tm_model* m) {
     const float big = std::numeric_limits<float>::max();
     float mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
     uint32_t kept = 0;
-    for (uint32_t i = 0; i < m->n; ++i) {
+    /* bounding box over the finite points of the subset handed to init() (include/impl/model.hpp:17-38);
+     * an empty subset stands for the whole cloud (:17-19) */
+    const uint32_t n_sel = m->grid_subset.empty() ? m->n : (uint32_t)m->grid_subset.size();
+    for (uint32_t k = 0; k < n_sel; ++k) {
+        const uint32_t i = m->grid_subset.empty() ? k : m->grid_subset[k];
         const float* s = m->h_cloud.data() + (size_t)i * 12;
         if (!(fin3(s) && fin3(s + 4) && fin3(s + 9))) continue;
         ++kept;
@@ -954,6 +958,23 @@ int tm_model_destroy(tm_model* m) {
     m->ht_key.release();
     delete m;
     return TM_OK;
+}
+
+int tm_model_set_grid_subset(tm_model* m, const uint32_t* subset, uint32_t n_subset) {
+    TM_REQUIRE(m, TM_ERR_INVALID, "null model");
+    TM_REQUIRE(subset || n_subset == 0, TM_ERR_INVALID, "tm_model_set_grid_subset: null subset");
+    for (uint32_t k = 0; k < n_subset; ++k)
+        TM_REQUIRE(subset[k] < m->n, TM_ERR_INVALID, "tm_model_set_grid_subset: index out of range");
+    std::vector<uint32_t> keep = m->grid_subset;
+    m->grid_subset.assign(subset, subset + n_subset);
+    m->voxels_ready = false; /* the grid changes: the voxel table has to be rebuilt */
+    m->h_voxels_cache.clear();
+    int rc = setup_grid(m);
+    if (rc != TM_OK) {
+        m->grid_subset = keep;
+        (void)setup_grid(m);
+    }
+    return rc;
 }
 
 int tm_model_build_voxels(tm_model* m) {

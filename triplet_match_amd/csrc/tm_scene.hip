@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
  * Grouped scoring: the hypotheses of one scene sample pair all map the first sample onto a model point,
  * so they reach the same neighbourhood of the scene (the reference's `nn`, include/impl/scene.hpp:273).
  * Instead of letting every hypothesis cull the whole scene and load its points for itself, groups of
- * kGroupHyps consecutive hypotheses share the work:
+ * 16 consecutive hypotheses share the work:
  *   k_group_cull   one thread per (group, 512-point chunk): which of the group's hypotheses can the
  *                  chunk's bounding sphere reach at all -> 16-bit mask per (group, chunk)
  *   rocprim select the (group, chunk) slots with a non-zero mask -> work items
@@ -385,7 +385,9 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
  * Everything skipped is skipped by the same conservative sphere tests as before, the sums are integers,
  * so counts and fixed-point scores are identical to k_score_culled / k_score_brute.
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kGroupHyps = 16;
+typedef uint32_t group_mask_t; /* up to 32 hypotheses per group */
+/* LDS of one wave of k_score_items<G>: chunk xyz + poses (3 float4 each) + (rnorm, abs_eps) + entries + sums */
+constexpr int item_lds(int G) { return 6144 + G * 48 + G * 8 + G * 32 * 2 + G * 8; }
 constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
 constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs; five
                                  waves = 96 VGPRs spill 100 bytes per lane and lose: 18.3 ms against 14.8) */
@@ -394,14 +396,15 @@ struct group_args {
     const float4* chunks;   /* bounding sphere per 512 sorted points */
     uint32_t n_chunks;
     uint32_t n_groups;
-    unsigned short* masks;  /* [group][chunk] */
+    uint32_t group_hyps;    /* hypotheses per group: 16 or 32 */
+    group_mask_t* masks;    /* [group][chunk] */
     const uint32_t* items;  /* slots with a non-zero mask */
     const uint32_t* n_items;
     const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
 };
 
 struct nonzero_mask {
-    __host__ __device__ bool operator()(unsigned short m) const { return m != 0; }
+    __host__ __device__ bool operator()(group_mask_t m) const { return m != 0; }
 };
 
 /* per hypothesis: Frobenius norm of the rotation block and the absolute rounding slack of the sphere tests */
@@ -426,8 +429,8 @@ __global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, 
         ss = ca.supers[chunk >> 3];
     }
     uint32_t m = 0;
-    for (uint32_t g = 0; g < (uint32_t)kGroupHyps; ++g) {
-        const uint32_t h = group * kGroupHyps + g; /* uniform: the pose comes through scalar loads */
+    for (uint32_t g = 0; g < ga.group_hyps; ++g) {
+        const uint32_t h = group * ga.group_hyps + g; /* uniform: the pose comes through scalar loads */
         if (h >= a.n_hyp) break;
         const pose12 T = load_pose(a.poses + (size_t)h * 16);
         const float2 ax = ga.aux[h];
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, 
         if (hit) hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
         m |= hit ? (1u << g) : 0u;
     }
-    if (live) ga.masks[(size_t)group * ga.n_chunks + chunk] = (unsigned short)m;
+    if (live) ga.masks[(size_t)group * ga.n_chunks + chunk] = (group_mask_t)m;
 }
 
 /* sum over the 16 lanes of a DPP row; lane 15 of every row ends up with the row's total */
@@ -458,10 +461,10 @@ __device__ __forceinline__ pose12 lds_pose(const float4* p) {
     return T;
 }
 
-template <bool L2, int NC>
+template <bool L2, int NC, int G>
 __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, cull_args ca, group_args ga) {
     /* 8 KiB of LDS per wave, private to it: no workgroup barrier inside the loop */
-    __shared__ __align__(16) unsigned char s_raw[4][8192];
+    __shared__ __align__(16) unsigned char s_raw[4][item_lds(G)];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n_items = *ga.n_items;
     /* XCD-aware split (speed only): blocks b and b + 8 share an L2; consecutive items belong to the same
@@ -471,16 +474,17 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
     const uint32_t lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3);
     const uint32_t hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1u)) >> 3);
     uint32_t evals = 0, pass = 0, n_in = 0, n_near = 0;
-    float* pts = reinterpret_cast<float*>(s_raw[wave]);                           /* 512 x packed xyz: 6144 B */
-    float4* poses = reinterpret_cast<float4*>(s_raw[wave] + 6144);                /* 16 poses x 3 float4: 768 B */
-    float2* auxl = reinterpret_cast<float2*>(s_raw[wave] + 6912);                 /* 16 x (rnorm, abs_eps): 128 B */
-    unsigned short* ent = reinterpret_cast<unsigned short*>(s_raw[wave] + 7040);  /* <= 512 entries: 1024 B */
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(s_raw[wave] + 8064); /* count << 52 | sum: 128 B */
-    if (lane < (uint32_t)kGroupHyps) acc[lane] = 0ull;
+    float* pts = reinterpret_cast<float*>(s_raw[wave]);                                   /* 512 x packed xyz */
+    float4* poses = reinterpret_cast<float4*>(s_raw[wave] + 6144);                        /* 3 float4 per pose */
+    float2* auxl = reinterpret_cast<float2*>(s_raw[wave] + 6144 + G * 48);       /* (rnorm, abs_eps) */
+    unsigned short* ent = reinterpret_cast<unsigned short*>(s_raw[wave] + 6144 + G * 56); /* entries */
+    unsigned long long* acc =
+        reinterpret_cast<unsigned long long*>(s_raw[wave] + 6144 + G * 56 + G * 64); /* count << 52 | sum */
+    if (lane < (uint32_t)G) acc[lane] = 0ull;
     for (uint32_t it = lo + wave_in_xcd; it < hi; it += waves_per_xcd) {
         const uint32_t slot = ga.items[it];
         const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
-        uint32_t m = ga.masks[slot];
+        uint32_t m = (uint32_t)ga.masks[slot];
         /* stage the chunk (1536 floats = six float4 per lane, contiguous) and the group's poses */
         {
             const float4* src = reinterpret_cast<const float4*>(a.spos3 + (size_t)chunk * (kChunkPts * 3));
@@ -488,12 +492,17 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             __builtin_amdgcn_wave_barrier();
             const float4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + lane], v3 = src[192 + lane],
                          v4 = src[256 + lane], v5 = src[320 + lane];
-            /* lanes 0..47: column c of pose l / 3, its w replaced by the translation component c */
-            const uint32_t pl = min(lane, 47u);
-            const uint32_t hp = min(group * kGroupHyps + pl / 3u, a.n_hyp - 1u), pc = pl % 3u;
-            float4 pv = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + pc];
-            pv.w = a.poses[(size_t)hp * 16 + 12u + pc];
-            const float2 ax = ga.aux[min(group * kGroupHyps + (lane & 15u), a.n_hyp - 1u)];
+            /* float4 f of the pose block = column f % 3 of pose f / 3, its w replaced by the translation
+             * component; G * 3 of them, 64 per round */
+            float4 pv[(G * 3 + 63) / 64];
+#pragma unroll
+            for (int r = 0; r < (G * 3 + 63) / 64; ++r) {
+                const uint32_t f = min(64u * r + lane, (uint32_t)G * 3u - 1u);
+                const uint32_t hp = min(group * G + f / 3u, a.n_hyp - 1u), pc = f % 3u;
+                pv[r] = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + pc];
+                pv[r].w = a.poses[(size_t)hp * 16 + 12u + pc];
+            }
+            const float2 ax = ga.aux[min(group * G + (lane % (uint32_t)G), a.n_hyp - 1u)];
             float4* dst = reinterpret_cast<float4*>(pts);
             dst[lane] = v0;
             dst[64 + lane] = v1;
@@ -501,8 +510,10 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             dst[192 + lane] = v3;
             dst[256 + lane] = v4;
             dst[320 + lane] = v5;
-            if (lane < 48u) poses[lane] = pv;
-            if (lane < 16u) auxl[lane] = ax;
+#pragma unroll
+            for (int r = 0; r < (G * 3 + 63) / 64; ++r)
+                if (64u * r + lane < (uint32_t)G * 3u) poses[64u * r + lane] = pv[r];
+            if (lane < (uint32_t)G) auxl[lane] = ax;
         }
         const float4 qs = ca.subs[(size_t)chunk * 32u + (lane & 31u)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -512,44 +523,47 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
          * k_score_culled; survivors are appended to the entry list */
         uint32_t hm = 0; /* lane q < 32: which hypotheses of the group reach quarter-tile q */
         {
-            /* eight rounds, two hypotheses each (lanes 0-31 / 32-63): the level-3 test of k_score_culled.
-             * All eight probes first, then the eight brick-code loads together, then the decisions */
-            tile_probe_t pr[kGroupHyps / 2];
-            uint32_t code[kGroupHyps / 2];
-#pragma unroll
-            for (int r = 0; r < kGroupHyps / 2; ++r) {
-                const uint32_t g = 2u * r + (lane >> 5);
-                const pose12 T = lds_pose(poses + 3u * g);
-                const float2 ax = auxl[g];
-                const float rnorm = ax.x, abs_eps = ax.y;
-                if (L2) {
-                    pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
-                } else {
-                    pr[r].hit = sphere_hits_box(a, T, rnorm, abs_eps, qs);
-                    pr[r].need = false;
-                    pr[r].brick = 0u;
-                    pr[r].lim = 0.f;
-                }
-                pr[r].hit = pr[r].hit & (((m >> g) & 1u) != 0u);
-                pr[r].need = pr[r].need & pr[r].hit;
-                if (!pr[r].need) pr[r].brick = 0u;
-                __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
-            }
-#pragma unroll
-            for (int r = 0; r < kGroupHyps / 2; ++r) code[r] = L2 ? (uint32_t)a.bcode[pr[r].brick] : 0u;
+            /* rounds of two hypotheses (lanes 0-31 / 32-63): the level-3 test of k_score_culled */
             const uint32_t ql = lane & 31u;
 #pragma unroll
-            for (int r = 0; r < kGroupHyps / 2; ++r) {
-                const unsigned long long qm = __ballot(tile_decide(pr[r], code[r]));
-                hm |= ((uint32_t)(qm >> ql) & 1u) << (2 * r);
-                hm |= ((uint32_t)(qm >> (32u + ql)) & 1u) << (2 * r + 1);
+            for (int r0 = 0; r0 < G / 2; r0 += 8) { /* eight rounds' brick-code loads in flight together */
+                tile_probe_t pr[8];
+                uint32_t code[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t g = 2u * (r0 + r) + (lane >> 5);
+                    const pose12 T = lds_pose(poses + 3u * g);
+                    const float2 ax = auxl[g];
+                    const float rnorm = ax.x, abs_eps = ax.y;
+                    if (L2) {
+                        pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
+                    } else {
+                        pr[r].hit = sphere_hits_box(a, T, rnorm, abs_eps, qs);
+                        pr[r].need = false;
+                        pr[r].brick = 0u;
+                        pr[r].lim = 0.f;
+                    }
+                    pr[r].hit = pr[r].hit & (((m >> g) & 1u) != 0u);
+                    pr[r].need = pr[r].need & pr[r].hit;
+                    if (!pr[r].need) pr[r].brick = 0u;
+                    __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) code[r] = L2 ? (uint32_t)a.bcode[pr[r].brick] : 0u;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned long long qm = __ballot(tile_decide(pr[r], code[r]));
+                    hm |= ((uint32_t)(qm >> ql) & 1u) << (2 * (r0 + r));
+                    hm |= ((uint32_t)(qm >> (32u + ql)) & 1u) << (2 * (r0 + r) + 1);
+                }
             }
         }
-        /* entry list in quarter-major order: the lane groups of one gather instruction then hold the same
-         * scene points under consecutive hypotheses of the group. Consecutive hypotheses of a sample pair
-         * come from neighbouring model pairs (the table is sorted), i.e. nearly the same pose: they land in
-         * the same voxel lines, and this order lets them share those lines inside the instruction and L1
-         * instead of fetching them again microseconds later, when L2 has already turned over */
+        /* Entry list in quarter-major order: the lane groups of consecutive gather instructions then hold the
+         * same scene points under consecutive hypotheses of the group. Consecutive hypotheses of a sample pair
+         * come from neighbouring model pairs (the table is sorted), i.e. nearly the same pose: they land in the
+         * same voxel lines and share them inside the instruction and through L1. L2 turns over every few
+         * microseconds here, so what is not re-used at once is fetched again: hypothesis-major order fetched
+         * 8.7e8 lines per batch, tiles of 4 quarter-tiles x 4 hypotheses 6.4e8, this order 5.2e8. */
         if (lane >= 32u) hm = 0u;
         const uint32_t mine = (uint32_t)__popc(hm);
         uint32_t incl = mine; /* inclusive prefix sum over the lanes */
@@ -670,10 +684,10 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < (uint32_t)kGroupHyps) {
+        if (lane < (uint32_t)G) {
             const unsigned long long v = acc[lane];
             if (v && a.ablate != 11) {
-                const uint32_t h = group * kGroupHyps + lane;
+                const uint32_t h = group * G + lane;
                 atomicAdd(&a.counts[h], (uint32_t)(v >> 52));
                 atomicAdd(&a.scores_fx[h], v & 0xFFFFFFFFFFFFFull);
                 acc[lane] = 0ull;
@@ -1113,11 +1127,16 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         bool grouped = !d_active && !d_centers;
         if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
         if (grouped) {
-            /* groups of kGroupHyps consecutive hypotheses share the scene chunks they reach */
+            /* groups of consecutive hypotheses share the scene chunks they reach */
             group_args ga;
             ga.chunks = s->chunks.p;
             ga.n_chunks = s->n_sorted / kChunkPts;
-            ga.n_groups = (n_hyp + kGroupHyps - 1) / kGroupHyps;
+            /* 16 hypotheses per group. Groups of 32 (TM_GROUP_HYPS=32) let more near-identical poses meet in one
+             * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
+             * as that saves: 13.05 ms against 12.90 ms in the same run. */
+            ga.group_hyps = 16u;
+            if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 ? 32u : 16u;
+            ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
             TM_REQUIRE(ga.n_groups <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
             const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
             TM_REQUIRE(n_slots_g < 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "groups x chunks exceeds 32 bits");
@@ -1145,7 +1164,8 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
             /* persistent waves with a static share of the items each: the grid must be exactly what is
              * resident at once, or the surplus workgroups run their share after everyone else */
-            auto kern = l2 ? k_score_items<true, 4> : k_score_items<false, 4>;
+            auto kern = ga.group_hyps == 16u ? (l2 ? k_score_items<true, 4, 16> : k_score_items<false, 4, 16>)
+                                             : (l2 ? k_score_items<true, 4, 32> : k_score_items<false, 4, 32>);
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
@@ -1159,11 +1179,12 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                 fprintf(stderr, "[tm] grouped: %u persistent workgroups (%d per CU)\n", wgs, per_cu);
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, a, ca, ga);
             if (c->debug_stats && getenv("TM_DEBUG_ITEMS")) {
-                std::vector<unsigned short> hm(n_slots_g);
-                TM_HIP_CHECK(hipMemcpyAsync(hm.data(), s->w_masks.p, n_slots_g * 2, hipMemcpyDeviceToHost, c->stream));
+                std::vector<group_mask_t> hm(n_slots_g);
+                TM_HIP_CHECK(hipMemcpyAsync(hm.data(), s->w_masks.p, n_slots_g * sizeof(group_mask_t), hipMemcpyDeviceToHost,
+                                            c->stream));
                 TM_HIP_CHECK(hipStreamSynchronize(c->stream));
                 unsigned long long items = 0, steps = 0;
-                for (unsigned short v : hm) {
+                for (group_mask_t v : hm) {
                     items += v != 0;
                     steps += (unsigned)__builtin_popcount(v);
                 }
