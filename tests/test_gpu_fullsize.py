@@ -1,8 +1,9 @@
 """Full-size parity (BASELINE.json configs[1]: 100k-pt model, 1M-pt scene, 64k hypotheses/batch)
 through size-independent properties, all through the C ABI:
 
-  * the voxel NN grid (1.7e8 voxels) of the kd-tree kernel equals the exhaustive kernel's, and sampled
-    voxels hold a true nearest neighbour (fp64 check against all 100k points);
+  * the voxel NN grid (1.7e8 voxels) equals the oracle's own table (SHA-256 committed under tests/golden/,
+    built offline on the CPU), the kd-tree kernel equals the exhaustive kernel, and sampled voxels hold a
+    true nearest neighbour (fp64 check against all 100k points);
   * the pair table (1.4e7 entries) equals the oracle's, keys, counts and container order;
   * generated hypotheses for a sample of pairs are bit-identical to the oracle's;
   * culled scoring == exhaustive scoring on the whole 64k batch (counts bit-exact, fixed-point scores equal);
@@ -62,6 +63,17 @@ def test_voxel_grid_full_size(gpu_ctx, full):
     ext, to_voxel = gm.grid()
     assert vox.size == int(ext[0]) * int(ext[1]) * int(ext[2]) > 1e8
     assert vox.max() < N_MODEL
+    # the ORACLE's own table of this model, built offline on the CPU (tests/golden/make_voxel_sha.py: once with
+    # its kd-tree, once exhaustively): the full-size result, ties included, is pinned by an implementation that
+    # shares no code with the GPU kernels
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_voxel_grid.json")))
+    assert gold["extents"] == [int(e) for e in ext] and gold["voxels"] == vox.size
+    sha = hashlib.sha256(np.ascontiguousarray(vox, np.uint32).tobytes()).hexdigest()
+    assert sha == gold["sha256_kd_tree"]
+    if "sha256_exhaustive" in gold:
+        assert sha == gold["sha256_exhaustive"]
     # kd-tree kernel == exhaustive kernel (same tie rule), whole table
     os.environ["TM_VOXEL_BRUTEFORCE"] = "1"
     try:
