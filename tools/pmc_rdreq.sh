@@ -11,7 +11,8 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_TOTAL_ACCESSES_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
-           "TA_BUSY_avr TA_TA_BUSY_sum" "GRBM_GUI_ACTIVE"; do
+           "TA_BUSY_avr TA_TA_BUSY_sum" "GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM"; do
   i=$((i+1))
   echo "pass $i: $set" >> $out/progress.log
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/pass$i.json 2> $out/pass$i.log || echo "pass $i failed rc=$?" >> $out/progress.log
