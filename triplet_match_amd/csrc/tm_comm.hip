@@ -5,8 +5,8 @@
  * deterministic selection (count desc, score desc, hypothesis id asc). The reference has no counterpart
  * (its only reduction is fut.get() + std::sort over threads, include/impl/scene.hpp:168-195).
  *
- * RCCL is bound at run time (dlopen of librccl.so.1): libtm_hip.so carries no link-time dependency on it,
- * and a process that already holds an RCCL (PyTorch does) shares that copy. tm_comm_* return
+ * RCCL is bound at run time (dlopen of librccl.so.1, RTLD_LOCAL): libtm_hip.so carries no link-time
+ * dependency on it, and a process that already holds an RCCL (PyTorch does) shares that copy. tm_comm_* return
  * TM_ERR_UNSUPPORTED with a message when no RCCL can be loaded; nothing falls back to another transport.
  */
 #include "tm_internal.h"
@@ -37,10 +37,17 @@ static rccl_api& rccl() {
     static rccl_api api;
     static std::once_flag once;
     std::call_once(once, [] {
+        /* an RCCL the process already holds (PyTorch's, when torch was imported first) is shared; otherwise
+         * load one privately: RTLD_LOCAL, so that its symbols never interpose on a library loaded later (a
+         * torch imported after an RTLD_GLOBAL RCCL ended in a double free at process exit) */
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
-            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
             if (api.lib) break;
+        }
+        for (const char* n : names) {
+            if (api.lib) break;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         }
         if (!api.lib) return;
         api.GetUniqueId = (int (*)(rccl_unique_id*))dlsym(api.lib, "ncclGetUniqueId");
