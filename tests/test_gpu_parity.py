@@ -845,3 +845,42 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
         lists = gs.radius_lists(centers, r)
         for k, c in enumerate(centers):
             assert np.array_equal(lists[k], os_.radius_subset(int(c), r))
+
+
+def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case, monkeypatch):
+    """The grouped kernel (16 or 32 hypotheses share the scene chunks they reach) against the exhaustive kernel
+    and the oracle at the sizes where its bookkeeping has edges: fewer hypotheses than a group, one more than a
+    group, a last partial group; a scene smaller than one 512-point chunk; a masked scene."""
+    g, s = gpu_small["model"], gpu_small["scene"]
+    poses = random_poses_near_truth(small_case, 100, seed=23)
+    cb, sb = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_BRUTEFORCE)
+    co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, threads=8)
+    assert np.array_equal(cb, co)
+    for group in ("16", "32"):
+        monkeypatch.setenv("TM_GROUP_HYPS", group)
+        for n in (1, 15, 16, 17, 31, 32, 33, 100):
+            cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
+            assert np.array_equal(cg, cb[:n]), (group, n)
+            assert np.array_equal(sg, sb[:n]), (group, n)  # fixed-point sums: identical, not merely close
+    monkeypatch.delenv("TM_GROUP_HYPS")
+    # the per-hypothesis kernel of round 1 (still used for ball / subset scoring) agrees as well
+    monkeypatch.setenv("TM_SCORE_GROUPED", "0")
+    cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
+    monkeypatch.delenv("TM_SCORE_GROUPED")
+    assert np.array_equal(cg, cb) and np.array_equal(sg, sb)
+    # a scene of 300 points: less than one chunk
+    sc = small_case["scene"]
+    inst = np.nonzero(sc["instance_id"] == 0)[0][:300]
+    tiny = capi.Scene(gpu_ctx, sc["surfels"][inst], sc["tangent_mask"][inst])
+    ct, st = tiny.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
+    ctb, stb = tiny.score_hypotheses(g, poses, DT, mode=capi.SCORE_BRUTEFORCE)
+    assert np.array_equal(ct, ctb) and np.array_equal(st, stb) and ct.max() > 100
+    # a mask over half of the scene
+    mask = (np.arange(len(sc["surfels"])) % 2).astype(np.int32)
+    s.set_mask(mask)
+    try:
+        cm, sm = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
+        cmb, smb = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_BRUTEFORCE)
+        assert np.array_equal(cm, cmb) and np.array_equal(sm, smb) and cm.max() < cb.max()
+    finally:
+        s.set_mask(None)

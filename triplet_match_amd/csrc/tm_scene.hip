@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void k_pose_aux(const float* __restrict__ pose
 }
 
 __global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, group_args ga) {
-    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t group = blockIdx.y;
+    const uint32_t chunk = blockIdx.y * 256 + threadIdx.x; /* groups along x: any batch size fits one launch */
+    const uint32_t group = blockIdx.x;
     const bool live = chunk < ga.n_chunks;
     float4 sb = make_float4(0.f, 0.f, 0.f, -1.f), ss = sb;
     if (live) {
@@ -1126,20 +1126,21 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         }
         bool grouped = !d_active && !d_centers;
         if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
+        /* groups of consecutive hypotheses share the scene chunks they reach */
+        group_args ga;
+        ga.chunks = s->chunks.p;
+        ga.n_chunks = s->n_sorted / kChunkPts;
+        /* 16 hypotheses per group. Groups of 32 (TM_GROUP_HYPS=32) let more near-identical poses meet in one
+         * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
+         * as that saves: 13.05 ms against 12.90 ms in the same run. */
+        ga.group_hyps = 16u;
+        if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 ? 32u : 16u;
+        ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
+        const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
+        /* slots are addressed with 32 bits and the chunks ride in blockIdx.y: beyond that (billions of points,
+         * or hundreds of millions of (group, chunk) slots in one call) the per-hypothesis kernel takes the launch */
+        if (n_slots_g >= 0xFFFFFFFFull || (ga.n_chunks + 255) / 256 > 65535u) grouped = false;
         if (grouped) {
-            /* groups of consecutive hypotheses share the scene chunks they reach */
-            group_args ga;
-            ga.chunks = s->chunks.p;
-            ga.n_chunks = s->n_sorted / kChunkPts;
-            /* 16 hypotheses per group. Groups of 32 (TM_GROUP_HYPS=32) let more near-identical poses meet in one
-             * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
-             * as that saves: 13.05 ms against 12.90 ms in the same run. */
-            ga.group_hyps = 16u;
-            if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 ? 32u : 16u;
-            ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
-            TM_REQUIRE(ga.n_groups <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
-            const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
-            TM_REQUIRE(n_slots_g < 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "groups x chunks exceeds 32 bits");
             TM_FORWARD(s->w_masks.ensure(n_slots_g));
             TM_FORWARD(s->w_items.ensure(n_slots_g + 1));
             TM_FORWARD(s->w_aux.ensure(n_hyp));
@@ -1150,7 +1151,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.items = s->w_items.p;
             ga.n_items = s->w_items.p + n_slots_g;
             d_n_items = ga.n_items;
-            hipLaunchKernelGGL(k_group_cull, dim3((ga.n_chunks + 255) / 256, ga.n_groups), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, (ga.n_chunks + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
             size_t tmp = 0;
             rocprim::counting_iterator<uint32_t> slots(0u);
