@@ -1,9 +1,10 @@
 /* e2e_demo.cpp — times the drop-in scene<Point>::find_all_parallel on a fixture written by
  * tests/test_cpp_dropin.py::_fixture (model, scene, resolution, ground-truth poses).
- * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] */
+ * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] [repeats of the search on the kept scene] */
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <unistd.h>
 
 #include "triplet_match/scene.hpp"
 
@@ -57,11 +58,14 @@ int main(int argc, char** argv) {
                st.radius, st.shuffle, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask,
                st.total, std::chrono::duration<double>(t2 - t1).count() - st.total);
     }
-    {   /* the same search again: the prepared scene stays on the device between calls */
+    const int repeats = argc > 4 ? atoi(argv[4]) : 1;
+    for (int r = 0; r < repeats; ++r) { /* the same search again: the prepared scene stays on the device between calls */
+        if (repeats > 1) usleep(300000); /* a gap the kernel trace can be cut at (tools/trace_summary.py --segments) */
         auto t3 = std::chrono::steady_clock::now();
         auto again = s.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
         auto t4 = std::chrono::steady_clock::now();
-        printf("second call %.3f s -> %zu matches\n", std::chrono::duration<double>(t4 - t3).count(), again.size());
+        printf("%s call %.3f s -> %zu matches\n", r == 0 ? "second" : "further", std::chrono::duration<double>(t4 - t3).count(),
+               again.size());
     }
     for (const auto& mt : matches) {
         double best = 1e30;

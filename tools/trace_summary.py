@@ -8,7 +8,7 @@ import glob
 import sys
 
 d = sys.argv[1]
-start_at = sys.argv[2] if len(sys.argv) > 2 else None
+start_at = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else None
 rows = []
 for f in glob.glob(d + "/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
@@ -29,3 +29,16 @@ print("%-56s %8s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:16]:
     print("%-56s %8d %12.1f %12.1f %7.2f" % (n[:56], c, t / 1e3, t / 1e3 / c, 100.0 * t / max(busy, 1)))
 print("span %.1f ms, busy %.1f ms (%.2f of the span), %d dispatches" % (span / 1e6, busy / 1e6, busy / max(span, 1), len(rows)))
+if "--segments" in sys.argv:
+    # cut the trace where no kernel starts for 0.1 s (e2e_demo sleeps between its repeated searches)
+    seg, segs = [rows[0]], []
+    for prev, cur in zip(rows, rows[1:]):
+        if cur[0] - prev[1] > 100_000_000:
+            segs.append(seg)
+            seg = []
+        seg.append(cur)
+    segs.append(seg)
+    for k, sg in enumerate(segs):
+        b = sum(e - s for s, e, _ in sg)
+        sp = sg[-1][1] - sg[0][0]
+        print("segment %d: span %.1f ms, busy %.1f ms (%.2f of the span), %d dispatches" % (k, sp / 1e6, b / 1e6, b / max(sp, 1), len(sg)))
