@@ -389,8 +389,9 @@ typedef uint32_t group_mask_t; /* up to 32 hypotheses per group */
 /* LDS of one wave of k_score_items<G>: chunk xyz + poses (3 float4 each) + (rnorm, abs_eps) + entries + sums */
 constexpr int item_lds(int G) { return 6144 + G * 48 + G * 8 + G * 32 * 2 + G * 8; }
 constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
-constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs; five
-                                 waves = 96 VGPRs spill 100 bytes per lane and lose: 18.3 ms against 14.8) */
+constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs). Five
+                                 waves = 96 VGPRs spill and lose: four chains 100 bytes per lane, 18.3 ms against
+                                 14.8; three chains 72 bytes, 16.8 ms against 12.9 */
 
 struct group_args {
     const float4* chunks;   /* bounding sphere per 512 sorted points */
@@ -646,13 +647,14 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     float4 sr[2], mr[2];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (ok[k0 + j]) {
-                            sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[k0 + j]];
-                            mr[j] = a.mref[mi[k0 + j]];
+                        if (k0 + j < NC && ok[(k0 + j) % NC]) {
+                            sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]];
+                            mr[j] = a.mref[mi[(k0 + j) % NC]];
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        if (k0 + j >= NC) continue;
                         /* 2^40 fixed-point term split as hi * 2^20 + lo, the match flag rides above lo:
                          * two dwords to add up over the 16 lanes of the entry */
                         uint32_t w_lo = 0u, w_hi = 0u;
