@@ -258,7 +258,7 @@ def main():
                             ACCEPT_PROB)
 
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg runs at N = 1 only
         cpu_baseline = run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp,
                                         DIST_THRES, ACCEPT_PROB, pairs=pairs, d_prov=d_prov)
 
