@@ -395,6 +395,43 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
     const unsigned long long* member = ball ? a.ball.member + (size_t)slot * a.ball.mwords : nullptr;
     const uint32_t* wprefix = ball ? a.ball.wprefix + (size_t)slot * a.ball.mwords : nullptr;
+    /* 98 % of the hypotheses of a search are dropped at the first checkpoint (5 % of the scan), so the bits are
+     * produced in two steps. Step 0 takes the first B = first checkpoint + 1024 scan positions straight from
+     * the neighbourhood list (position -> point, the order project_ scans in) — a few thousand points, no
+     * culling of the scene at all — and the walk decides on those; only a hypothesis that is still alive
+     * (or whose check needs a later position) runs step 1, the tile-culled pass over the rest of its
+     * neighbourhood. The bits, hence counts, checkpoint, `saved` and score, are the same as when everything is
+     * evaluated at once. */
+    __shared__ uint32_t s_done;
+    const uint32_t S_words = (S + 63u) / 64u;
+    uint32_t B_words = (tests[0] + 1024u + 63u) / 64u;
+    if (B_words > S_words) B_words = S_words;
+    if (a.sc.ablate == 30) B_words = 0u; /* TM_ABLATE=30: everything in the tile-culled pass (timing comparison) */
+    for (uint32_t step = 0; step < 2; ++step) {
+        const uint32_t pos_lo = step == 0 ? 0u : B_words * 64u;
+        const uint32_t pos_hi = step == 0 ? B_words * 64u : 0xFFFFFFFFu;
+        const uint32_t walk_words = step == 0 ? B_words : a.words;
+        if (step == 0) {
+            if (B_words == 0u) continue;
+            score_args sc0 = a.sc;
+            sc0.sref = oref; /* original order, as pass 3 */
+            const uint32_t n_pos = min(pos_hi, S);
+            for (uint32_t pos = threadIdx.x; pos < n_pos; pos += 256) {
+                const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
+                                          : (a.subset ? (uint32_t)a.subset[pos] : pos);
+                if (a.otan[idx].w != 0.f) continue; /* mask_ (:434) */
+                const float4 P = a.opos[idx];
+                long long fx0 = 0;
+                uint32_t pass0 = 0;
+                bool tail = false;
+                const uint32_t corr = eval_point(sc0, T, make3(P.x, P.y, P.z), idx, fx0, pass0, nullptr, &tail);
+                if (!tail) continue;
+                const unsigned long long bit = 1ull << (pos & 63u);
+                atomicOr(&tb[pos >> 6], bit);
+                if (corr) atomicOr(&cb[pos >> 6], bit);
+            }
+            __syncthreads();
+        } else
     /* ---- pass 1: bits ---- */
     for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kEdFusedChunk) {
         if (wave == 0) {
@@ -429,11 +466,16 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
             const uint32_t sidx = s_list[i] * 64u + lane;
             const float4 P = ca.spos[sidx];
             if (!(P.x == P.x)) continue; /* mask_ (:434), non-finite, padding */
-            long long fx = 0;
-            uint32_t pass = 0;
-            bool tail = false;
-            const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), sidx, fx, pass, nullptr, &tail);
-            if (!tail) continue; /* only in-grid points need their scan position */
+            /* in-grid test first (the arithmetic of eval_point): only in-grid points have a bit, and only those
+             * whose scan position belongs to this step go through the gathers */
+            {
+                const f3 q = xform_point(T, make3(P.x, P.y, P.z));
+                const float vx = a.sc.g.sx * q.x + a.sc.g.tx, vy = a.sc.g.sy * q.y + a.sc.g.ty,
+                            vz = a.sc.g.sz * q.z + a.sc.g.tz;
+                const bool in = (vx > -1.f) & (vx < a.sc.g.fex) & (vy > -1.f) & (vy < a.sc.g.fey) & (vz > -1.f) &
+                                (vz < a.sc.g.fez);
+                if (!in) continue;
+            }
             const uint32_t orig = __float_as_uint(P.w);
             uint32_t pos;
             if (ball) {
@@ -444,23 +486,29 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
                 pos = ca.pos_of_orig[orig];
                 if (pos == 0xFFFFFFFFu) continue;
             }
+            if (pos < pos_lo || pos >= pos_hi) continue;
+            long long fx = 0;
+            uint32_t pass = 0;
+            bool tail = false;
+            const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), sidx, fx, pass, nullptr, &tail);
+            if (!tail) continue;
             const unsigned long long bit = 1ull << (pos & 63u);
             atomicOr(&tb[pos >> 6], bit);
             if (corr) atomicOr(&cb[pos >> 6], bit);
         }
         __syncthreads();
     }
-    /* ---- pass 2: the sequential rule, one wave ---- */
+    /* ---- pass 2: the sequential rule, one wave; over the first walk_words words of the bit arrays ---- */
     if (wave == 0) {
         uint32_t k = 0, min_pos = 0;
         if (tests[0] > 0) min_pos = tests[0] - 1;
         uint32_t corr_before = 0;
         int32_t dropped = -1;
         uint32_t drop_count = 0, drop_pos = 0;
-        for (uint32_t w0 = 0; w0 < a.words && dropped < 0; w0 += 64) {
+        for (uint32_t w0 = 0; w0 < walk_words && dropped < 0; w0 += 64) {
             const uint32_t w = w0 + lane;
-            const unsigned long long tword = w < a.words ? tb[w] : 0ull;
-            const unsigned long long cword = w < a.words ? cb[w] : 0ull;
+            const unsigned long long tword = w < walk_words ? tb[w] : 0ull;
+            const unsigned long long cword = w < walk_words ? cb[w] : 0ull;
             uint32_t pc = (uint32_t)__popcll(cword);
             uint32_t incl = pc;
             for (int off = 1; off < 64; off <<= 1) {
@@ -504,9 +552,13 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
             s_count = dropped >= 0 ? drop_count : corr_before;
             s_saved = dropped >= 0 ? S - (drop_pos + 1) : 0u;
             s_limit = dropped >= 0 ? drop_pos : (S ? S - 1 : 0xFFFFFFFFu);
+            /* decided: dropped inside the evaluated prefix, or the prefix was the whole scan */
+            s_done = (dropped >= 0 || walk_words >= S_words) ? 1u : 0u;
         }
     }
     __syncthreads();
+    if (s_done) break;
+    } /* step */
     /* ---- pass 3: score terms of the correspondences up to the stop position ---- */
     const uint32_t lim = s_limit;
     long long fx = 0;
@@ -634,7 +686,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
-    a.sc.ablate = 0;
+    a.sc.ablate = c->ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
     a.sc.kind = m->metric_kind;
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
@@ -828,7 +880,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
-    a.sc.ablate = 0;
+    a.sc.ablate = c->ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
     a.sc.kind = m->metric_kind;
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
