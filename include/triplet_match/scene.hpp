@@ -67,14 +67,22 @@ struct hip_backend {
             cache_hi = cache_lo + batch.size();
             cache_radius = radius;
             count_cache.assign(batch.size(), 0u);
-            check(tm_scene_radius_lists(s, batch.data(), (uint32_t)batch.size(), radius, nullptr, 0, count_cache.data()),
-                  "tm_scene_radius_lists");
-            cache_stride = 1;
-            for (uint32_t cnt : count_cache) cache_stride = std::max<size_t>(cache_stride, cnt);
-            if (list_cache.size() < batch.size() * cache_stride) list_cache.resize(batch.size() * cache_stride);
-            check(tm_scene_radius_lists(s, batch.data(), (uint32_t)batch.size(), radius, list_cache.data(),
-                                        (uint32_t)cache_stride, count_cache.data()),
-                  "tm_scene_radius_lists");
+            /* one call with the stride of the last batch (+25 %); a larger neighbourhood reports
+             * TM_ERR_CAPACITY with the counts filled in, and the call is repeated with room for it */
+            if (cache_stride < 1024) cache_stride = 1024;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (list_cache.size() < batch.size() * cache_stride) list_cache.resize(batch.size() * cache_stride);
+                const int rc = tm_scene_radius_lists(s, batch.data(), (uint32_t)batch.size(), radius, list_cache.data(),
+                                                     (uint32_t)cache_stride, count_cache.data());
+                if (rc == TM_ERR_CAPACITY && attempt == 0) {
+                    size_t mx = 1;
+                    for (uint32_t cnt : count_cache) mx = std::max<size_t>(mx, cnt);
+                    cache_stride = mx + mx / 4;
+                    continue;
+                }
+                check(rc, "tm_scene_radius_lists");
+                break;
+            }
             k = cache_lo;
         }
         const int32_t* src = list_cache.data() + (k - cache_lo) * cache_stride;

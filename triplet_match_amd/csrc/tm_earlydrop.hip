@@ -980,17 +980,28 @@ extern "C" int tm_scene_radius_lists(tm_scene* s, const uint32_t* centers, uint3
     if (!lists) return TM_OK; /* counts only */
     uint32_t S_max = 0;
     for (uint32_t k = 0; k < n_centers; ++k) S_max = std::max(S_max, counts[k]);
+    /* counts are valid on TM_ERR_CAPACITY: the caller may retry with a larger stride */
     TM_REQUIRE(stride >= S_max, TM_ERR_CAPACITY, "tm_scene_radius_lists: stride smaller than a neighbourhood");
     if (S_max == 0) return TM_OK;
     TM_FORWARD(s->ed_subset.ensure((size_t)n_centers * S_max));
     hipLaunchKernelGGL(k_ball_list, grid_n, dim3(256), 0, c->stream, s->ed_member.p, s->ed_wprefix.p, s->n, mwords,
                        S_max, s->ed_subset.p);
     TM_HIP_CHECK(hipGetLastError());
+    /* one copy into pinned staging memory (a pageable destination moves at a fraction of the PCIe rate), then the
+     * rows go to the caller's buffer */
+    const size_t need = (size_t)n_centers * S_max * 4;
+    if (s->h_pinned_bytes < need) {
+        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+        s->h_pinned = nullptr;
+        s->h_pinned_bytes = 0;
+        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
+        s->h_pinned_bytes = need + need / 4;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_subset.p, need, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (uint32_t k = 0; k < n_centers; ++k)
         if (counts[k])
-            TM_HIP_CHECK(hipMemcpyAsync(lists + (size_t)k * stride, s->ed_subset.p + (size_t)k * S_max,
-                                        (size_t)counts[k] * 4, hipMemcpyDeviceToHost, c->stream));
-    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            memcpy(lists + (size_t)k * stride, (const int32_t*)s->h_pinned + (size_t)k * S_max, (size_t)counts[k] * 4);
     return TM_OK;
 }
 

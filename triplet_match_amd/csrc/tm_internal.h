@@ -199,6 +199,8 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;
+    void* h_pinned = nullptr; /* pinned staging memory of tm_scene_radius_lists */
+    size_t h_pinned_bytes = 0;
 };
 
 namespace tmx {

@@ -1392,6 +1392,7 @@ int tm_scene_destroy(tm_scene* s) {
     }
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     s->d_cloud.release();
     s->d_tmask.release();
     s->d_mask.release();
