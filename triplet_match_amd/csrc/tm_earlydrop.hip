@@ -364,20 +364,35 @@ __global__ __launch_bounds__(256) void k_ed_score(ed_args a, const uint32_t* __r
 constexpr int kEdFusedChunk = 2048; /* tiles per culling round in the fused kernel: 8 KB of LDS */
 constexpr size_t kEdFusedLdsMax = 48 * 1024; /* dynamic LDS for the two bit arrays: subsets up to 196k points */
 
+constexpr uint32_t kEdPrefixWords = 256; /* scan positions a prefix-only workgroup can hold bits for: 16,384 */
+
+/* PREFIX = true: step 0 only, with 4 KiB of static LDS for the bits (eight workgroups per CU instead of the
+ * two or three the full bit arrays allow): decides the 98 % of hypotheses that drop at the first checkpoint and
+ * appends the others to `pending`. PREFIX = false: the whole rule; with a pending list, workgroup b takes
+ * hypothesis pending[b] (workgroups beyond *n_pending leave at once). */
+template <bool PREFIX>
 __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out o, float accept_thresh,
-                                                  const uint32_t* __restrict__ tests, const float4* __restrict__ oref) {
-    extern __shared__ unsigned long long s_bits[]; /* [words] in-grid bits, then [words] correspondence bits */
-    __shared__ uint32_t s_list[kEdFusedChunk];
+                                                  const uint32_t* __restrict__ tests, const float4* __restrict__ oref,
+                                                  uint32_t* __restrict__ pending, uint32_t* __restrict__ n_pending) {
+    extern __shared__ unsigned long long s_dyn[]; /* PREFIX = false: [words] in-grid bits, then [words] correspondence bits */
+    __shared__ unsigned long long s_static[PREFIX ? 2 * kEdPrefixWords : 1];
+    unsigned long long* s_bits = PREFIX ? s_static : s_dyn;
+    __shared__ uint32_t s_list[PREFIX ? 1 : kEdFusedChunk];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_smask;
     __shared__ uint32_t s_limit, s_count, s_saved;
     __shared__ int32_t s_dropped;
     __shared__ unsigned long long s_fx[4];
-    const uint32_t hl = blockIdx.x;
+    uint32_t hl = blockIdx.x;
+    if (!PREFIX && pending) { /* continuation of the hypotheses the prefix kernel could not decide */
+        if (blockIdx.x >= *n_pending) return;
+        hl = pending[blockIdx.x];
+    }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bit_words = PREFIX ? kEdPrefixWords : a.words;
     unsigned long long* tb = s_bits;
-    unsigned long long* cb = s_bits + a.words;
-    for (uint32_t w = threadIdx.x; w < 2u * a.words; w += 256) s_bits[w] = 0ull;
+    unsigned long long* cb = s_bits + bit_words;
+    for (uint32_t w = threadIdx.x; w < 2u * bit_words; w += 256) s_bits[w] = 0ull;
     const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
     const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
                               ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
@@ -406,13 +421,20 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     const uint32_t S_words = (S + 63u) / 64u;
     uint32_t B_words = (tests[0] + 1024u + 63u) / 64u;
     if (B_words > S_words) B_words = S_words;
-    if (a.sc.ablate == 30) B_words = 0u; /* TM_ABLATE=30: everything in the tile-culled pass (timing comparison) */
-    for (uint32_t step = 0; step < 2; ++step) {
+    if (PREFIX && B_words > kEdPrefixWords) B_words = kEdPrefixWords; /* a shorter prefix may just not decide */
+    if (!PREFIX && (pending || a.sc.ablate == 30)) B_words = 0u; /* the whole scan in the tile-culled pass */
+    for (uint32_t step = 0; step < (PREFIX ? 1u : 2u); ++step) {
         const uint32_t pos_lo = step == 0 ? 0u : B_words * 64u;
         const uint32_t pos_hi = step == 0 ? B_words * 64u : 0xFFFFFFFFu;
         const uint32_t walk_words = step == 0 ? B_words : a.words;
         if (step == 0) {
-            if (B_words == 0u) continue;
+            if (B_words == 0u) {
+                if (PREFIX) { /* nothing to decide on: hand over */
+                    if (threadIdx.x == 0) pending[atomicAdd(n_pending, 1u)] = hl;
+                    return;
+                }
+                continue;
+            }
             score_args sc0 = a.sc;
             sc0.sref = oref; /* original order, as pass 3 */
             const uint32_t n_pos = min(pos_hi, S);
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
                 if (corr) atomicOr(&cb[pos >> 6], bit);
             }
             __syncthreads();
-        } else
+        } else if (!PREFIX)
     /* ---- pass 1: bits ---- */
     for (uint32_t t0 = 0; t0 < ca.n_tiles; t0 += kEdFusedChunk) {
         if (wave == 0) {
@@ -558,6 +580,10 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     }
     __syncthreads();
     if (s_done) break;
+    if (PREFIX) { /* not decided inside the prefix: the full kernel takes this hypothesis */
+        if (threadIdx.x == 0) pending[atomicAdd(n_pending, 1u)] = hl;
+        return;
+    }
     } /* step */
     /* ---- pass 3: score terms of the correspondences up to the stop position ---- */
     const uint32_t lim = s_limit;
@@ -593,6 +619,26 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
         o.saved[h] = s_saved;
         o.limit[h] = lim;
     }
+}
+
+/* the fused rule in two launches: the prefix kernel (small LDS, high occupancy) decides the hypotheses that
+ * drop at the first checkpoint, the full kernel continues with the rest (TM_ED_ONE_KERNEL=1: full kernel only) */
+static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t fused_lds, const ed_args& a,
+                                  const ed_cull& cu, const ed_out& o, float accept_thresh, const uint32_t* d_tests) {
+    if (getenv("TM_ED_ONE_KERNEL")) {
+        hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh,
+                           d_tests, s->oref.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        return hipGetLastError();
+    }
+    if (s->ed_pending.ensure((size_t)n_hyp + 1) != TM_OK) return hipErrorOutOfMemory;
+    uint32_t* d_n = s->ed_pending.p + n_hyp;
+    hipError_t e = hipMemsetAsync(d_n, 0, 4, c->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 0, c->stream, a, cu, o, accept_thresh, d_tests,
+                       s->oref.p, s->ed_pending.p, d_n);
+    hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh, d_tests,
+                       s->oref.p, s->ed_pending.p, d_n);
+    return hipGetLastError();
 }
 
 }  // namespace tmx
@@ -752,9 +798,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     const bool fused = culled && fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
     if (fused) { /* bits, walk and score in one kernel, bit arrays in LDS */
         ac.h0 = 0;
-        hipLaunchKernelGGL(k_ed_fused, dim3(n_hyp), dim3(256), fused_lds, c->stream, ac, cu, o, accept_thresh,
-                           d_tests.p, s->oref.p);
-        ED_HIP(hipGetLastError());
+        ED_HIP(launch_ed_fused(s, c, n_hyp, fused_lds, ac, cu, o, accept_thresh, d_tests.p));
     }
     for (uint32_t h0 = 0; h0 < n_hyp && !fused; h0 += chunk) {
         const uint32_t nh = std::min(chunk, n_hyp - h0);
@@ -924,9 +968,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
     const bool fused = fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
     if (fused) {
         a.h0 = 0;
-        hipLaunchKernelGGL(k_ed_fused, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh, d_tests.p,
-                           s->oref.p);
-        TM_HIP_CHECK(hipGetLastError());
+        TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p));
     }
     for (uint32_t h0 = 0; h0 < n_hyp && !fused; h0 += chunk) {
         const uint32_t nh = std::min(chunk, n_hyp - h0);

@@ -194,6 +194,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
     tmx::dbuf<unsigned long long> ed_tail, ed_corr, ed_tilebits, ed_member;
     tmx::dbuf<uint32_t> ed_slot, ed_centres, ed_wprefix, ed_S;
+    tmx::dbuf<uint32_t> ed_pending; /* hypotheses the prefix kernel of the early-drop rule hands to the full kernel, + count */
     tmx::dbuf<float4> ed_cpos;
     tmx::dbuf<unsigned char> w_active_sorted; /* subset flags in sorted order */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */

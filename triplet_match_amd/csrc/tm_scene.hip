@@ -1437,6 +1437,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->ed_centres.release();
     s->ed_wprefix.release();
     s->ed_S.release();
+    s->ed_pending.release();
     s->ed_cpos.release();
     delete s;
     return TM_OK;
