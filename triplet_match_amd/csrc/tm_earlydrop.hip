@@ -383,11 +383,14 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     __shared__ uint32_t s_limit, s_count, s_saved;
     __shared__ int32_t s_dropped;
     __shared__ unsigned long long s_fx[4];
-    uint32_t hl = blockIdx.x;
-    if (!PREFIX && pending) { /* continuation of the hypotheses the prefix kernel could not decide */
-        if (blockIdx.x >= *n_pending) return;
-        hl = pending[blockIdx.x];
-    }
+    /* the continuation of the hypotheses the prefix kernel could not decide runs on a small grid whose
+     * workgroups walk the pending list; the other launches take one hypothesis per workgroup */
+    const bool from_list = !PREFIX && pending != nullptr;
+    const uint32_t n_items = from_list ? *n_pending : gridDim.x;
+    const uint32_t* const tests_in = tests;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t hl = from_list ? pending[item] : item;
+    tests = tests_in;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bit_words = PREFIX ? kEdPrefixWords : a.words;
     unsigned long long* tb = s_bits;
@@ -619,6 +622,8 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
         o.saved[h] = s_saved;
         o.limit[h] = lim;
     }
+    __syncthreads(); /* the shared state is reused by the next item */
+    } /* item */
 }
 
 /* the fused rule in two launches: the prefix kernel (small LDS, high occupancy) decides the hypotheses that
@@ -636,8 +641,10 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 0, c->stream, a, cu, o, accept_thresh, d_tests,
                        s->oref.p, s->ed_pending.p, d_n);
-    hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh, d_tests,
-                       s->oref.p, s->ed_pending.p, d_n);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    hipLaunchKernelGGL(k_ed_fused<false>, dim3(std::min<uint32_t>(n_hyp, (uint32_t)cus * 2u)), dim3(256), fused_lds,
+                       c->stream, a, cu, o, accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
     return hipGetLastError();
 }
 
