@@ -189,6 +189,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_masks;       /* grouped scoring: hypothesis mask per (group, chunk) */
     tmx::dbuf<uint32_t> w_items;       /* grouped scoring: slots with a non-zero mask, + the count */
     tmx::dbuf<float2> w_aux;           /* grouped scoring: per hypothesis (rnorm, abs_eps) */
+    tmx::dbuf<uint32_t> w_heads;       /* grouped scoring: per-XCD head words of the item hand-out */
     /* early-drop path (tm_earlydrop.hip) */
     tmx::dbuf<int32_t> ed_subset, ed_dropped;
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;

@@ -402,6 +402,7 @@ struct group_args {
     const uint32_t* items;  /* slots with a non-zero mask */
     const uint32_t* n_items;
     const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
+    uint32_t* heads;        /* per XCD (128 bytes apart): next item of its range, or null = static shares */
 };
 
 struct nonzero_mask {
@@ -482,7 +483,18 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
     unsigned long long* acc =
         reinterpret_cast<unsigned long long*>(s_raw[wave] + 6144 + G * 56 + G * 64); /* count << 52 | sum */
     if (lane < (uint32_t)G) acc[lane] = 0ull;
-    for (uint32_t it = lo + wave_in_xcd; it < hi; it += waves_per_xcd) {
+    /* Items differ a lot in cost (1 to 16 hypotheses, 0 to 32 quarter-tiles each): with a static share per wave
+     * the average wave was resident for 72 % of the kernel only. Each wave therefore pulls its next item from
+     * its XCD's head word (one returning atomic per ~70 us item; the ranges stay contiguous per XCD and are
+     * handed out in order, so concurrently running waves still work on neighbouring items). */
+    uint32_t it = lo + wave_in_xcd;
+    for (;;) {
+        if (ga.heads) {
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(ga.heads + 32u * xcd, 1u);
+            it = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+        }
+        if (it >= hi) break;
         const uint32_t slot = ga.items[it];
         const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
         uint32_t m = (uint32_t)ga.masks[slot];
@@ -582,8 +594,10 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 ent[o++] = (unsigned short)((g << 5) | lane);
             }
         }
-        if (n == 0u) continue;
-        if (a.ablate == 10) continue; /* timing experiment: staging and culling only */
+        if (n == 0u || a.ablate == 10) { /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
+            if (!ga.heads) it += waves_per_xcd;
+            continue;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -695,6 +709,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 acc[lane] = 0ull;
             }
         }
+        if (!ga.heads) it += waves_per_xcd;
     }
     for (int off = 32; off > 0; off >>= 1) {
         evals += __shfl_down(evals, off);
@@ -1153,6 +1168,12 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.items = s->w_items.p;
             ga.n_items = s->w_items.p + n_slots_g;
             d_n_items = ga.n_items;
+            ga.heads = nullptr;
+            if (!getenv("TM_ITEM_STATIC")) { /* dynamic hand-out of the items: eight head words, 128 B apart */
+                TM_FORWARD(s->w_heads.ensure(8 * 32));
+                TM_HIP_CHECK(hipMemsetAsync(s->w_heads.p, 0, 8 * 32 * 4, c->stream));
+                ga.heads = s->w_heads.p;
+            }
             hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, (ga.n_chunks + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
             size_t tmp = 0;
@@ -1409,6 +1430,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->subs.release();
     s->chunks.release();
     s->w_masks.release();
+    s->w_heads.release();
     s->w_aux.release();
     s->w_items.release();
     s->w_poses.release();
