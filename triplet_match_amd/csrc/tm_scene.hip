@@ -403,6 +403,8 @@ struct group_args {
     const uint32_t* n_items;
     const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
     uint32_t* heads;        /* per XCD (128 bytes apart): next item of its range, or null = static shares */
+    uint32_t steal;         /* 1 = a wave whose XCD's range is exhausted continues in the other XCDs' ranges */
+    uint32_t run_shift;     /* log2 of the run of consecutive items one XCD owns; 0xFFFFFFFF = from n_items */
 };
 
 struct nonzero_mask {
@@ -484,17 +486,33 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         reinterpret_cast<unsigned long long*>(s_raw[wave] + 6144 + G * 56 + G * 64); /* count << 52 | sum */
     if (lane < (uint32_t)G) acc[lane] = 0ull;
     /* Items differ a lot in cost (1 to 16 hypotheses, 0 to 32 quarter-tiles each): with a static share per wave
-     * the average wave was resident for 72 % of the kernel only. Each wave therefore pulls its next item from
-     * its XCD's head word (one returning atomic per ~70 us item; the ranges stay contiguous per XCD and are
-     * handed out in order, so concurrently running waves still work on neighbouring items). */
-    uint32_t it = lo + wave_in_xcd;
+     * the average wave was resident for 72 % of the kernel only (12.97 ms). Each wave therefore pulls its next
+     * item from a counter of its XCD (one returning atomic per ~50 us item; 11.3 ms), and when the XCD's items
+     * are exhausted it continues with the next XCD's (9.65 ms). The items of an XCD are runs of 2^run_shift
+     * consecutive items handed out in order, so the waves of one L2 work on neighbouring items at any time
+     * (one counter for the whole chip: 11.7 ms); runs of 8192 and one contiguous range per XCD measure the
+     * same, shorter runs lose locality (128: 9.95 ms). */
+    const uint32_t run_shift =
+        ga.run_shift != 0xFFFFFFFFu ? ga.run_shift : min(13u, max(6u, 31u - (uint32_t)__clz((int)((n_items >> 6) | 1u))));
+    uint32_t it = lo + wave_in_xcd, victim = 0, pend = 0;
+    if (ga.heads && lane == 0) pend = atomicAdd(ga.heads + 32u * xcd, 1u);
     for (;;) {
         if (ga.heads) {
-            uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(ga.heads + 32u * xcd, 1u);
-            it = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+            /* own items first, then those of the XCDs after this one (the tail of the kernel only); the
+             * counter is read one item ahead so its round trip to the fabric is off the item's path */
+            const uint32_t x = (xcd + victim) & 7u;
+            const uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pend);
+            /* the n-th item of XCD x: runs of 2^run_shift consecutive items go round the XCDs */
+            it = ((((nxt >> run_shift) << 3) + x) << run_shift) + (nxt & ((1u << run_shift) - 1u));
+            if (it >= n_items) {
+                if (++victim == 8u || ga.steal == 0u) break;
+                if (lane == 0) pend = atomicAdd(ga.heads + 32u * ((xcd + victim) & 7u), 1u);
+                continue;
+            }
+            if (lane == 0) pend = atomicAdd(ga.heads + 32u * x, 1u);
+        } else if (it >= hi) {
+            break;
         }
-        if (it >= hi) break;
         const uint32_t slot = ga.items[it];
         const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
         uint32_t m = (uint32_t)ga.masks[slot];
@@ -1169,10 +1187,14 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.n_items = s->w_items.p + n_slots_g;
             d_n_items = ga.n_items;
             ga.heads = nullptr;
+            ga.steal = 0;
+            ga.run_shift = 0;
             if (!getenv("TM_ITEM_STATIC")) { /* dynamic hand-out of the items: eight head words, 128 B apart */
                 TM_FORWARD(s->w_heads.ensure(8 * 32));
                 TM_HIP_CHECK(hipMemsetAsync(s->w_heads.p, 0, 8 * 32 * 4, c->stream));
                 ga.heads = s->w_heads.p;
+                ga.steal = getenv("TM_ITEM_NOSTEAL") ? 0u : 1u;
+                ga.run_shift = getenv("TM_ITEM_RUN") ? (uint32_t)atoi(getenv("TM_ITEM_RUN")) : 0xFFFFFFFFu;
             }
             hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, (ga.n_chunks + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
