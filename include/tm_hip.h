@@ -252,6 +252,26 @@ int tm_score_hypotheses_early_drop_ball(tm_scene* scene, tm_model* model, const 
                                         float dist_thres, float accept_prob, uint32_t* counts,
                                         double* scores, int32_t* dropped_at, uint32_t* saved);
 
+/* One batch of find_in_subset's inner loop in one call (include/impl/scene.hpp:284-350 for up to 16 first
+ * points): the hypotheses of the valid sample pairs (i, j) are generated in visit order (pair after pair, the
+ * pair's table entries in stored order, at most query_limit each; query_limit > 0), every hypothesis is scored
+ * on nn = radius_search_inclusive(radius, i) of its own first point (with the early-drop rule when early_drop),
+ * and the first hypothesis in visit order with score > 0 and (float)count > sufficient is returned (:330-338).
+ * Same results as tm_generate_hypotheses + tm_score_hypotheses_[early_drop_]ball + a host scan, without the
+ * poses and the per-hypothesis results crossing PCIe: 8 bytes per pair go up, one 88-byte record comes back. */
+typedef struct tm_batch_result {
+    int32_t index;         /* position of that hypothesis in the batch, -1 = none is sufficient */
+    uint32_t n_hypotheses; /* hypotheses generated from the pairs */
+    uint32_t count;        /* its correspondences */
+    int32_t dropped_at;    /* its early-drop checkpoint, -1 = scanned to the end */
+    double score;          /* as tm_score_hypotheses_[early_drop_]ball reports it */
+    float pose[16];
+} tm_batch_result; /* 88 bytes */
+int tm_search_batch(tm_scene* scene, tm_model* model, const uint32_t* ij_pairs, uint32_t n_pairs,
+                    float min_diameter_factor, float max_diameter_factor, int force_up, int query_limit,
+                    float radius, float dist_thres, float accept_prob, int early_drop, float sufficient,
+                    tm_batch_result* result);
+
 /* finish_find (include/impl/scene.hpp:100-106): correspondences of one pose over all points,
  * ascending scene index; *score normalised by |model cloud| */
 int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pose16[16],

@@ -7,6 +7,8 @@
 #ifndef TRIPLET_MATCH_SCENE_HPP_
 #define TRIPLET_MATCH_SCENE_HPP_
 
+#include <cstdlib>
+
 #include "model.hpp"
 #include "projected_search.hpp"
 #include "search.hpp"
@@ -115,6 +117,20 @@ struct hip_backend {
         poses.resize(count);
         pair_of_hyp.resize(count);
         for (uint32_t h = 0; h < count; ++h) pair_of_hyp[h] = prov[4 * (size_t)h];
+    }
+    /* one batch of find_in_subset on the device (tm_search_batch); TM_SEARCH_UNFUSED=1: the three calls above
+     * and below with the scan on the host (same results) */
+    bool supports_fused_batch() const { return getenv("TM_SEARCH_UNFUSED") == nullptr; }
+    bool search_batch(const std::vector<uint32_t>& ij, float radius, bool early_drop, float sufficient,
+                      search::pose_t& pose) {
+        tm_batch_result r;
+        check(tm_search_batch(s, m, ij.data(), (uint32_t)(ij.size() / 2), p.min_diameter_factor, p.max_diameter_factor,
+                              p.force_up ? 1 : 0, search::query_limit, radius, p.dist_thres, p.accept_prob,
+                              early_drop ? 1 : 0, sufficient, &r),
+              "tm_search_batch");
+        if (r.index < 0) return false;
+        for (int k = 0; k < 16; ++k) pose.m[k] = r.pose[k];
+        return true;
     }
     void score_ball(const std::vector<search::pose_t>& poses, const std::vector<uint32_t>& centers, float radius,
                     bool early_drop, std::vector<uint32_t>& counts, std::vector<double>& scores) {

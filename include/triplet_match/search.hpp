@@ -25,6 +25,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <random>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace triplet_match {
@@ -222,6 +224,26 @@ inline void partial_shuffle(std::vector<T>& v, size_t count, std::mt19937& rng) 
     }
 }
 
+/* does the backend offer the whole batch step (generate + neighbourhood scoring + first sufficient
+ * hypothesis) as one call? (hip_backend: tm_search_batch) */
+template <class B, class = void>
+struct has_search_batch : std::false_type {};
+template <class B>
+struct has_search_batch<B, decltype(void(std::declval<B&>().search_batch(
+                               std::declval<const std::vector<uint32_t>&>(), 0.f, false, 0.f, std::declval<pose_t&>())))>
+    : std::true_type {};
+template <class B>
+inline bool fused_batch(B& be, const std::vector<uint32_t>& ij, float radius, bool early_drop, float sufficient,
+                        pose_t& pose, bool& found, std::true_type) {
+    if (!be.supports_fused_batch()) return false;
+    found = be.search_batch(ij, radius, early_drop, sufficient, pose);
+    return true;
+}
+template <class B>
+inline bool fused_batch(B&, const std::vector<uint32_t>&, float, bool, float, pose_t&, bool&, std::false_type) {
+    return false;
+}
+
 }  // namespace detail
 
 /* find_in_subset, include/impl/scene.hpp:242-367 */
@@ -279,6 +301,16 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             return;
         }
         TM_TIMED(generate_score);
+        if (!p.min_tangent_inliers) { /* the whole step on the device when the backend has it */
+            pose_t hit;
+            bool found = false;
+            if (detail::fused_batch(be, batch_ij, be.model_diameter(), p.early_drop, sufficient, hit, found,
+                                    detail::has_search_batch<Backend>{})) {
+                if (found) best_ts.push_back(hit);
+                batch_ij.clear();
+                return;
+            }
+        }
         be.generate_with_pairs(batch_ij, poses, pair_of_hyp);
         if (!poses.empty()) {
             centers.resize(poses.size());

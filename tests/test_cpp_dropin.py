@@ -95,10 +95,16 @@ def test_rank_sharded_search_equals_single_process(tmp_path, world):
 
 
 @pytest.mark.gpu
-def test_host_orchestration_hip_equals_oracle(tmp_path):
+@pytest.mark.parametrize("unfused", [False, True])
+def test_host_orchestration_hip_equals_oracle(tmp_path, unfused):
+    """the HIP backend's batch step is one tm_search_batch call by default; TM_SEARCH_UNFUSED=1 takes the separate
+    generate / score / host-scan calls: both equal the oracle backend's one-first-point-at-a-time loop"""
     exe = _compile("test_search", _oracle_link())
     fx = _fixture(str(tmp_path / "case.bin"))
-    r = subprocess.run([exe, fx, "both"], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ)
+    if unfused:
+        env["TM_SEARCH_UNFUSED"] = "1"
+    r = subprocess.run([exe, fx, "both"], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
 
@@ -137,7 +143,11 @@ def test_batched_search_equals_one_at_a_time(tmp_path):
     launch), the oracle backend the reference's one-first-point-at-a-time loop: identical results."""
     exe = _compile("test_search", _oracle_link())
     fx = _fixture(str(tmp_path / "case.bin"))
-    r = subprocess.run([exe, fx, "both_noearlydrop"], capture_output=True, text=True, timeout=900)
+    for extra in ({}, {"TM_SEARCH_UNFUSED": "1"}):
+        r = subprocess.run([exe, fx, "both_noearlydrop"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **extra))
+        print(r.stdout[-3000:], r.stderr[-2000:])
+        assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "ok   hip backend == oracle backend" in r.stdout
 

@@ -836,6 +836,51 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
             os_.set_mask(None)
 
 
+def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_case):
+    """tm_search_batch (one find_in_subset batch on the device) == tm_generate_hypotheses +
+    tm_score_hypotheses_[early_drop_]ball + the host scan for the first sufficient hypothesis in visit order
+    (reference include/impl/scene.hpp:284-350), for thresholds that put the hit early, late and nowhere."""
+    gs, gm = gpu_small["scene"], gpu_small["model"]
+    om = oracle_small["model"]
+    pairs = sample_pairs(small_case, om, n_first=16, per_first=8, seed=31)
+    diam = om.diameter
+    mask = np.zeros(gs.n, np.int32)
+    mask[np.random.default_rng(8).integers(0, gs.n, 500)] = 1
+    hits = 0
+    for use_mask in (False, True):
+        gs.set_mask(mask if use_mask else None)
+        try:
+            poses, prov, _ = gs.generate_hypotheses(gm, pairs)  # a masked sample point generates nothing
+            centers = pairs[prov[:, 0], 0].astype(np.uint32)
+            assert len(poses) > 500
+            for early_drop in (True, False):
+                if early_drop:
+                    c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
+                else:
+                    c, sc = gs.score_hypotheses_ball(gm, poses, centers, diam, DT)
+                    dr = np.full(len(c), -1, np.int32)
+                order = np.sort(c[sc > 0])
+                for sufficient in (-1.0, float(np.median(order)), float(order[-3]), float(order[-1]) - 0.5,
+                                   float(order[-1]), 1e9):
+                    ok = np.nonzero((sc > 0) & (c.astype(np.float32) > np.float32(sufficient)))[0]
+                    want = int(ok[0]) if len(ok) else -1
+                    idx, n_hyp, cnt, dropped, score, pose = gs.search_batch(gm, pairs, diam, DT, 0.5, early_drop,
+                                                                            sufficient, min_diameter_factor=0.2)
+                    assert n_hyp == len(poses)
+                    assert idx == want, (early_drop, sufficient)
+                    if want >= 0:
+                        hits += 1
+                        assert cnt == c[want] and score == sc[want] and dropped == dr[want]
+                        assert np.array_equal(pose, poses[want].reshape(-1))
+        finally:
+            gs.set_mask(None)
+    assert hits >= 12
+    # degenerate batches
+    assert gs.search_batch(gm, np.zeros((0, 2), np.uint32), diam, DT, 0.5, True, 0.0)[0] == -1
+    with pytest.raises(capi.TmError):
+        gs.search_batch(gm, np.array([[0, gs.n]], np.uint32), diam, DT, 0.5, True, 0.0)
+
+
 def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
     gs, os_ = gpu_small["scene"], oracle_small["scene"]
     diam = oracle_small["model"].diameter

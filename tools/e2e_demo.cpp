@@ -66,6 +66,9 @@ int main(int argc, char** argv) {
         auto t4 = std::chrono::steady_clock::now();
         printf("%s call %.3f s -> %zu matches\n", r == 0 ? "second" : "further", std::chrono::duration<double>(t4 - t3).count(),
                again.size());
+        const auto& st = s.last_stats();
+        printf("   phases [s]: radius %.3f sample %.3f generate+score %.3f extract %.3f icp %.3f arbitration %.3f mask %.3f | "
+               "total %.3f\n", st.radius, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask, st.total);
     }
     for (const auto& mt : matches) {
         double best = 1e30;

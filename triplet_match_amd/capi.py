@@ -30,6 +30,12 @@ class BestRecord(C.Structure):
                 ("pose", C.c_float * 16), ("pad", C.c_uint32 * 4)]
 
 
+class BatchResult(C.Structure):
+    """tm_batch_result (include/tm_hip.h), 88 bytes"""
+    _fields_ = [("index", C.c_int32), ("n_hypotheses", C.c_uint32), ("count", C.c_uint32),
+                ("dropped_at", C.c_int32), ("score", C.c_double), ("pose", C.c_float * 16)]
+
+
 assert C.sizeof(BestRecord) == 96
 
 # every symbol include/tm_hip.h declares: name -> (restype, argtypes)
@@ -101,6 +107,8 @@ SIGNATURES = {
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
     "tm_score_hypotheses_early_drop_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, C.c_float,
                                                      u32p, f64p, i32p, u32p]),
+    "tm_search_batch": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
+                                  C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(BatchResult)]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
@@ -689,6 +697,16 @@ class Scene:
                                                          counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p),
                                                          dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
         return counts, scores, dropped, saved
+
+    def search_batch(self, model, ij_pairs, radius, dist_thres, accept_prob, early_drop, sufficient,
+                     min_diameter_factor=0.0, max_diameter_factor=1.0, force_up=False, query_limit=200):
+        """One batch of find_in_subset on the device: (index or -1, n_hypotheses, count, dropped_at, score, pose16)"""
+        ij, pij = _u(np.asarray(ij_pairs).reshape(-1))
+        r = BatchResult()
+        _check(lib().tm_search_batch(self.h, model.h, pij, ij.size // 2, min_diameter_factor, max_diameter_factor,
+                                     1 if force_up else 0, query_limit, radius, dist_thres, accept_prob,
+                                     1 if early_drop else 0, sufficient, C.byref(r)))
+        return r.index, r.n_hypotheses, r.count, r.dropped_at, r.score, np.array(r.pose, np.float32)
 
     def icp_accumulate(self, model, pose16, dist_thres):
         T, pT = _f(pose16)

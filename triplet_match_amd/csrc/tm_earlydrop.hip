@@ -840,50 +840,25 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     return TM_OK;
 }
 
-extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
-                                                   const uint32_t* centers, float radius, float dist_thres,
-                                                   float accept_prob, uint32_t* counts, double* scores,
-                                                   int32_t* dropped_at, uint32_t* saved) {
-    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
-    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
-    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
-    TM_REQUIRE(counts && scores && dropped_at && saved, TM_ERR_INVALID, "null outputs");
-    if (n_hyp == 0) return TM_OK;
-    TM_REQUIRE(poses16 && centers, TM_ERR_INVALID, "null poses or centres");
-    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+/* The ball mode with everything already on the device: poses at d_poses, the slot (index into uniq) of every
+ * hypothesis in s->ed_slot. Leaves counts (s->w_counts), fixed-point sums (s->w_scores_fx), the drop checkpoint
+ * (s->ed_dropped) and the saved evaluations (s->ed_saved) on the device, launched on the context's stream. */
+static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t n_hyp, const uint32_t* uniq,
+                        uint32_t n_slots, float radius, float dist_thres, float accept_prob) {
     tm_ctx* c = s->ctx;
-    TM_HIP_CHECK(hipSetDevice(c->device));
-    /* distinct centres -> slots */
-    std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
-        for (uint32_t h = 0; h < n_hyp; ++h) {
-            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
-            order[h] = {centers[h], h};
-        }
-        std::sort(order.begin(), order.end());
-        for (uint32_t k = 0; k < n_hyp; ++k) {
-            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
-            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
-        }
-    }
-    const uint32_t n_slots = (uint32_t)uniq.size();
     const uint32_t mwords = (s->n + 63) / 64;
     dbuf<uint32_t>&d_slot = s->ed_slot, &d_cent = s->ed_centres, &d_wprefix = s->ed_wprefix, &d_S = s->ed_S,
                   &d_tests = s->ed_tests, &d_counts = s->w_counts, &d_saved = s->ed_saved, &d_limit = s->ed_limit;
     dbuf<unsigned long long>&d_member = s->ed_member, &d_tail = s->ed_tail, &d_corr = s->ed_corr, &d_fx = s->w_scores_fx;
     dbuf<int32_t>&d_list = s->ed_subset, &d_dropped = s->ed_dropped;
-    dbuf<float>& d_poses = s->w_poses;
     int rc;
-    if ((rc = d_slot.ensure(n_hyp)) || (rc = d_cent.ensure(n_slots)) || (rc = d_member.ensure((size_t)n_slots * mwords)) ||
+    if ((rc = d_cent.ensure(n_slots)) || (rc = d_member.ensure((size_t)n_slots * mwords)) ||
         (rc = d_wprefix.ensure((size_t)n_slots * mwords)) || (rc = d_S.ensure(n_slots)) ||
-        (rc = s->ed_cpos.ensure(n_slots)) || (rc = d_poses.ensure((size_t)n_hyp * 16)) || (rc = d_counts.ensure(n_hyp)) ||
+        (rc = s->ed_cpos.ensure(n_slots)) || (rc = d_counts.ensure(n_hyp)) ||
         (rc = d_saved.ensure(n_hyp)) || (rc = d_limit.ensure(n_hyp)) || (rc = d_dropped.ensure(n_hyp)) ||
         (rc = d_fx.ensure(n_hyp)) || (rc = d_tests.ensure((size_t)n_slots * 18 + 2)))
         return rc;
-    TM_HIP_CHECK(hipMemcpyAsync(d_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(d_cent.p, uniq.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(d_cent.p, uniq, (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemsetAsync(d_fx.p, 0, (size_t)n_hyp * 8, c->stream));
     const dim3 grid_n((s->n + 255) / 256, n_slots);
     hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, d_cent.p, radius * radius,
@@ -939,7 +914,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
     a.sc.bx = m->bdim[0];
     a.sc.by = m->bdim[1];
     a.sc.code_max = 255u;
-    a.sc.poses = d_poses.p;
+    a.sc.poses = d_poses;
     a.sc.counts = d_counts.p;
     a.sc.scores_fx = d_fx.p;
     a.sc.stat_slots = nullptr;
@@ -987,6 +962,45 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
         hipLaunchKernelGGL(k_ed_score, dim3((S_max + 255) / 256, nh), dim3(256), 0, c->stream, as, d_limit.p);
         TM_HIP_CHECK(hipGetLastError());
     }
+    return TM_OK;
+}
+
+extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
+                                                   const uint32_t* centers, float radius, float dist_thres,
+                                                   float accept_prob, uint32_t* counts, double* scores,
+                                                   int32_t* dropped_at, uint32_t* saved) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(counts && scores && dropped_at && saved, TM_ERR_INVALID, "null outputs");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(poses16 && centers, TM_ERR_INVALID, "null poses or centres");
+    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    /* distinct centres -> slots */
+    std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
+        for (uint32_t h = 0; h < n_hyp; ++h) {
+            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
+            order[h] = {centers[h], h};
+        }
+        std::sort(order.begin(), order.end());
+        for (uint32_t k = 0; k < n_hyp; ++k) {
+            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
+            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
+        }
+    }
+    TM_FORWARD(s->ed_slot.ensure(n_hyp));
+    TM_FORWARD(s->w_poses.ensure((size_t)n_hyp * 16));
+    TM_HIP_CHECK(hipMemcpyAsync(s->ed_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
+                            accept_prob));
+    dbuf<uint32_t>&d_counts = s->w_counts, &d_saved = s->ed_saved;
+    dbuf<int32_t>& d_dropped = s->ed_dropped;
+    dbuf<unsigned long long>& d_fx = s->w_scores_fx;
     std::vector<unsigned long long> fx(n_hyp);
     TM_HIP_CHECK(hipMemcpyAsync(counts, d_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(saved, d_saved.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
@@ -997,6 +1011,134 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
         double raw = (double)fx[h] * (1.0 / kFx);
         scores[h] = dropped_at[h] >= 0 ? raw : raw / (double)m->n; /* :502 / :509 */
     }
+    return TM_OK;
+}
+
+namespace tmx {
+
+/* hypothesis -> slot of its pair's first point (provenance word 0 = pair index) */
+__global__ void k_batch_slots(const uint4* __restrict__ prov, uint32_t n_hyp, const uint32_t* __restrict__ of_pair,
+                              uint32_t* __restrict__ of_hyp) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < n_hyp) of_hyp[h] = of_pair[prov[h].x];
+}
+
+/* first hypothesis in visit order with score > 0 and (float)count > sufficient (reference :330-338); one block.
+ * fx != null: early-drop results (score = sum / 2^40, divided by n_model when the scan ran to the end);
+ * else scores holds the full-pass scores. */
+__global__ void __launch_bounds__(1024)
+k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ fx,
+                   const double* __restrict__ scores, const int32_t* __restrict__ dropped, uint32_t n_hyp,
+                   float sufficient, double n_model, const float* __restrict__ poses, tm_batch_result* out) {
+    __shared__ uint32_t s_first;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t first = 0xFFFFFFFFu;
+    for (uint32_t h = threadIdx.x; h < n_hyp; h += blockDim.x) {
+        const bool positive = fx ? fx[h] != 0ull : scores[h] > 0.0;
+        if (positive && (float)counts[h] > sufficient) {
+            first = h;
+            break; /* this thread's later candidates come later in visit order */
+        }
+    }
+    if (first != 0xFFFFFFFFu) atomicMin(&s_first, first);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t h = s_first;
+        out->index = h == 0xFFFFFFFFu ? -1 : (int32_t)h;
+        out->n_hypotheses = n_hyp;
+        out->count = 0;
+        out->dropped_at = -1;
+        out->score = 0.0;
+        if (h != 0xFFFFFFFFu) {
+            out->count = counts[h];
+            if (fx) {
+                const double raw = (double)fx[h] * (1.0 / kFx);
+                out->dropped_at = dropped[h];
+                out->score = dropped[h] >= 0 ? raw : raw / n_model;
+            } else {
+                out->score = scores[h];
+            }
+        }
+    }
+    if (s_first != 0xFFFFFFFFu && threadIdx.x < 16) out->pose[threadIdx.x] = poses[(size_t)s_first * 16 + threadIdx.x];
+}
+
+}  // namespace tmx
+
+extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs, float minf,
+                               float maxf, int force_up, int query_limit, float radius, float dist_thres,
+                               float accept_prob, int early_drop, float sufficient, tm_batch_result* out) {
+    TM_REQUIRE(s && m && out, TM_ERR_INVALID, "tm_search_batch: null argument");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(query_limit > 0, TM_ERR_INVALID, "tm_search_batch: query_limit must be positive");
+    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+    memset(out, 0, sizeof(*out));
+    out->index = -1;
+    out->dropped_at = -1;
+    if (n_pairs == 0) return m->pairs_ready ? TM_OK : TM_ERR_NOT_INITIALIZED;
+    TM_REQUIRE(ij_pairs, TM_ERR_INVALID, "tm_search_batch: null pairs");
+    TM_REQUIRE((uint64_t)n_pairs * (uint64_t)query_limit <= 0x7FFFFFFFull, TM_ERR_INVALID, "tm_search_batch: batch too large");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    /* distinct first points -> slots (ascending, as the per-hypothesis entry point numbers them) */
+    std::vector<uint32_t> uniq, slot_of_pair(n_pairs);
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        TM_REQUIRE(ij_pairs[2 * p] < s->n && ij_pairs[2 * p + 1] < s->n, TM_ERR_INVALID, "tm_search_batch: index out of range");
+        uniq.push_back(ij_pairs[2 * p]);
+    }
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (uint32_t p = 0; p < n_pairs; ++p)
+        slot_of_pair[p] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), ij_pairs[2 * p]) - uniq.begin());
+    const uint32_t cap = n_pairs * (uint32_t)query_limit;
+    TM_FORWARD(s->sb_ij.ensure((size_t)n_pairs * 2));
+    TM_FORWARD(s->sb_pair_slot.ensure(n_pairs));
+    TM_FORWARD(s->sb_prov.ensure(cap));
+    TM_FORWARD(s->sb_result.ensure(1));
+    TM_FORWARD(s->w_poses.ensure((size_t)cap * 16));
+    TM_HIP_CHECK(hipMemcpyAsync(s->sb_ij.p, ij_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream));
+    if (early_drop)
+        TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p, slot_of_pair.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice,
+                                    c->stream));
+    uint32_t n_hyp = 0, total = 0;
+    TM_FORWARD(tm_generate_hypotheses_dev(s, m, s->sb_ij.p, n_pairs, minf, maxf, force_up, query_limit, s->w_poses.p,
+                                          (uint32_t*)s->sb_prov.p, cap, &n_hyp, &total));
+    out->n_hypotheses = n_hyp;
+    if (n_hyp == 0) return TM_OK;
+    if (early_drop) {
+        TM_FORWARD(s->ed_slot.ensure(n_hyp));
+        hipLaunchKernelGGL(k_batch_slots, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
+                           s->sb_pair_slot.p, s->ed_slot.p);
+        TM_HIP_CHECK(hipGetLastError());
+        TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
+                                accept_prob));
+        hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
+                           (const double*)nullptr, s->ed_dropped.p, n_hyp, sufficient, (double)m->n, s->w_poses.p,
+                           s->sb_result.p);
+    } else {
+        /* centre of a hypothesis = first point of its pair: the pairs' first words, indexed through the slots */
+        TM_FORWARD(s->sb_centres.ensure(n_hyp));
+        TM_FORWARD(s->w_counts.ensure(n_hyp));
+        TM_FORWARD(s->w_scores.ensure(n_hyp));
+        std::vector<uint32_t> first_of_pair(n_pairs);
+        for (uint32_t p = 0; p < n_pairs; ++p) first_of_pair[p] = ij_pairs[2 * p];
+        TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p, first_of_pair.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice,
+                                    c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream)); /* first_of_pair leaves scope */
+        hipLaunchKernelGGL(k_batch_slots, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
+                           s->sb_pair_slot.p, s->sb_centres.p);
+        TM_HIP_CHECK(hipGetLastError());
+        TM_FORWARD(tm_score_hypotheses_ball_dev(s, m, s->w_poses.p, n_hyp, s->sb_centres.p, radius, dist_thres,
+                                                s->w_counts.p, s->w_scores.p));
+        hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p,
+                           (const unsigned long long*)nullptr, s->w_scores.p, (const int32_t*)nullptr, n_hyp, sufficient,
+                           (double)m->n, s->w_poses.p, s->sb_result.p);
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipMemcpyAsync(out, s->sb_result.p, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return TM_OK;
 }
 

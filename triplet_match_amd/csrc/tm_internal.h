@@ -197,6 +197,10 @@ struct tm_scene {
     tmx::dbuf<uint32_t> ed_slot, ed_centres, ed_wprefix, ed_S;
     tmx::dbuf<uint32_t> ed_pending; /* hypotheses the prefix kernel of the early-drop rule hands to the full kernel, + count */
     tmx::dbuf<float4> ed_cpos;
+    /* tm_search_batch: pairs, provenance, slot of a pair's first point, centre per hypothesis, result record */
+    tmx::dbuf<uint32_t> sb_ij, sb_pair_slot, sb_centres;
+    tmx::dbuf<uint4> sb_prov;
+    tmx::dbuf<tm_batch_result> sb_result;
     tmx::dbuf<unsigned char> w_active_sorted; /* subset flags in sorted order */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */

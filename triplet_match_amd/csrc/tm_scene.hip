@@ -1482,6 +1482,11 @@ int tm_scene_destroy(tm_scene* s) {
     s->ed_wprefix.release();
     s->ed_S.release();
     s->ed_pending.release();
+    s->sb_ij.release();
+    s->sb_pair_slot.release();
+    s->sb_centres.release();
+    s->sb_prov.release();
+    s->sb_result.release();
     s->ed_cpos.release();
     delete s;
     return TM_OK;
