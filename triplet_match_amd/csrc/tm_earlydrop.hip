@@ -54,7 +54,11 @@ struct ed_args {
     uint32_t h0;             /* first hypothesis of this chunk */
     unsigned long long* tail_bits;
     unsigned long long* corr_bits;
+    const uint32_t* stop;    /* tm_search_batch: index of the first sufficient hypothesis found so far, 0xFFFFFFFF =
+                                none yet; the kernels of later segments leave at once when it is set. null = unused */
 };
+
+__device__ __forceinline__ bool ed_stopped(const ed_args& a) { return a.stop && *a.stop != 0xFFFFFFFFu; }
 
 __global__ __launch_bounds__(256) void k_ed_bits(ed_args a) {
     const uint32_t pos = blockIdx.x * 256 + threadIdx.x;
@@ -259,14 +263,20 @@ struct ed_out {
 };
 
 __global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accept_thresh,
-                                                const uint32_t* __restrict__ tests) {
-    const uint32_t hl = blockIdx.x, lane = threadIdx.x;
+                                                const uint32_t* __restrict__ tests,
+                                                const uint32_t* __restrict__ pending = nullptr,
+                                                const uint32_t* __restrict__ n_pending = nullptr, uint32_t row0 = 0) {
+    /* with a pending list: bit row blockIdx.x belongs to hypothesis pending[row0 + blockIdx.x] */
+    const uint32_t row = blockIdx.x, lane = threadIdx.x;
+    if (ed_stopped(a)) return;
+    if (pending && row0 + row >= *n_pending) return;
+    const uint32_t hl = pending ? pending[row0 + row] : row;
     const bool ball = a.ball.slot_of_hyp != nullptr;
     const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
     const uint32_t S = ball ? a.ball.S_of_slot[slot] : a.S;
     if (ball) tests = a.ball.tests_of_slot + 18u * slot;
-    const unsigned long long* tb = a.tail_bits + (size_t)hl * a.words;
-    const unsigned long long* cb = a.corr_bits + (size_t)hl * a.words;
+    const unsigned long long* tb = a.tail_bits + (size_t)row * a.words;
+    const unsigned long long* cb = a.corr_bits + (size_t)row * a.words;
     uint32_t k = 0;           /* next_test */
     uint32_t min_pos = 0;     /* earliest 0-based position the next test may run at */
     if (tests[0] > 0) min_pos = tests[0] - 1;
@@ -355,6 +365,141 @@ __global__ __launch_bounds__(256) void k_ed_score(ed_args a, const uint32_t* __r
     if ((threadIdx.x & 63) == 0 && fx) atomicAdd(&a.sc.scores_fx[a.h0 + hl], (unsigned long long)fx);
 }
 
+/* Wide continuation of the early-drop rule. The ~2 % of hypotheses that survive the first checkpoint are few, so
+ * one workgroup each (k_ed_fused<false>) leaves most of the chip idle while each of them culls the whole scene
+ * and walks its neighbourhood. Here the same three passes run over (pending hypothesis, part of the scene):
+ *   k_ed_zero_rows   clears the bit rows of the pending hypotheses
+ *   k_ed_bits_wide   a workgroup = one super-tile (64 tiles) of the sorted scene for one pending hypothesis, a
+ *                    wave 16 of its tiles: sphere tests, then the points of the surviving tiles -> (tail,
+ *                    correspondence) bits at their scan positions (global atomicOr), as k_ed_bits_culled does
+ *   k_ed_walk        the rule on those rows
+ *   k_ed_score_rows  score terms of the correspondences up to the stop position, eight positions per thread, one
+ *                    atomic per workgroup (same-address atomics serialise: one per wave cost 0.4 ms) */
+__global__ __launch_bounds__(256) void k_ed_zero_rows(unsigned long long* __restrict__ tail_bits,
+                                                      unsigned long long* __restrict__ corr_bits, uint32_t words,
+                                                      const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                      uint32_t rows_cap) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    if (w >= words) return;
+    for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        tail_bits[(size_t)row * words + w] = 0ull;
+        corr_bits[(size_t)row * words + w] = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ed_bits_wide(ed_args a, ed_cull ca, const uint32_t* __restrict__ pending,
+                                                      const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                      uint32_t rows_cap) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t u = blockIdx.x; /* super-tile of this workgroup; wave w takes its tiles 16 w .. 16 w + 15 */
+    if (u * 64u >= ca.n_tiles || ed_stopped(a)) return;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    const float4 sb = ca.supers[u];
+    const uint32_t t = u * 64u + wave * 16u + (lane & 15u);
+    const bool have_tile = lane < 16u && t < ca.n_tiles && (ball || ((ca.tile_bits[u] >> (t & 63u)) & 1ull));
+    const float4 tbs = have_tile ? ca.tiles[t] : make_float4(0.f, 0.f, 0.f, -1.f);
+    const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
+    for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        const uint32_t hl = pending[row0 + row];
+        const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+        const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                                  ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                                  T.r22 * T.r22);
+        const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
+        const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+        f3 bc = make3(0.f, 0.f, 0.f);
+        if (ball) {
+            const float4 C = a.ball.centre_pos[slot];
+            bc = make3(C.x, C.y, C.z);
+        }
+        /* the super-tile as a whole (the same test in every lane), then one tile per lane */
+        bool shit = (ball || ca.tile_bits[u]) && sphere_hits_box(a.sc, T, rnorm, abs_eps, sb);
+        if (ball) shit = shit && !(len(make3(sb.x, sb.y, sb.z) - bc) > a.ball.radius + sb.w * 1.00001f + ball_margin);
+        if (!shit) continue;
+        bool hit = have_tile && sphere_hits_box(a.sc, T, rnorm, abs_eps, tbs);
+        if (ball) hit = hit && !(len(make3(tbs.x, tbs.y, tbs.z) - bc) > a.ball.radius + tbs.w * 1.00001f + ball_margin);
+        unsigned long long tmask = __ballot(hit);
+        const unsigned long long* member = ball ? a.ball.member + (size_t)slot * a.ball.mwords : nullptr;
+        const uint32_t* wprefix = ball ? a.ball.wprefix + (size_t)slot * a.ball.mwords : nullptr;
+        unsigned long long* tb = a.tail_bits + (size_t)row * a.words;
+        unsigned long long* cb = a.corr_bits + (size_t)row * a.words;
+        while (tmask) {
+            const uint32_t tile = u * 64u + wave * 16u + (uint32_t)__builtin_ctzll(tmask);
+            tmask &= tmask - 1ull;
+            const uint32_t sidx = tile * 64u + lane;
+            const float4 P = ca.spos[sidx];
+            if (!(P.x == P.x)) continue; /* mask_ (:434), non-finite, padding */
+            uint32_t pos;
+            if (ball) { /* position = rank of the point inside its centre's neighbourhood */
+                const uint32_t orig = __float_as_uint(P.w);
+                const unsigned long long mbits = member[orig >> 6];
+                if (!((mbits >> (orig & 63u)) & 1ull)) continue;
+                pos = wprefix[orig >> 6] + (uint32_t)__popcll(mbits & ((1ull << (orig & 63u)) - 1ull));
+            } else {
+                pos = ca.pos_of_orig[__float_as_uint(P.w)];
+                if (pos == 0xFFFFFFFFu) continue;
+            }
+            long long fx = 0;
+            uint32_t pass = 0;
+            bool tail = false;
+            const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), sidx, fx, pass, nullptr, &tail);
+            if (tail) {
+                const unsigned long long bit = 1ull << (pos & 63u);
+                atomicOr(&tb[pos >> 6], bit);
+                if (corr) atomicOr(&cb[pos >> 6], bit);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ed_score_rows(ed_args a, const uint32_t* __restrict__ limit,
+                                                       const uint32_t* __restrict__ pending,
+                                                       const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                       uint32_t rows_cap) {
+    __shared__ unsigned long long s_part[4];
+    if (ed_stopped(a)) return;
+    const uint32_t byte = blockIdx.x * 256 + threadIdx.x, w = byte >> 3; /* eight scan positions per thread */
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    const bool ball = a.ball.slot_of_hyp != nullptr;
+    for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        const uint32_t hl = pending[row0 + row];
+        const uint32_t lim = limit[a.h0 + hl];
+        long long fx = 0;
+        if (lim != 0xFFFFFFFFu && w <= (lim >> 6) && w < a.words) {
+            unsigned long long bitsw = a.corr_bits[(size_t)row * a.words + w];
+            if (w == (lim >> 6) && (lim & 63u) != 63u) bitsw &= (2ull << (lim & 63u)) - 1ull;
+            uint32_t bits8 = (uint32_t)(bitsw >> (8u * (byte & 7u))) & 0xFFu;
+            if (bits8) {
+                const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
+                const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+                while (bits8) {
+                    const uint32_t pos = byte * 8u + (uint32_t)__builtin_ctz(bits8);
+                    bits8 &= bits8 - 1u;
+                    const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
+                                              : (a.subset ? (uint32_t)a.subset[pos] : pos);
+                    const float4 P = a.opos[idx];
+                    uint32_t pass = 0;
+                    (void)eval_point(a.sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) fx += __shfl_down(fx, off);
+        if (lane == 0) s_part[wave] = (unsigned long long)fx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long sum = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            if (sum) atomicAdd(&a.sc.scores_fx[a.h0 + hl], sum);
+        }
+        __syncthreads();
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Fused variant: one workgroup does all three passes for its hypothesis with the two bit arrays in LDS
  * (LDS atomics instead of global ones, no memsets, one launch). Used whenever 2 * words * 8 bytes fit
@@ -385,6 +530,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     __shared__ unsigned long long s_fx[4];
     /* the continuation of the hypotheses the prefix kernel could not decide runs on a small grid whose
      * workgroups walk the pending list; the other launches take one hypothesis per workgroup */
+    if (ed_stopped(a)) return;
     const bool from_list = !PREFIX && pending != nullptr;
     const uint32_t n_items = from_list ? *n_pending : gridDim.x;
     const uint32_t* const tests_in = tests;
@@ -629,7 +775,8 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
 /* the fused rule in two launches: the prefix kernel (small LDS, high occupancy) decides the hypotheses that
  * drop at the first checkpoint, the full kernel continues with the rest (TM_ED_ONE_KERNEL=1: full kernel only) */
 static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t fused_lds, const ed_args& a,
-                                  const ed_cull& cu, const ed_out& o, float accept_thresh, const uint32_t* d_tests) {
+                                  const ed_cull& cu, const ed_out& o, float accept_thresh, const uint32_t* d_tests,
+                                  uint32_t rows_cap = 0) {
     if (getenv("TM_ED_ONE_KERNEL")) {
         hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh,
                            d_tests, s->oref.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -641,6 +788,26 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 0, c->stream, a, cu, o, accept_thresh, d_tests,
                        s->oref.p, s->ed_pending.p, d_n);
+    if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !getenv("TM_ED_NARROW")) {
+        /* wide continuation (ball mode: the scan order is the neighbourhood list): bits of all positions of the
+         * pending hypotheses, then the rule and the score terms on those rows; rows_cap rows of bit arrays */
+        ed_args as = a; /* k_ed_score addresses scene points by original index */
+        as.sc.sref = s->oref.p;
+        const uint32_t gw = (a.words + 255u) / 256u, gs = (cu.n_tiles + 63u) / 64u, gb = (a.words * 8u + 255u) / 256u;
+        for (uint32_t row0 = 0; row0 < n_hyp; row0 += rows_cap) {
+            const uint32_t rows = std::min(rows_cap, n_hyp - row0);
+            const uint32_t gy = std::min(rows, 128u);
+            hipLaunchKernelGGL(k_ed_zero_rows, dim3(gw, gy), dim3(256), 0, c->stream, a.tail_bits, a.corr_bits, a.words,
+                               d_n, row0, rows);
+            hipLaunchKernelGGL(k_ed_bits_wide, dim3(gs, gy), dim3(256), 0, c->stream, a, cu, s->ed_pending.p, d_n, row0,
+                               rows);
+            hipLaunchKernelGGL(k_ed_walk, dim3(rows), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests,
+                               s->ed_pending.p, d_n, row0);
+            hipLaunchKernelGGL(k_ed_score_rows, dim3(gb, gy), dim3(256), 0, c->stream, as, o.limit, s->ed_pending.p, d_n,
+                               row0, rows);
+        }
+        return hipGetLastError();
+    }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     hipLaunchKernelGGL(k_ed_fused<false>, dim3(std::min<uint32_t>(n_hyp, (uint32_t)cus * 2u)), dim3(256), fused_lds,
@@ -762,6 +929,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.words = words;
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
+    a.stop = nullptr;
     ed_out o;
     o.counts = d_counts.p;
     o.dropped_at = d_dropped.p;
@@ -840,11 +1008,32 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     return TM_OK;
 }
 
+namespace tmx {
+/* first hypothesis of [n0, n1) with a positive score and (float)count > sufficient -> *found, unless an earlier
+ * segment already has one; one workgroup */
+__global__ __launch_bounds__(1024) void k_segment_first(const uint32_t* __restrict__ counts,
+                                                        const unsigned long long* __restrict__ fx, uint32_t n0,
+                                                        uint32_t n1, float sufficient, uint32_t* found) {
+    __shared__ uint32_t s_first;
+    if (*found != 0xFFFFFFFFu) return;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t h = n0 + threadIdx.x; h < n1; h += blockDim.x)
+        if (fx[h] != 0ull && (float)counts[h] > sufficient) {
+            atomicMin(&s_first, h);
+            break;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_first != 0xFFFFFFFFu) *found = s_first;
+}
+}  // namespace tmx
+
 /* The ball mode with everything already on the device: poses at d_poses, the slot (index into uniq) of every
  * hypothesis in s->ed_slot. Leaves counts (s->w_counts), fixed-point sums (s->w_scores_fx), the drop checkpoint
  * (s->ed_dropped) and the saved evaluations (s->ed_saved) on the device, launched on the context's stream. */
 static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t n_hyp, const uint32_t* uniq,
-                        uint32_t n_slots, float radius, float dist_thres, float accept_prob) {
+                        uint32_t n_slots, float radius, float dist_thres, float accept_prob, uint32_t segment = 0,
+                        float sufficient = 0.f, uint32_t* d_found = nullptr) {
     tm_ctx* c = s->ctx;
     const uint32_t mwords = (s->n + 63) / 64;
     dbuf<uint32_t>&d_slot = s->ed_slot, &d_cent = s->ed_centres, &d_wprefix = s->ed_wprefix, &d_S = s->ed_S,
@@ -929,6 +1118,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.words = words;
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
+    a.stop = nullptr;
     ed_brick_filter(m, dist_thres * m->resolution, a.sc);
     ed_args as = a; /* k_ed_score addresses scene points by original index */
     as.sc.sref = s->oref.p;
@@ -948,9 +1138,29 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     const float accept_thresh = accept_prob * (float)m->n;
     const size_t fused_lds = 2 * (size_t)words * 8;
     const bool fused = fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
-    if (fused) {
+    if (fused && segment && d_found) {
+        /* tm_search_batch: only the first sufficient hypothesis in visit order is wanted (reference :330-338: later
+         * ones are scored without effect). The hypotheses go through in segments; after each, *d_found takes the
+         * first sufficient index of the segment, and the kernels of all later segments leave at once. */
+        a.stop = d_found;
+        for (uint32_t h0 = 0; h0 < n_hyp; h0 += segment) {
+            const uint32_t nh = std::min(segment, n_hyp - h0);
+            a.h0 = h0;
+            TM_HIP_CHECK(launch_ed_fused(s, c, nh, fused_lds, a, cu, o, accept_thresh, d_tests.p, std::min(chunk, nh)));
+            hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, h0, h0 + nh,
+                               sufficient, d_found);
+            TM_HIP_CHECK(hipGetLastError());
+        }
+    } else if (fused) {
         a.h0 = 0;
-        TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p));
+        TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p, chunk));
+        if (getenv("TM_DEBUG_ED")) { /* how many hypotheses the prefix kernel could not decide */
+            uint32_t n_pend = 0;
+            TM_HIP_CHECK(hipMemcpyAsync(&n_pend, s->ed_pending.p + n_hyp, 4, hipMemcpyDeviceToHost, c->stream));
+            TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            fprintf(stderr, "[early drop] %u hypotheses, %u slots, largest neighbourhood %u (%u words), %u pending\n", n_hyp,
+                    n_slots, S_max, words, n_pend);
+        }
     }
     for (uint32_t h0 = 0; h0 < n_hyp && !fused; h0 += chunk) {
         const uint32_t nh = std::min(chunk, n_hyp - h0);
@@ -960,6 +1170,11 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         hipLaunchKernelGGL(k_ed_bits_culled, dim3(nh), dim3(256), 0, c->stream, a, cu);
         hipLaunchKernelGGL(k_ed_walk, dim3(nh), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests.p);
         hipLaunchKernelGGL(k_ed_score, dim3((S_max + 255) / 256, nh), dim3(256), 0, c->stream, as, d_limit.p);
+        TM_HIP_CHECK(hipGetLastError());
+    }
+    if (d_found && !(fused && segment)) { /* no segments were used: the one look over the whole batch */
+        hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, 0u, n_hyp, sufficient,
+                           d_found);
         TM_HIP_CHECK(hipGetLastError());
     }
     return TM_OK;
@@ -1029,12 +1244,13 @@ __global__ void k_batch_slots(const uint4* __restrict__ prov, uint32_t n_hyp, co
 __global__ void __launch_bounds__(1024)
 k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ fx,
                    const double* __restrict__ scores, const int32_t* __restrict__ dropped, uint32_t n_hyp,
-                   float sufficient, double n_model, const float* __restrict__ poses, tm_batch_result* out) {
+                   float sufficient, double n_model, const float* __restrict__ poses, tm_batch_result* out,
+                   const uint32_t* __restrict__ found = nullptr) {
     __shared__ uint32_t s_first;
-    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_first = found ? *found : 0xFFFFFFFFu; /* found: the segments have already looked */
     __syncthreads();
     uint32_t first = 0xFFFFFFFFu;
-    for (uint32_t h = threadIdx.x; h < n_hyp; h += blockDim.x) {
+    for (uint32_t h = threadIdx.x; h < (found ? 0u : n_hyp); h += blockDim.x) {
         const bool positive = fx ? fx[h] != 0ull : scores[h] > 0.0;
         if (positive && (float)counts[h] > sufficient) {
             first = h;
@@ -1112,11 +1328,20 @@ extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pair
         hipLaunchKernelGGL(k_batch_slots, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
                            s->sb_pair_slot.p, s->ed_slot.p);
         TM_HIP_CHECK(hipGetLastError());
+        /* segments of 2048 hypotheses (one resident round of the prefix kernel); TM_SEARCH_SEGMENT=0: all at once */
+        const char* seg_env = getenv("TM_SEARCH_SEGMENT");
+        const uint32_t segment = seg_env ? (uint32_t)atoi(seg_env) : 2048u;
+        uint32_t* d_found = nullptr;
+        if (segment) {
+            TM_FORWARD(s->sb_centres.ensure(1)); /* unused by this branch otherwise: holds the found index */
+            d_found = s->sb_centres.p;
+            TM_HIP_CHECK(hipMemsetAsync(d_found, 0xFF, 4, c->stream));
+        }
         TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
-                                accept_prob));
+                                accept_prob, segment, sufficient, d_found));
         hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
                            (const double*)nullptr, s->ed_dropped.p, n_hyp, sufficient, (double)m->n, s->w_poses.p,
-                           s->sb_result.p);
+                           s->sb_result.p, (const uint32_t*)d_found);
     } else {
         /* centre of a hypothesis = first point of its pair: the pairs' first words, indexed through the slots */
         TM_FORWARD(s->sb_centres.ensure(n_hyp));
