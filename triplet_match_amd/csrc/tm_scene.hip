@@ -455,14 +455,29 @@ __device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
     return v;
 }
 
-/* pose as staged in LDS: three float4 = the rotation columns with the translation in the w components */
+/* pose as staged in LDS: three float4 laid out for two-wide arithmetic on (x, y):
+ *   A = (r00, r10, r01, r11)   B = (r02, r12, tx, ty)   C = (r20, r21, r22, tz)
+ * so that T*p = ((A.xy * px + A.zw * py) + B.xy * pz) + B.zw for (x, y) — register pairs straight from the
+ * 16-byte reads, v_pk_mul_f32 / v_pk_add_f32 without operand shuffling — and the dot of C with (p, 1) for z.
+ * Same operations in the same association as xform_point / xform_dir (tm_math.h). */
+typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pose12 lds_pose(const float4* p) {
-    const float4 c0 = p[0], c1 = p[1], c2 = p[2];
+    const float4 A = p[0], B = p[1], C = p[2];
     pose12 T;
-    T.r00 = c0.x; T.r10 = c0.y; T.r20 = c0.z; T.tx = c0.w;
-    T.r01 = c1.x; T.r11 = c1.y; T.r21 = c1.z; T.ty = c1.w;
-    T.r02 = c2.x; T.r12 = c2.y; T.r22 = c2.z; T.tz = c2.w;
+    T.r00 = A.x; T.r10 = A.y; T.r01 = A.z; T.r11 = A.w;
+    T.r02 = B.x; T.r12 = B.y; T.tx = B.z; T.ty = B.w;
+    T.r20 = C.x; T.r21 = C.y; T.r22 = C.z; T.tz = C.w;
     return T;
+}
+__device__ __forceinline__ f3 lds_xform_point(const float4 A, const float4 B, const float4 C, float px, float py, float pz) {
+    const f2v a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y}, b23 = {B.z, B.w};
+    const f2v xy = ((a01 * px + a23 * py) + b01 * pz) + b23;
+    return make3(xy.x, xy.y, ((C.x * px + C.y * py) + C.z * pz) + C.w);
+}
+__device__ __forceinline__ f3 lds_xform_dir(const float4 A, const float4 B, const float4 C, float px, float py, float pz) {
+    const f2v a01 = {A.x, A.y}, a23 = {A.z, A.w}, b01 = {B.x, B.y};
+    const f2v xy = (a01 * px + a23 * py) + b01 * pz;
+    return make3(xy.x, xy.y, (C.x * px + C.y * py) + C.z * pz);
 }
 
 template <bool L2, int NC, int G>
@@ -523,15 +538,16 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             __builtin_amdgcn_wave_barrier();
             const float4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + lane], v3 = src[192 + lane],
                          v4 = src[256 + lane], v5 = src[320 + lane];
-            /* float4 f of the pose block = column f % 3 of pose f / 3, its w replaced by the translation
-             * component; G * 3 of them, 64 per round */
+            /* float4 f of the pose block = part f % 3 (A, B, C of lds_pose) of pose f / 3; G * 3 of them, 64 per round */
             float4 pv[(G * 3 + 63) / 64];
 #pragma unroll
             for (int r = 0; r < (G * 3 + 63) / 64; ++r) {
                 const uint32_t f = min(64u * r + lane, (uint32_t)G * 3u - 1u);
                 const uint32_t hp = min(group * G + f / 3u, a.n_hyp - 1u), pc = f % 3u;
-                pv[r] = reinterpret_cast<const float4*>(a.poses)[(size_t)hp * 4 + pc];
-                pv[r].w = a.poses[(size_t)hp * 16 + 12u + pc];
+                /* A, B, C of lds_pose from the column-major 4x4 */
+                const float* mp = a.poses + (size_t)hp * 16;
+                pv[r] = make_float4(mp[pc == 0u ? 0 : pc == 1u ? 8 : 2], mp[pc == 0u ? 1 : pc == 1u ? 9 : 6],
+                                    mp[pc == 0u ? 4 : pc == 1u ? 12 : 10], mp[pc == 0u ? 5 : pc == 1u ? 13 : 14]);
             }
             const float2 ax = ga.aux[min(group * G + (lane % (uint32_t)G), a.n_hyp - 1u)];
             float4* dst = reinterpret_cast<float4*>(pts);
@@ -634,10 +650,11 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const pose12 T = lds_pose(poses + 3u * gk[k]);
+                const float4* pp = poses + 3u * gk[k];
                 const float* sp = pts + 3u * pidx[k];
-                q[k] = xform_point(T, make3(sp[0], sp[1], sp[2]));
-                float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
+                q[k] = lds_xform_point(pp[0], pp[1], pp[2], sp[0], sp[1], sp[2]);
+                const f2v vxy = f2v{a.g.sx, a.g.sy} * f2v{q[k].x, q[k].y} + f2v{a.g.tx, a.g.ty};
+                const float vx = vxy.x, vy = vxy.y, vz = a.g.sz * q[k].z + a.g.tz;
                 in[k] = in[k] & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
                         (vz < a.g.fez);
                 uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
@@ -693,8 +710,8 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                         if (ok[k0 + j]) {
                             ++pass;
                             if (sr[j].w == mr[j].w) {
-                                const pose12 T = lds_pose(poses + 3u * gk[k0 + j]);
-                                f3 r = xform_dir(T, make3(sr[j].x, sr[j].y, sr[j].z));
+                                const float4* pp = poses + 3u * gk[k0 + j];
+                                f3 r = lds_xform_dir(pp[0], pp[1], pp[2], sr[j].x, sr[j].y, sr[j].z);
                                 float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
                                 const unsigned long long t = (unsigned long long)(long long)((double)term * kFx);
                                 w_lo = (uint32_t)(t & 0xFFFFFull) | (1u << 24);
