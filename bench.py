@@ -233,8 +233,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 # a fraction above 1 means the 40-B price over-charges evaluations that stop at the in-grid
                 # test; such a figure is not evidence, so the physical model takes its place
-                "frac": round(frac_formula if frac_formula <= 1.0 else achieved_phys / HBM_PEAK_GBS, 4),
-                "frac_basis": "baseline_formula_40E+32P+64H" if frac_formula <= 1.0 else "physical_model",
+                "frac": None, "frac_basis": None,
                 "traffic": traffic,
                 "kernel": "k_score", "kernel_ms": round(k_ms, 4), "evaluations_per_launch": E,
                 "in_grid_per_launch": N_in, "near_per_launch": N_near, "staged_chunks_per_launch": N_items,
@@ -243,6 +242,17 @@ def main():
                 "achieved_physical": round(achieved_phys, 1),
                 "frac_physical": round(achieved_phys / HBM_PEAK_GBS, 4),
                 "measured_copy_GBs": copy_gbs}
+    frac_phys = achieved_phys / HBM_PEAK_GBS
+    frac_meas = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pmc else None
+    # the first byte model that stays below the peak: BASELINE's formula, the requested bytes, the measured
+    # L2->fabric bytes; a model above the peak prices bytes that came out of LDS / L1 / L2 and is not evidence
+    for f, basis in ((frac_formula, "baseline_formula_40E+32P+64H"), (frac_phys, "physical_model"),
+                     (frac_meas, "measured_l2_fabric_bytes")):
+        if f is not None and f <= 1.0:
+            roofline["frac"], roofline["frac_basis"] = round(f, 4), basis
+            break
+    else:
+        roofline["frac_basis"] = "none: every byte model exceeds the HBM peak"
     if pmc:  # counters of the profiled build (same sources: the hash is checked), scaled by this run's time
         roofline["frac_measured_hbm"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         roofline["pmc"] = {k: pmc[k] for k in ("source", "l2_fabric_read_requests", "l2_fabric_read_128B",

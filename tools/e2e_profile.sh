@@ -21,5 +21,5 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_HIT_sum TCC_MISS_sum" "
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- /tmp/e2e_demo /tmp/c2.bin $ed 10 > $out/pass$i.txt 2>&1 || echo "pass $i failed" >> $out/progress.log
 done
-python3 tools/pmc_summary.py $out | grep -A16 "k_ed_fused" > $out/k_ed_fused_pmc.txt || true
+python3 tools/pmc_summary.py $out | grep -A16 -E "k_ed_fused|k_ed_bits_wide|k_ed_score_rows" > $out/k_ed_fused_pmc.txt || true
 cat $out/k_ed_fused_pmc.txt

@@ -1152,8 +1152,12 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
             TM_HIP_CHECK(hipGetLastError());
         }
     } else if (fused) {
+        /* the whole batch at once: with ~2 % of 65,536 hypotheses pending the wide continuation has over a
+         * thousand rows and loses to one workgroup per pending hypothesis (21.4 against 18.0 ms per batch); it
+         * pays for the few rows of a segment (end-to-end search 0.030 against 0.034 s) */
         a.h0 = 0;
-        TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p, chunk));
+        TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p,
+                                     n_hyp <= 4096u || getenv("TM_ED_WIDE") ? chunk : 0u));
         if (getenv("TM_DEBUG_ED")) { /* how many hypotheses the prefix kernel could not decide */
             uint32_t n_pend = 0;
             TM_HIP_CHECK(hipMemcpyAsync(&n_pend, s->ed_pending.p + n_hyp, 4, hipMemcpyDeviceToHost, c->stream));
