@@ -286,6 +286,17 @@ int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pos
 int tm_icp_accumulate(tm_scene* scene, tm_model* model, const float pose16[16], float dist_thres,
                       uint32_t* count, long long sums15[15]);
 
+/* icp_ (include/impl/scene.hpp:369-400) as one call: starting from pose16, repeat { rigid fit of the current
+ * correspondences (Eigen::umeyama without scale, :393) -> correspondences of the fitted pose } while their number
+ * does not decrease (:396), at most max_iterations times; every pass, fit and test runs on the device, one
+ * read-back at the end. out_pose16 / out_count = the last accepted pose and its number of correspondences
+ * (= pose16 and its count when nothing was accepted); the caller extracts the correspondences
+ * (tm_extract_correspondences). Same poses as a host loop over tm_icp_accumulate + tm_rigid_fit. */
+int tm_icp_refine(tm_scene* scene, tm_model* model, const float pose16[16], float dist_thres,
+                  uint32_t max_iterations, float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations);
+/* The rigid fit itself, on the host: Horn's closed form on the sums of tm_icp_accumulate (count >= 3) */
+int tm_rigid_fit(const long long sums15[15], uint32_t count, float pose16[16]);
+
 /* ---- best-hypothesis record and its reduction (new functionality) ---- */
 typedef struct tm_best_record {
     uint32_t inlier_count;

@@ -180,6 +180,14 @@ struct hip_backend {
         out.scene_corrs.assign(sc_scratch.begin(), sc_scratch.begin() + count);
         out.model_corrs.assign(mc_scratch.begin(), mc_scratch.begin() + count);
     }
+    /* the whole ICP loop on the device (tm_icp_refine); TM_ICP_HOST_LOOP=1: one call per pass, fits on the host */
+    bool supports_icp_refine() const { return getenv("TM_ICP_HOST_LOOP") == nullptr; }
+    search::pose_t icp_refine(const search::pose_t& T, float dist_thres, uint32_t max_iterations) {
+        search::pose_t out;
+        uint32_t n = 0, it = 0;
+        check(tm_icp_refine(s, m, T.m, dist_thres, max_iterations, out.m, &n, &it), "tm_icp_refine");
+        return out;
+    }
     search::detail::icp_sums_t icp_sums(const search::pose_t& T, float dist_thres) {
         search::detail::icp_sums_t r;
         check(tm_icp_accumulate(s, m, T.m, dist_thres, &r.n, r.v), "tm_icp_accumulate");

@@ -244,6 +244,24 @@ inline bool fused_batch(B&, const std::vector<uint32_t>&, float, bool, float, po
     return false;
 }
 
+/* does the backend run the whole ICP loop itself? (hip_backend: tm_icp_refine) */
+template <class B, class = void>
+struct has_icp_refine : std::false_type {};
+template <class B>
+struct has_icp_refine<B, decltype(void(std::declval<B&>().icp_refine(std::declval<const pose_t&>(), 0.f, 0u)))>
+    : std::true_type {};
+template <class B>
+inline bool device_icp(B& be, const pose_t& start, float dist_thres, uint32_t max_iterations, pose_t& out,
+                       std::true_type) {
+    if (!be.supports_icp_refine()) return false;
+    out = be.icp_refine(start, dist_thres, max_iterations);
+    return true;
+}
+template <class B>
+inline bool device_icp(B&, const pose_t&, float, uint32_t, pose_t&, std::false_type) {
+    return false;
+}
+
 }  // namespace detail
 
 /* find_in_subset, include/impl/scene.hpp:242-367 */
@@ -404,6 +422,14 @@ inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p)
     TM_TIMED(icp);
     const float dt2 = 2.f * p.dist_thres;
     pose_t best_t = match.transform;
+    {
+        pose_t refined;
+        if (detail::device_icp(be, best_t, dt2, p.max_icp_iterations, refined, detail::has_icp_refine<Backend>{})) {
+            candidate_t out;
+            be.extract(refined, dt2, out);
+            return out;
+        }
+    }
     detail::icp_sums_t best = be.icp_sums(best_t, dt2);
     uint32_t iter = 0;
     for (;;) {

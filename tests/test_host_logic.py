@@ -107,3 +107,76 @@ def test_icp_accumulate_sums_and_pose(gpu_ctx, gpu_small, small_case, tmp_path):
         got = _rigid_fit(tmp_path, [(scene[sc, 0:3], model[mc, 0:3])])[0]
         ref = mod.umeyama_noscale(scene[sc, 0:3], model[mc, 0:3])
         assert np.abs(got - ref).max() <= 1e-6
+
+
+def _sums(s, m):
+    """the 15 fixed-point sums of tm_icp_accumulate formed with numpy integers"""
+    s, m = np.asarray(s, np.float32).astype(np.float64), np.asarray(m, np.float32).astype(np.float64)
+    S = 4294967296.0
+    v = np.zeros(15, np.int64)
+    v[0:3] = np.trunc(s * S).astype(np.int64).sum(0)
+    v[3:6] = np.trunc(m * S).astype(np.int64).sum(0)
+    for a in range(3):
+        for b in range(3):
+            v[6 + 3 * a + b] = np.trunc((s[:, a] * m[:, b]) * S).astype(np.int64).sum()
+    return v
+
+
+def test_library_rigid_fit_equals_search_hpp_and_golden(tmp_path):
+    """tm_rigid_fit (csrc/tm_icp_math.h: what the device-side ICP loop runs, here on the host) gives bit for bit
+    the pose of search::detail::rigid_fit on the same correspondences, and both match the numpy SVD golden."""
+    from triplet_match_amd import capi
+    g = np.load(GOLDEN)
+    sets = [(g["scene"][i, :g["count"][i]], g["model"][i, :g["count"][i]]) for i in range(len(g["count"]))]
+    hpp = _rigid_fit(tmp_path, sets)
+    for (s, m), T_hpp, want, name in zip(sets, hpp, g["transform"], g["names"]):
+        T = capi.rigid_fit(_sums(s, m), len(s)).reshape(4, 4).T.astype(np.float64)
+        assert np.array_equal(T, T_hpp), name
+        assert np.abs(T - want).max() <= 1e-6, name
+    with pytest.raises(capi.TmError):
+        capi.rigid_fit(np.zeros(15, np.int64), 2)
+
+
+@pytest.mark.gpu
+def test_icp_refine_on_the_device_equals_the_host_loop(gpu_ctx, gpu_small, small_case):
+    """tm_icp_refine (passes, fits and the stop test on the device) == the loop of icp_ (reference
+    include/impl/scene.hpp:376-400) driven from the host over tm_icp_accumulate + tm_rigid_fit: same pose bits,
+    same number of correspondences and iterations, for several starting poses and iteration limits."""
+    from triplet_match_amd import capi, synth
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_icp_golden", os.path.join(ROOT, "tests", "golden",
+                                                                                  "make_icp_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gm, gs = gpu_small["model"], gpu_small["scene"]
+    rng = np.random.default_rng(19)
+    dt2 = 6.0
+    moved = 0
+    for k, T in enumerate(small_case["scene"]["poses_scene_to_model"]):
+        for trial, (angle, shift) in enumerate([(0.01, 0.5), (0.03, 1.5), (0.0, 0.0), (1.0, 50.0)]):
+            dR = mod.rot(rng.normal(size=3), angle)
+            P = np.eye(4)
+            P[:3, :3] = dR @ T[:3, :3]
+            P[:3, 3] = dR @ T[:3, 3] + rng.normal(size=3) * shift * small_case["resolution"]
+            start = synth.pose_colmajor(P).astype(np.float32)
+            for max_it in (0, 1, 3, 10):
+                # host loop
+                best_t = start.copy()
+                best_n, best = gs.icp_accumulate(gm, best_t, dt2)
+                it = 0
+                while max_it > 0:
+                    if best_n < 3:
+                        break
+                    trans = capi.rigid_fit(best, best_n)
+                    n, sums = gs.icp_accumulate(gm, trans, dt2)
+                    if n < best_n:
+                        break
+                    best_n, best, best_t = n, sums, trans
+                    it += 1
+                    if it == max_it:
+                        break
+                pose, cnt, iters = gs.icp_refine(gm, start, dt2, max_it)
+                assert cnt == best_n and iters == it, (k, trial, max_it)
+                assert np.array_equal(pose.view(np.uint32), np.asarray(best_t, np.float32).view(np.uint32)), (k, trial, max_it)
+                moved += int(it > 0)
+    assert moved >= 6

@@ -112,6 +112,8 @@ SIGNATURES = {
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
+    "tm_icp_refine": (C.c_int, [vp, vp, f32p, C.c_float, C.c_uint32, f32p, u32p, u32p]),
+    "tm_rigid_fit": (C.c_int, [C.POINTER(C.c_longlong), C.c_uint32, f32p]),
     "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(BestRecord)]),
     "tm_scene_live_count": (C.c_uint64, [vp]),
@@ -708,6 +710,15 @@ class Scene:
                                      1 if early_drop else 0, sufficient, C.byref(r)))
         return r.index, r.n_hypotheses, r.count, r.dropped_at, r.score, np.array(r.pose, np.float32)
 
+    def icp_refine(self, model, pose16, dist_thres, max_iterations):
+        """icp_ on the device: (pose16, count, iterations)"""
+        T, pT = _f(pose16)
+        out = np.zeros(16, np.float32)
+        cnt, it = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().tm_icp_refine(self.h, model.h, pT, dist_thres, max_iterations, out.ctypes.data_as(f32p),
+                                   C.byref(cnt), C.byref(it)))
+        return out, cnt.value, it.value
+
     def icp_accumulate(self, model, pose16, dist_thres):
         T, pT = _f(pose16)
         cnt = C.c_uint32(0)
@@ -774,3 +785,11 @@ def traits_intrinsic_distance(kind, state, p0, p1):
     a, pa = _f(p0)
     b, pb = _f(p1)
     return float(lib().tm_traits_intrinsic_distance(kind, ps, pa, pb))
+
+
+def rigid_fit(sums15, count):
+    """tm_rigid_fit: the ICP loop's rigid fit (Horn) from the 15 fixed-point sums, on the host"""
+    v = np.ascontiguousarray(sums15, dtype=np.int64)
+    out = np.zeros(16, np.float32)
+    _check(lib().tm_rigid_fit(v.ctypes.data_as(C.POINTER(C.c_longlong)), int(count), out.ctypes.data_as(f32p)))
+    return out

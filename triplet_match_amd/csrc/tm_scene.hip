@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "tm_internal.h"
+#include "tm_icp_math.h"
 #include "tm_table.h"
 #include "tm_score.h"
 
@@ -837,8 +838,10 @@ __global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
 constexpr int kIcpBlocks = 512;
 
 __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n_pad,
-                                                        unsigned long long* __restrict__ partials /* [grid][16] */) {
+                                                        unsigned long long* __restrict__ partials /* [grid][16] */,
+                                                        const uint32_t* __restrict__ done = nullptr) {
     __shared__ long long s_acc[4][16];
+    if (done && *done) return; /* tm_icp_refine: the loop has ended */
     long long acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0;
@@ -877,9 +880,50 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n
             s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
 }
 
+/* One turn of icp_ (reference include/impl/scene.hpp:376-400) on the device, a single thread: `sums` holds the
+ * correlation sums of the pose in `pose` (the initial one when first, else the last fit). State: best sums /
+ * count / pose, iteration count, done flag. When the loop goes on, the next fit is written to `pose`. */
+struct icp_state {
+    unsigned long long best_sums[16]; /* [15] = count */
+    float best_t[16];
+    uint32_t iter, done;
+};
+__device__ void icp_step(const unsigned long long* sums, float* pose, icp_state* st, uint32_t max_iterations, bool first) {
+    if (first) {
+        st->iter = 0;
+        st->done = 0;
+    } else {
+        if (st->done) return;
+        if ((uint32_t)sums[15] < (uint32_t)st->best_sums[15]) { /* :396: fewer correspondences than before */
+            st->done = 1;
+            return;
+        }
+    }
+    for (int k = 0; k < 16; ++k) st->best_sums[k] = sums[k];
+    for (int k = 0; k < 16; ++k) st->best_t[k] = pose[k];
+    if (!first && ++st->iter == max_iterations) {
+        st->done = 1;
+        return;
+    }
+    if ((uint32_t)sums[15] < 3u || max_iterations == 0u) { /* :381 */
+        st->done = 1;
+        return;
+    }
+    long long v[15];
+    for (int k = 0; k < 15; ++k) v[k] = (long long)sums[k];
+    float T[16];
+    rigid_fit_sums(v, (uint32_t)sums[15], T); /* :385-393 */
+    for (int k = 0; k < 16; ++k) pose[k] = T[k];
+}
+
+/* st != null (tm_icp_refine): thread 0 goes on with the turn of the loop these sums belong to */
 __global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
-                                                      unsigned long long* __restrict__ sums /* 16 */) {
+                                                      unsigned long long* __restrict__ sums /* 16 */,
+                                                      const uint32_t* __restrict__ done = nullptr,
+                                                      float* pose = nullptr, icp_state* st = nullptr,
+                                                      uint32_t max_iterations = 0, int first = 0) {
     __shared__ unsigned long long s_part[16][16];
+    if (done && *done) return;
     const uint32_t k = threadIdx.x & 15, slice = threadIdx.x >> 4; /* 16 slices of the block list */
     unsigned long long t = 0;
     for (uint32_t b = slice; b < n_blocks; b += 16) t += partials[(size_t)b * 16 + k];
@@ -889,6 +933,11 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* 
         unsigned long long r = 0;
         for (int sl = 0; sl < 16; ++sl) r += s_part[sl][threadIdx.x];
         sums[threadIdx.x] = r;
+    }
+    if (st) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) icp_step(sums, pose, st, max_iterations, first != 0);
     }
 }
 
@@ -1793,19 +1842,7 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     return TM_OK;
 }
 
-int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t* count,
-                      long long sums15[15]) {
-    TM_FORWARD(check_pair(s, m));
-    TM_REQUIRE(pose16 && count && sums15, TM_ERR_INVALID, "tm_icp_accumulate: null argument");
-    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
-    tm_ctx* c = s->ctx;
-    TM_HIP_CHECK(hipSetDevice(c->device));
-    TM_FORWARD(s->w_poses.ensure(16));
-    TM_FORWARD(s->w_counts.ensure(1));
-    const uint32_t icp_blocks = std::min<uint32_t>((uint32_t)kIcpBlocks, s->n_sorted / 256);
-    TM_FORWARD(s->w_scores_fx.ensure(16 + (size_t)kIcpBlocks * 16));
-    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
-    score_args a;
+static void icp_score_args(const tm_scene* s, const tm_model* m, float dist_thres, score_args& a) {
     a.spos = s->spos.p;
     a.spos3 = s->spos3.p;
     a.sref = s->sref.p;
@@ -1830,6 +1867,22 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     a.code_max = 255u;
+}
+
+int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t* count,
+                      long long sums15[15]) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(pose16 && count && sums15, TM_ERR_INVALID, "tm_icp_accumulate: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure(16));
+    TM_FORWARD(s->w_counts.ensure(1));
+    const uint32_t icp_blocks = std::min<uint32_t>((uint32_t)kIcpBlocks, s->n_sorted / 256);
+    TM_FORWARD(s->w_scores_fx.ensure(16 + (size_t)kIcpBlocks * 16));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
+    score_args a;
+    icp_score_args(s, m, dist_thres, a);
     hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_scores_fx.p + 16);
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
@@ -1840,6 +1893,51 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     *count = (uint32_t)h_sums[15];
     for (int k = 0; k < 15; ++k) sums15[k] = (long long)h_sums[k];
+    return TM_OK;
+}
+
+/* icp_ as one call (reference include/impl/scene.hpp:369-400 without the final finish_find): the passes, the
+ * rigid fits and the "stop when the correspondences get fewer" test all run on the device, queued up front; one
+ * 80-byte read-back at the end. Same poses as the host loop over tm_icp_accumulate + search::detail::rigid_fit. */
+int tm_icp_refine(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t max_iterations,
+                  float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations) {
+    TM_FORWARD(check_pair(s, m));
+    TM_REQUIRE(pose16 && out_pose16 && out_count, TM_ERR_INVALID, "tm_icp_refine: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure(16));
+    TM_FORWARD(s->w_counts.ensure(1));
+    const uint32_t icp_blocks = std::min<uint32_t>((uint32_t)kIcpBlocks, s->n_sorted / 256);
+    const size_t state_words = (sizeof(icp_state) + 7) / 8;
+    TM_FORWARD(s->w_scores_fx.ensure(16 + (size_t)kIcpBlocks * 16 + state_words));
+    icp_state* st = reinterpret_cast<icp_state*>(s->w_scores_fx.p + 16 + (size_t)kIcpBlocks * 16);
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
+    score_args a;
+    icp_score_args(s, m, dist_thres, a);
+    unsigned long long* sums = s->w_scores_fx.p;
+    unsigned long long* partials = s->w_scores_fx.p + 16;
+    for (uint32_t pass = 0; pass <= max_iterations; ++pass) {
+        const uint32_t* done = pass ? &st->done : nullptr;
+        hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted, partials, done);
+        hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, partials, icp_blocks, sums, done,
+                           s->w_poses.p, st, max_iterations, pass == 0 ? 1 : 0);
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    icp_state h;
+    TM_HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 16; ++k) out_pose16[k] = h.best_t[k];
+    *out_count = (uint32_t)h.best_sums[15];
+    if (out_iterations) *out_iterations = h.iter;
+    return TM_OK;
+}
+
+/* the rigid fit of the ICP loop on the host (the same function the device loop runs) */
+int tm_rigid_fit(const long long sums15[15], uint32_t count, float pose16[16]) {
+    TM_REQUIRE(sums15 && pose16, TM_ERR_INVALID, "tm_rigid_fit: null argument");
+    TM_REQUIRE(count >= 3, TM_ERR_INVALID, "tm_rigid_fit: fewer than three correspondences");
+    rigid_fit_sums(sums15, count, pose16);
     return TM_OK;
 }
 
