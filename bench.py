@@ -230,7 +230,8 @@ def main():
     traffic = pmc["hbm_bytes_per_launch"] if pmc else None
     copy_gbs = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
     frac_formula = achieved / HBM_PEAK_GBS
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "achieved_formula": round(achieved, 1), "frac_formula": round(frac_formula, 4),
                 # a fraction above 1 means the 40-B price over-charges evaluations that stop at the in-grid
                 # test; such a figure is not evidence, so the physical model takes its place
                 "frac": None, "frac_basis": None,
@@ -248,8 +249,8 @@ def main():
     # L2->fabric bytes; a model above the peak prices bytes that came out of LDS / L1 / L2 and is not evidence
     for f, basis in ((frac_formula, "baseline_formula_40E+32P+64H"), (frac_phys, "physical_model"),
                      (frac_meas, "measured_l2_fabric_bytes")):
-        if f is not None and f <= 1.0:
-            roofline["frac"], roofline["frac_basis"] = round(f, 4), basis
+        if f is not None and f <= 1.0:  # achieved = the GB/s of that model, so that frac = achieved / peak
+            roofline["achieved"], roofline["frac"], roofline["frac_basis"] = round(f * HBM_PEAK_GBS, 1), round(f, 4), basis
             break
     else:
         roofline["frac_basis"] = "none: every byte model exceeds the HBM peak"
