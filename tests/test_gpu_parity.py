@@ -875,6 +875,31 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
         finally:
             gs.set_mask(None)
     assert hits >= 12
+    # the other routes through the early-drop rule give the same record (segment sizes, no segments, the
+    # three-kernel rule, one workgroup per pending hypothesis, no prefix kernel)
+    poses, prov, _ = gs.generate_hypotheses(gm, pairs)
+    centers = pairs[prov[:, 0], 0].astype(np.uint32)
+    c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
+    order = np.sort(c[sc > 0])
+    for env in ({"TM_SEARCH_SEGMENT": "0"}, {"TM_SEARCH_SEGMENT": "300"}, {"TM_ED_UNFUSED": "1"}, {"TM_ED_NARROW": "1"},
+                {"TM_ED_ONE_KERNEL": "1"}, {"TM_ED_WIDE": "1", "TM_SEARCH_SEGMENT": "0"}):
+        old_env = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            for sufficient in (float(np.median(order)), float(order[-2]), float(order[-1])):
+                ok = np.nonzero((sc > 0) & (c.astype(np.float32) > np.float32(sufficient)))[0]
+                want = int(ok[0]) if len(ok) else -1
+                idx, n_hyp, cnt, dropped, score, pose = gs.search_batch(gm, pairs, diam, DT, 0.5, True, sufficient,
+                                                                        min_diameter_factor=0.2)
+                assert idx == want and n_hyp == len(poses), (env, sufficient)
+                if want >= 0:
+                    assert cnt == c[want] and score == sc[want] and dropped == dr[want], (env, sufficient)
+        finally:
+            for k, v in old_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     # degenerate batches
     assert gs.search_batch(gm, np.zeros((0, 2), np.uint32), diam, DT, 0.5, True, 0.0)[0] == -1
     with pytest.raises(capi.TmError):
