@@ -51,10 +51,8 @@ struct hip_backend {
         upcoming = firsts;
         cache_lo = cache_hi = 0;
     }
-    void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
-        size_t k = cache_lo;
-        while (k < cache_hi && upcoming[k] != i) ++k;
-        if (k >= cache_hi || cache_radius != radius) { /* not cached: fetch i and the firsts that follow it */
+    void fetch_lists(uint32_t i, float radius) { /* i and the announced firsts that follow it */
+        {
             size_t pos = 0;
             while (pos < upcoming.size() && upcoming[pos] != i) ++pos;
             std::vector<uint32_t> batch;
@@ -85,10 +83,28 @@ struct hip_backend {
                 check(rc, "tm_scene_radius_lists");
                 break;
             }
+        }
+    }
+    void radius_subset(uint32_t i, float radius, std::vector<int32_t>& out) {
+        size_t k = cache_lo;
+        while (k < cache_hi && upcoming[k] != i) ++k;
+        if (k >= cache_hi || cache_radius != radius) { /* not cached */
+            fetch_lists(i, radius);
             k = cache_lo;
         }
         const int32_t* src = list_cache.data() + (k - cache_lo) * cache_stride;
         out.assign(src, src + count_cache[k - cache_lo]);
+    }
+    /* the same list in place: valid until the next radius_subset / radius_view call */
+    void radius_view(uint32_t i, float radius, const int32_t*& ptr, size_t& n) {
+        size_t k = cache_lo;
+        while (k < cache_hi && upcoming[k] != i) ++k;
+        if (k >= cache_hi || cache_radius != radius) {
+            fetch_lists(i, radius);
+            k = cache_lo;
+        }
+        ptr = list_cache.data() + (k - cache_lo) * cache_stride;
+        n = count_cache[k - cache_lo];
     }
     void generate(const std::vector<uint32_t>& ij, std::vector<search::pose_t>& poses) {
         const uint32_t n_pairs = (uint32_t)(ij.size() / 2);
