@@ -363,6 +363,11 @@ int tm_traits_project_cloud(tm_ctx* ctx, int kind, const float* state, const flo
  * include/impl/plane2_traits.hpp:70-84): one pass over the cloud in HBM, then the identity kernels run
  * on the result with the model's metric (tm_model_set_metric). */
 int tm_scene_create_projected(tm_scene* src, int traits_kind, const float* state, tm_scene** out);
+/* The two counts a caller rejects a projector candidate by, without building its scene: the points that project
+ * and are not masked (= tm_scene_live_count of what tm_scene_create_projected would return) and the tangent
+ * points among them with abs(w) <= band (band < 0: all of them). One pass over the resident scene. */
+int tm_scene_probe_projected(tm_scene* scene, int traits_kind, const float* state, float band, uint64_t* live,
+                             uint32_t* tangent_on_surface);
 /* points of the scene that take part in scoring: finite (for a projected scene: project() did not return
  * nullopt) and not masked */
 uint64_t tm_scene_live_count(const tm_scene* scene);

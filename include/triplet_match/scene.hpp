@@ -7,6 +7,7 @@
 #ifndef TRIPLET_MATCH_SCENE_HPP_
 #define TRIPLET_MATCH_SCENE_HPP_
 
+#include <chrono>
 #include <cstdlib>
 
 #include "model.hpp"
@@ -383,7 +384,18 @@ public:
                 !(std::fabs(handle->radius - pm.handle()->radius) <= ps.radius_tolerance * pm.handle()->radius))
                 continue;
             tm_scene* proj = nullptr;
+            const auto t_p0 = std::chrono::steady_clock::now();
             detail::check(tm_scene_set_mask(h_, mask.data()), "tm_scene_set_mask");
+            {   /* the two rejections below, counted on the device before anything is built or downloaded */
+                const float band = !(ps.on_surface_samples && pm.handle()->threshold > 0.f) ? -1.f
+                                   : Traits::kind == TM_TRAITS_CYLINDER && pm.handle()->radius > 0.f
+                                       ? pm.handle()->threshold / pm.handle()->radius
+                                       : pm.handle()->threshold;
+                uint64_t live = 0;
+                uint32_t n_tan = 0;
+                detail::check(tm_scene_probe_projected(h_, Traits::kind, st, band, &live, &n_tan), "tm_scene_probe_projected");
+                if ((float)live < model_match_factor * (float)n_model || n_tan < min_tangent) continue;
+            }
             detail::check(tm_scene_create_projected(h_, Traits::kind, st, &proj), "tm_scene_create_projected");
             struct guard {
                 tm_scene* s;
@@ -408,6 +420,7 @@ public:
                 if (n_tan < min_tangent) continue;
             }
             ++searches;
+            const auto t_p1 = std::chrono::steady_clock::now();
             detail::hip_backend<Point> be;
             be.s = proj;
             be.m = um.handle();
@@ -426,9 +439,17 @@ public:
                 search::single_rank one;
                 found = search::find_all(be, tmask, be.p, one, &mask);
             }
-            if (ps.verbose)
-                fprintf(stderr, "[projected search] draw %u: projector searched (%llu points project), %zu match(es)\n", draw,
-                        (unsigned long long)tm_scene_live_count(proj), found.size());
+            if (ps.verbose) {
+                const auto t_p2 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[projected search] draw %u: projector searched (%llu points project), %zu match(es); "
+                                "project + download %.1f ms, search %.1f ms (radius %.1f sample %.1f generate+score %.1f "
+                                "extract %.1f icp %.1f arbitration %.1f)\n", draw,
+                        (unsigned long long)tm_scene_live_count(proj), found.size(),
+                        std::chrono::duration<double, std::milli>(t_p1 - t_p0).count(),
+                        std::chrono::duration<double, std::milli>(t_p2 - t_p1).count(), stats_.radius * 1e3,
+                        stats_.sample * 1e3, stats_.generate_score * 1e3, stats_.extract * 1e3, stats_.icp * 1e3,
+                        stats_.arbitration * 1e3);
+            }
             if (found.empty()) {
                 ++idle;
                 continue;

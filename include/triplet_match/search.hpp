@@ -309,10 +309,8 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
      * one-first-point-at-a-time loop below. */
     /* first hypothesis in visit order that is sufficient (:330-338); projected searches: the sufficient one
      * with most tangent inliers, at least min_tangent_inliers */
-    std::vector<int32_t> tangent_subset;
-    if (p.min_tangent_inliers)
-        for (uint32_t i = 0; i < (uint32_t)tangent_mask.size(); ++i)
-            if (tangent_mask[i] && !mask[i]) tangent_subset.push_back((int32_t)i);
+    std::vector<int32_t> tangent_subset; /* filled when the first candidate needs it: a pass over the whole scene */
+    bool have_tangent_subset = false;
     auto first_sufficient = [&](const std::vector<pose_t>& ps, const std::vector<uint32_t>& cs,
                                 const std::vector<double>& ss) -> long {
         std::vector<uint32_t> cand;
@@ -321,7 +319,13 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
                 if (!p.min_tangent_inliers) return (long)h;
                 cand.push_back((uint32_t)h);
             }
-        if (cand.empty() || tangent_subset.empty()) return -1;
+        if (cand.empty()) return -1;
+        if (!have_tangent_subset) {
+            for (uint32_t i = 0; i < (uint32_t)tangent_mask.size(); ++i)
+                if (tangent_mask[i] && !mask[i]) tangent_subset.push_back((int32_t)i);
+            have_tangent_subset = true;
+        }
+        if (tangent_subset.empty()) return -1;
         std::vector<pose_t> cp(cand.size());
         for (size_t k = 0; k < cand.size(); ++k) cp[k] = ps[cand[k]];
         std::vector<uint32_t> tc;

@@ -49,7 +49,7 @@ static int run(pointcloud<P>::Ptr mcloud, pointcloud<P>::Ptr scloud, const std::
            std::chrono::duration<double>(t1 - t0).count());
     scene<P> s(scloud);
     s.disable_curvature_filter(); /* the base scene's own tangent mask plays no role in a projected search */
-    s.set_early_drop(false);
+    s.set_early_drop(getenv("TM_TRAITS_EARLY_DROP") != nullptr); /* default off: see DESIGN section 8 */
     s.set_verbose(getenv("TM_SEARCH_VERBOSE") != nullptr);
     projector_search ps;
     ps.max_idle_searches = 16;

@@ -423,6 +423,47 @@ def _project_cloud_oracle(kind, state, surfels):
 
 
 @pytest.mark.parametrize("kind", ["cylinder", "plane2"])
+def test_probe_projected_equals_the_built_scene(gpu_ctx, kind):
+    """tm_scene_probe_projected's two counts == what tm_scene_create_projected + tm_scene_download give: live
+    points (tm_scene_live_count) and tangent points within the band that are not masked, with and without mask_."""
+    rng = np.random.default_rng(31)
+    K = capi.CYLINDER if kind == "cylinder" else capi.PLANE2
+    ms = np.zeros(capi.STATE_FLOATS, np.float32)
+    ms[1] = 0.05
+    if kind == "cylinder":
+        _, scene, _, _ = _cylinder_case(rng)
+        state = capi.traits_init_from_samples(K, ms, np.concatenate([scene[0], scene[11]]))
+        band = 0.05 / float(state[0])
+    else:
+        scene = np.zeros((6000, 12), np.float32)
+        scene[:, 0:3] = rng.random((6000, 3)) * [3.0, 2.0, 0.2]
+        scene[:, 3] = 1
+        scene[:, 6] = 1
+        scene[::7, 9:12] = [1, 0, 0]
+        scene[5, 0] = np.nan
+        state = capi.traits_init_from_samples(K, ms, np.concatenate([scene[0], scene[700], scene[1400]]))
+        band = 0.05
+    assert state is not None
+    tmask_in = (np.linalg.norm(scene[:, 9:12], axis=1) > 0.7).astype(np.int32)
+    gs = capi.Scene(gpu_ctx, scene, tmask_in)
+    mask = np.zeros(len(scene), np.int32)
+    mask[rng.integers(0, len(scene), len(scene) // 5)] = 1
+    for m in (None, mask):
+        gs.set_mask(m)
+        proj = gs.project(K, state)
+        uvw, tm = proj.download()
+        mm = np.zeros(len(scene), bool) if m is None else m.astype(bool)
+        for b in (band, -1.0, 0.0):
+            live, tan = gs.probe_projected(K, state, b)
+            assert live == proj.live_count()
+            on = np.ones(len(scene), bool) if b < 0 else (np.abs(uvw[:, 2]) <= np.float32(b))
+            assert tan == int(((tm != 0) & ~mm & on).sum()), (kind, m is None, b)
+        assert live > 0
+    gs.set_mask(None)
+
+
+
+@pytest.mark.parametrize("kind", ["cylinder", "plane2"])
 def test_projected_traits_pipeline(gpu_ctx, kind):
     """configs 3/4 wiring: project model and scene into the projector's uvw space, then the same
     kernels run there with that traits' intrinsic_distance (cylinder: wrap-around, plane2: 2-D)."""

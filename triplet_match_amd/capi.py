@@ -89,6 +89,7 @@ SIGNATURES = {
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
     "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
+    "tm_scene_probe_projected": (C.c_int, [vp, C.c_int, f32p, C.c_float, u64p, u32p]),
     "tm_scene_download": (C.c_int, [vp, f32p, i32p]),
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
@@ -583,6 +584,17 @@ class Scene:
         out = Scene.__new__(Scene)
         out.ctx, out.n, out.h = self.ctx, self.n, h
         return out
+
+    def probe_projected(self, kind, state, band=-1.0):
+        """(points that project and are not masked, tangent points among them within `band` of the surface)
+        without building the projected scene (tm_scene_probe_projected)"""
+        st, pst = _f(state)
+        live, tan = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().tm_scene_probe_projected(self.h, kind, pst, band, C.byref(live), C.byref(tan)))
+        return live.value, tan.value
+
+    def live_count(self):
+        return int(lib().tm_scene_live_count(self.h))
 
     def download(self):
         s = np.zeros((self.n, 12), np.float32)

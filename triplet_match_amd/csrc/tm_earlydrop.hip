@@ -54,6 +54,7 @@ struct ed_args {
     uint32_t h0;             /* first hypothesis of this chunk */
     unsigned long long* tail_bits;
     unsigned long long* corr_bits;
+    uint32_t prefix_words;   /* k_ed_fused<true>: 64-bit words of scan positions its LDS bit arrays hold */
     const uint32_t* stop;    /* tm_search_batch: index of the first sufficient hypothesis found so far, 0xFFFFFFFF =
                                 none yet; the kernels of later segments leave at once when it is set. null = unused */
 };
@@ -509,7 +510,13 @@ __global__ __launch_bounds__(256) void k_ed_score_rows(ed_args a, const uint32_t
 constexpr int kEdFusedChunk = 2048; /* tiles per culling round in the fused kernel: 8 KB of LDS */
 constexpr size_t kEdFusedLdsMax = 48 * 1024; /* dynamic LDS for the two bit arrays: subsets up to 196k points */
 
-constexpr uint32_t kEdPrefixWords = 256; /* scan positions a prefix-only workgroup can hold bits for: 16,384 */
+constexpr uint32_t kEdPrefixWordsMax = 2048; /* most scan positions a prefix-only workgroup holds bits for: 131,072
+                                                (32 KiB of LDS); the host asks for what the first checkpoint needs */
+/* words the prefix step needs for a scan of S positions: first checkpoint (5 %) + 1024 positions */
+static inline uint32_t ed_prefix_words(uint32_t S) {
+    const uint32_t need = ((uint32_t)(0.05f * (float)S) + 1024u + 63u) / 64u + 1u;
+    return std::max(16u, std::min(need, kEdPrefixWordsMax));
+}
 
 /* PREFIX = true: step 0 only, with 4 KiB of static LDS for the bits (eight workgroups per CU instead of the
  * two or three the full bit arrays allow): decides the 98 % of hypotheses that drop at the first checkpoint and
@@ -519,9 +526,8 @@ template <bool PREFIX>
 __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out o, float accept_thresh,
                                                   const uint32_t* __restrict__ tests, const float4* __restrict__ oref,
                                                   uint32_t* __restrict__ pending, uint32_t* __restrict__ n_pending) {
-    extern __shared__ unsigned long long s_dyn[]; /* PREFIX = false: [words] in-grid bits, then [words] correspondence bits */
-    __shared__ unsigned long long s_static[PREFIX ? 2 * kEdPrefixWords : 1];
-    unsigned long long* s_bits = PREFIX ? s_static : s_dyn;
+    extern __shared__ unsigned long long s_dyn[]; /* [bit_words] in-grid bits, then [bit_words] correspondence bits */
+    unsigned long long* s_bits = s_dyn;
     __shared__ uint32_t s_list[PREFIX ? 1 : kEdFusedChunk];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_smask;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     const uint32_t hl = from_list ? pending[item] : item;
     tests = tests_in;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t bit_words = PREFIX ? kEdPrefixWords : a.words;
+    const uint32_t bit_words = PREFIX ? a.prefix_words : a.words;
     unsigned long long* tb = s_bits;
     unsigned long long* cb = s_bits + bit_words;
     for (uint32_t w = threadIdx.x; w < 2u * bit_words; w += 256) s_bits[w] = 0ull;
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     const uint32_t S_words = (S + 63u) / 64u;
     uint32_t B_words = (tests[0] + 1024u + 63u) / 64u;
     if (B_words > S_words) B_words = S_words;
-    if (PREFIX && B_words > kEdPrefixWords) B_words = kEdPrefixWords; /* a shorter prefix may just not decide */
+    if (PREFIX && B_words > a.prefix_words) B_words = a.prefix_words; /* a shorter prefix may just not decide */
     if (!PREFIX && (pending || a.sc.ablate == 30)) B_words = 0u; /* the whole scan in the tile-culled pass */
     for (uint32_t step = 0; step < (PREFIX ? 1u : 2u); ++step) {
         const uint32_t pos_lo = step == 0 ? 0u : B_words * 64u;
@@ -786,8 +792,8 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     uint32_t* d_n = s->ed_pending.p + n_hyp;
     hipError_t e = hipMemsetAsync(d_n, 0, 4, c->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 0, c->stream, a, cu, o, accept_thresh, d_tests,
-                       s->oref.p, s->ed_pending.p, d_n);
+    hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
+                       accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
     if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !getenv("TM_ED_NARROW")) {
         /* wide continuation (ball mode: the scan order is the neighbourhood list): bits of all positions of the
          * pending hypotheses, then the rule and the score terms on those rows; rows_cap rows of bit arrays */
@@ -930,6 +936,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
     a.stop = nullptr;
+    a.prefix_words = ed_prefix_words(a.S);
     ed_out o;
     o.counts = d_counts.p;
     o.dropped_at = d_dropped.p;
@@ -1119,6 +1126,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
     a.stop = nullptr;
+    a.prefix_words = ed_prefix_words(a.S);
     ed_brick_filter(m, dist_thres * m->resolution, a.sc);
     ed_args as = a; /* k_ed_score addresses scene points by original index */
     as.sc.sref = s->oref.p;
@@ -1137,7 +1145,12 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     o.limit = d_limit.p;
     const float accept_thresh = accept_prob * (float)m->n;
     const size_t fused_lds = 2 * (size_t)words * 8;
-    const bool fused = fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
+    /* neighbourhoods beyond 196k points do not fit the full kernel's LDS bit arrays; the prefix kernel and the
+     * wide continuation (bit rows in global memory) do not need them, so batches small enough for the wide
+     * continuation keep the two-step rule at any neighbourhood size */
+    const bool big_lds = fused_lds > kEdFusedLdsMax;
+    const bool fused = (!big_lds || n_hyp <= 4096u || (segment && segment <= 4096u && d_found)) &&
+                       getenv("TM_ED_UNFUSED") == nullptr && !(big_lds && (getenv("TM_ED_NARROW") || getenv("TM_ED_ONE_KERNEL")));
     if (fused && segment && d_found) {
         /* tm_search_batch: only the first sufficient hypothesis in visit order is wanted (reference :330-338: later
          * ones are scored without effect). The hypotheses go through in segments; after each, *d_found takes the
@@ -1157,7 +1170,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
          * pays for the few rows of a segment (end-to-end search 0.030 against 0.034 s) */
         a.h0 = 0;
         TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p,
-                                     n_hyp <= 4096u || getenv("TM_ED_WIDE") ? chunk : 0u));
+                                     n_hyp <= 4096u || big_lds || getenv("TM_ED_WIDE") ? chunk : 0u));
         if (getenv("TM_DEBUG_ED")) { /* how many hypotheses the prefix kernel could not decide */
             uint32_t n_pend = 0;
             TM_HIP_CHECK(hipMemcpyAsync(&n_pend, s->ed_pending.p + n_hyp, 4, hipMemcpyDeviceToHost, c->stream));

@@ -54,6 +54,26 @@ __global__ __launch_bounds__(256) void k_projected_masks(float* __restrict__ clo
     mask[i] = src_mask[i];
 }
 
+/* tm_scene_probe_projected: live = finite and not masked (k_scene_gather's rule), tangent = tangent_mask, not
+ * masked, within the band of the surface */
+__global__ __launch_bounds__(256) void k_probe_count(const float* __restrict__ cloud, const int32_t* __restrict__ tmask,
+                                                     const int32_t* __restrict__ mask, uint32_t n, float band,
+                                                     uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    bool live = false, tan = false;
+    if (i < n) {
+        const float* o = cloud + (size_t)i * 12;
+        const bool fin = (o[0] - o[0] == 0.f) && (o[1] - o[1] == 0.f) && (o[2] - o[2] == 0.f);
+        live = fin && mask[i] == 0;
+        tan = tmask[i] != 0 && mask[i] == 0 && (band < 0.f || fabsf(o[2]) <= band);
+    }
+    const unsigned long long bl = __ballot(live), bt = __ballot(tan);
+    if ((threadIdx.x & 63) == 0) {
+        if (bl) atomicAdd(&counts[0], (unsigned int)__popcll(bl));
+        if (bt) atomicAdd(&counts[1], (unsigned int)__popcll(bt));
+    }
+}
+
 /* column-major 4x4 * float4, left-to-right sum like opencl/util.cl:4-7 */
 __device__ __forceinline__ float4 cl_mat44(float4 p, const float* __restrict__ m) {
     return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * p.w,
@@ -290,6 +310,45 @@ int tm_scene_create_projected(tm_scene* src, int kind, const float* state, tm_sc
         return rc;
     }
     *out = t;
+    return TM_OK;
+}
+
+/* What tm_scene_create_projected would give, counted without building it: the points that project and are not
+ * masked (tm_scene_live_count of the projected scene) and the tangent points among them within `band` of the
+ * surface (abs(w) <= band; band < 0 = no test). The same two kernels into scratch memory + a count. */
+int tm_scene_probe_projected(tm_scene* src, int kind, const float* state, float band, uint64_t* live,
+                             uint32_t* tangent_on_surface) {
+    TM_REQUIRE(src && state && live && tangent_on_surface, TM_ERR_INVALID, "tm_scene_probe_projected: null argument");
+    TM_REQUIRE(kind >= 0 && kind <= 3, TM_ERR_INVALID, "bad traits kind");
+    tm_ctx* c = src->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t n = src->n;
+    *live = 0;
+    *tangent_on_surface = 0;
+    if (n == 0) return TM_OK;
+    /* scratch: projected cloud (12 floats per point), valid, tmask, mask, state, two counters */
+    const size_t bytes = (size_t)n * 48 + (size_t)n * 12 + TM_STATE_FLOATS * 4 + 16;
+    TM_FORWARD(scratch_ensure(c, bytes));
+    float* d_cloud = reinterpret_cast<float*>(c->scratch.p);
+    int32_t* d_valid = reinterpret_cast<int32_t*>(d_cloud + (size_t)n * 12);
+    int32_t* d_tmask = d_valid + n;
+    int32_t* d_mask = d_tmask + n;
+    float* d_state = reinterpret_cast<float*>(d_mask + n);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(d_state + TM_STATE_FLOATS);
+    TM_HIP_CHECK(hipMemcpyAsync(d_state, state, TM_STATE_FLOATS * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_project_cloud, dim3((n + 255) / 256), dim3(256), 0, c->stream, kind, d_state, src->d_cloud.p, n,
+                       d_cloud, d_valid);
+    hipLaunchKernelGGL(k_projected_masks, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_valid, src->d_mask.p,
+                       n, d_tmask, d_mask);
+    hipLaunchKernelGGL(k_probe_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_tmask, d_mask, n, band,
+                       d_cnt);
+    TM_HIP_CHECK(hipGetLastError());
+    uint32_t h[2] = {0, 0};
+    TM_HIP_CHECK(hipMemcpyAsync(h, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *live = h[0];
+    *tangent_on_surface = h[1];
     return TM_OK;
 }
 
