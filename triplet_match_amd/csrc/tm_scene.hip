@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
  * ---------------------------------------------------------------------------------------------- */
 typedef uint32_t group_mask_t; /* up to 32 hypotheses per group */
 /* LDS of one wave of k_score_items<G>: chunk xyz + poses (3 float4 each) + (rnorm, abs_eps) + entries + sums */
-constexpr int item_lds(int G) { return 6144 + G * 48 + G * 8 + G * 32 * 2 + G * 8; }
+constexpr int item_lds(int G, bool ball = false) { return 6144 + G * 48 + G * 8 + G * 32 * 2 + G * 8 + (ball ? G * 16 : 0); }
 constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
 constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs). Five
                                  waves = 96 VGPRs spill and lose: four chains 100 bytes per lane, 18.3 ms against
@@ -442,6 +442,11 @@ __global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, 
         const float rnorm = ax.x, abs_eps = ax.y;
         bool hit = sphere_hits_box(a, T, rnorm, abs_eps, ss);
         if (hit) hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
+        if (ca.centers) { /* neighbourhood restriction: the chunk must reach the ball of the hypothesis' first point */
+            const float4 C = ca.opos[ca.centers[h]];
+            const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
+            hit = hit && !(len(make3(sb.x, sb.y, sb.z) - make3(C.x, C.y, C.z)) > ca.ball_r + sb.w * 1.00001f + ball_margin);
+        }
         m |= hit ? (1u << g) : 0u;
     }
     if (live) ga.masks[(size_t)group * ga.n_chunks + chunk] = (group_mask_t)m;
@@ -481,10 +486,13 @@ __device__ __forceinline__ f3 lds_xform_dir(const float4 A, const float4 B, cons
     return make3(xy.x, xy.y, (C.x * px + C.y * py) + C.z * pz);
 }
 
-template <bool L2, int NC, int G>
+/* BALL: every hypothesis scores only the scene points within ca.ball_r of its own centre point (the reference's
+ * nn = radius_search_inclusive(diameter, p1)): quarter-tiles conservatively by a sphere-sphere test, points exactly
+ * by (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point, as k_score_culled does */
+template <bool L2, int NC, int G, bool BALL = false>
 __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, cull_args ca, group_args ga) {
     /* 8 KiB of LDS per wave, private to it: no workgroup barrier inside the loop */
-    __shared__ __align__(16) unsigned char s_raw[4][item_lds(G)];
+    __shared__ __align__(16) unsigned char s_raw[4][item_lds(G, BALL)];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n_items = *ga.n_items;
     /* XCD-aware split (speed only): blocks b and b + 8 share an L2; consecutive items belong to the same
@@ -500,6 +508,8 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
     unsigned short* ent = reinterpret_cast<unsigned short*>(s_raw[wave] + 6144 + G * 56); /* entries */
     unsigned long long* acc =
         reinterpret_cast<unsigned long long*>(s_raw[wave] + 6144 + G * 56 + G * 64); /* count << 52 | sum */
+    float4* cen = reinterpret_cast<float4*>(s_raw[wave] + 6144 + G * 56 + G * 64 + G * 8); /* BALL: centre per hypothesis */
+    const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
     if (lane < (uint32_t)G) acc[lane] = 0ull;
     /* Items differ a lot in cost (1 to 16 hypotheses, 0 to 32 quarter-tiles each): with a static share per wave
      * the average wave was resident for 72 % of the kernel only (12.97 ms). Each wave therefore pulls its next
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             for (int r = 0; r < (G * 3 + 63) / 64; ++r)
                 if (64u * r + lane < (uint32_t)G * 3u) poses[64u * r + lane] = pv[r];
             if (lane < (uint32_t)G) auxl[lane] = ax;
+            if (BALL && lane < (uint32_t)G) cen[lane] = ca.opos[ca.centers[min(group * G + lane, a.n_hyp - 1u)]];
         }
         const float4 qs = ca.subs[(size_t)chunk * 32u + (lane & 31u)];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -592,6 +603,11 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                         pr[r].lim = 0.f;
                     }
                     pr[r].hit = pr[r].hit & (((m >> g) & 1u) != 0u);
+                    if (BALL) {
+                        const float4 C = cen[g];
+                        pr[r].hit = pr[r].hit && !(len(make3(qs.x, qs.y, qs.z) - make3(C.x, C.y, C.z)) >
+                                                   ca.ball_r + qs.w * 1.00001f + ball_margin);
+                    }
                     pr[r].need = pr[r].need & pr[r].hit;
                     if (!pr[r].need) pr[r].brick = 0u;
                     __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
@@ -653,6 +669,10 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             for (int k = 0; k < NC; ++k) {
                 const float4* pp = poses + 3u * gk[k];
                 const float* sp = pts + 3u * pidx[k];
+                if (BALL) { /* exact membership of the neighbourhood, on the untransformed point */
+                    const float4 C = cen[gk[k]];
+                    in[k] = in[k] & (len2(make3(sp[0], sp[1], sp[2]) - make3(C.x, C.y, C.z)) <= ca.ball_r2);
+                }
                 q[k] = lds_xform_point(pp[0], pp[1], pp[2], sp[0], sp[1], sp[2]);
                 const f2v vxy = f2v{a.g.sx, a.g.sy} * f2v{q[k].x, q[k].y} + f2v{a.g.tx, a.g.ty};
                 const float vx = vxy.x, vy = vxy.y, vz = a.g.sz * q[k].z + a.g.tz;
@@ -1225,8 +1245,9 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                                s->d_order.p, s->n, s->n_sorted, s->w_active_sorted.p);
             ca.active_sorted = s->w_active_sorted.p;
         }
-        bool grouped = !d_active && !d_centers;
+        bool grouped = !d_active; /* with or without the neighbourhood restriction (d_centers) */
         if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
+        if (d_centers && getenv("TM_BALL_UNGROUPED")) grouped = false;
         /* groups of consecutive hypotheses share the scene chunks they reach */
         group_args ga;
         ga.chunks = s->chunks.p;
@@ -1235,7 +1256,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
          * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
          * as that saves: 13.05 ms against 12.90 ms in the same run. */
         ga.group_hyps = 16u;
-        if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 ? 32u : 16u;
+        if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 && !d_centers ? 32u : 16u;
         ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
         const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
         /* slots are addressed with 32 bits and the chunks ride in blockIdx.y: beyond that (billions of points,
@@ -1278,6 +1299,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
              * resident at once, or the surplus workgroups run their share after everyone else */
             auto kern = ga.group_hyps == 16u ? (l2 ? k_score_items<true, 4, 16> : k_score_items<false, 4, 16>)
                                              : (l2 ? k_score_items<true, 4, 32> : k_score_items<false, 4, 32>);
+            if (d_centers) kern = l2 ? k_score_items<true, 4, 16, true> : k_score_items<false, 4, 16, true>;
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
