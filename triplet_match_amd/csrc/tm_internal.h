@@ -202,6 +202,8 @@ struct tm_scene {
     tmx::dbuf<uint4> sb_prov;
     tmx::dbuf<tm_batch_result> sb_result;
     tmx::dbuf<unsigned char> w_active_sorted; /* subset flags in sorted order */
+    tmx::dbuf<unsigned char> w_active;        /* subset flags in original order (tm_score_hypotheses) */
+    std::vector<unsigned char> h_act;         /* host copy of the same, all zero between calls */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;

@@ -1575,6 +1575,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->sb_centres.release();
     s->sb_prov.release();
     s->sb_result.release();
+    s->w_active.release();
     s->ed_cpos.release();
     delete s;
     return TM_OK;
@@ -1644,34 +1645,25 @@ int tm_generate_hypotheses(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, u
     if (n_pairs == 0) return m->pairs_ready ? TM_OK : TM_ERR_NOT_INITIALIZED;
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
-    dbuf<uint2> d_ij;
-    dbuf<float> d_pose;
-    dbuf<uint4> d_prov;
+    /* the scene's work buffers (no allocation per call) */
     int rc;
-    uint32_t dev_cap = std::max(cap, 1u);
-    if ((rc = d_ij.alloc(n_pairs)) || (rc = d_pose.alloc((size_t)dev_cap * 16)) ||
-        (rc = d_prov.alloc(dev_cap))) {
-        d_ij.release();
-        d_pose.release();
-        d_prov.release();
-        return rc;
-    }
-    hipError_t e = hipMemcpyAsync(d_ij.p, ij_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream);
+    const uint32_t dev_cap = std::max(cap, 1u);
+    TM_FORWARD(s->sb_ij.ensure((size_t)n_pairs * 2));
+    TM_FORWARD(s->w_poses.ensure((size_t)dev_cap * 16));
+    TM_FORWARD(s->sb_prov.ensure(dev_cap));
+    hipError_t e = hipMemcpyAsync(s->sb_ij.p, ij_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream);
     uint32_t got = 0, total = 0;
     rc = TM_OK;
     if (e == hipSuccess)
-        rc = generate_device(s, m, d_ij.p, n_pairs, min_diameter_factor, max_diameter_factor, force_up,
-                             query_limit, d_pose.p, d_prov.p, cap, &got, &total);
+        rc = generate_device(s, m, reinterpret_cast<const uint2*>(s->sb_ij.p), n_pairs, min_diameter_factor,
+                             max_diameter_factor, force_up, query_limit, s->w_poses.p, s->sb_prov.p, cap, &got, &total);
     if (e == hipSuccess && rc == TM_OK && got) {
         if (poses16)
-            e = hipMemcpyAsync(poses16, d_pose.p, (size_t)got * 64, hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(poses16, s->w_poses.p, (size_t)got * 64, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && provenance4)
-            e = hipMemcpyAsync(provenance4, d_prov.p, (size_t)got * 16, hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(provenance4, s->sb_prov.p, (size_t)got * 16, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    d_ij.release();
-    d_pose.release();
-    d_prov.release();
     if (e != hipSuccess) {
         set_error("tm_generate_hypotheses: %s", hipGetErrorString(e));
         return TM_ERR_HIP;
@@ -1704,31 +1696,36 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_FORWARD(s->w_counts.ensure(n_hyp));
     TM_FORWARD(s->w_scores.ensure(n_hyp));
     TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
-    dbuf<unsigned char> d_active;
+    const unsigned char* d_active = nullptr;
     uint64_t n_active = 0;
     if (subset) {
-        std::vector<unsigned char> act(s->n, 0);
+        /* flags per point: the scene keeps the host array (zero between calls) and the device buffer, so a call
+         * costs its own subset, not a pass over the scene */
+        for (uint32_t k = 0; k < n_subset; ++k)
+            TM_REQUIRE(subset[k] >= 0 && (uint32_t)subset[k] < s->n, TM_ERR_INVALID,
+                       "tm_score_hypotheses: subset index out of range");
+        if (s->h_act.size() != s->n) s->h_act.assign(s->n, 0);
+        std::vector<unsigned char>& act = s->h_act;
         for (uint32_t k = 0; k < n_subset; ++k) {
-            if (subset[k] < 0 || (uint32_t)subset[k] >= s->n) {
-                set_error("tm_score_hypotheses: subset index out of range");
-                return TM_ERR_INVALID;
-            }
-            act[subset[k]] = 1;
+            const uint32_t i = (uint32_t)subset[k];
+            if (act[i]) continue;
+            act[i] = 1;
+            if (!s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++n_active;
         }
-        for (uint32_t i = 0; i < s->n; ++i)
-            if (act[i] && !s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++n_active;
-        TM_FORWARD(d_active.alloc(s->n));
-        hipError_t e = hipMemcpyAsync(d_active.p, act.data(), s->n, hipMemcpyHostToDevice, c->stream);
+        int rc0 = s->w_active.ensure(s->n);
+        hipError_t e = rc0 ? hipErrorOutOfMemory
+                           : hipMemcpyAsync(s->w_active.p, act.data(), s->n, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        for (uint32_t k = 0; k < n_subset; ++k) act[(uint32_t)subset[k]] = 0;
         if (e != hipSuccess) {
-            d_active.release();
             set_error("tm_score_hypotheses: %s", hipGetErrorString(e));
-            return TM_ERR_HIP;
+            return rc0 ? rc0 : TM_ERR_HIP;
         }
+        d_active = s->w_active.p;
     } else {
         n_active = count_active(s);
     }
-    int rc = score_device(s, m, traits_kind, s->w_poses.p, n_hyp, d_active.p, n_active, dist_thres, mode,
+    int rc = score_device(s, m, traits_kind, s->w_poses.p, n_hyp, d_active, n_active, dist_thres, mode,
                           s->w_counts.p, s->w_scores.p);
     hipError_t e = hipSuccess;
     if (rc == TM_OK) {
@@ -1737,7 +1734,6 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
             e = hipMemcpyAsync(scores, s->w_scores.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream);
     }
     hipError_t e2 = hipStreamSynchronize(c->stream);
-    d_active.release();
     if (rc) return rc;
     if (e != hipSuccess || e2 != hipSuccess) {
         set_error("tm_score_hypotheses: %s", hipGetErrorString(e != hipSuccess ? e : e2));
