@@ -236,6 +236,14 @@ int tm_score_hypotheses_ball_dev(tm_scene* scene, tm_model* model, const float* 
                                  const uint32_t* d_centers, float radius, float dist_thres,
                                  uint32_t* d_counts, double* d_scores);
 
+/* The same full pass (project_ without early drop, include/impl/scene.hpp:411-510) over a LIST of scene points,
+ * each listed at most once (TM_ERR_INVALID otherwise; at most 65,535 poses per call): one thread per (pose,
+ * point) straight from the list instead of a walk over the whole scene — the form for short lists (a tangent
+ * subset, a neighbourhood). counts / scores equal tm_score_hypotheses with the same points as subset. */
+int tm_score_hypotheses_on_points(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n_hyp,
+                                  const int32_t* points, uint32_t n_points, float dist_thres, uint32_t* counts,
+                                  double* scores);
+
 /* early-drop rule of project_ (include/impl/scene.hpp:422-426,492-506) evaluated exactly for a
  * batch: dropped_at[h] = checkpoint index (0..17) or -1, counts/scores/saved as project_ returns */
 int tm_score_hypotheses_early_drop(tm_scene* scene, tm_model* model, const float* poses16,

@@ -179,10 +179,18 @@ struct hip_backend {
                                                  dropped.data(), saved.data()),
                   "tm_score_hypotheses_early_drop");
         } else {
-            check(tm_score_hypotheses(s, m, traits_kind, &poses[0].m[0], n, subset.data(),
-                                      (uint32_t)subset.size(), p.dist_thres, TM_SCORE_AUTO, counts.data(),
-                                      scores.data()),
-                  "tm_score_hypotheses");
+            /* a short list of points and few poses: one thread per (pose, point) instead of a walk over the scene
+             * per pose (a list with a repeated point is refused and takes the general call) */
+            int rc = TM_ERR_INVALID;
+            if (n <= 65535u && !subset.empty() && (uint64_t)n * subset.size() <= (1ull << 28) &&
+                getenv("TM_SUBSET_GENERAL") == nullptr)
+                rc = tm_score_hypotheses_on_points(s, m, &poses[0].m[0], n, subset.data(), (uint32_t)subset.size(),
+                                                   p.dist_thres, counts.data(), scores.data());
+            if (rc != TM_OK)
+                check(tm_score_hypotheses(s, m, traits_kind, &poses[0].m[0], n, subset.data(),
+                                          (uint32_t)subset.size(), p.dist_thres, TM_SCORE_AUTO, counts.data(),
+                                          scores.data()),
+                      "tm_score_hypotheses");
         }
     }
     void extract(const search::pose_t& T, float dist_thres, search::candidate_t& out) {

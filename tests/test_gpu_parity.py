@@ -208,6 +208,15 @@ def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
     co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, subset=sub)
     cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT, subset=sub)
     assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+    # the list form (one thread per (pose, point)): same counts and the same score bits
+    cp, sp = gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, sub, DT)
+    assert np.array_equal(cp, cg) and np.array_equal(sp, sg)
+    cp0, sp0 = gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, np.zeros(0, np.int32), DT)
+    assert not cp0.any() and not sp0.any()
+    with pytest.raises(capi.TmError):  # a point listed twice
+        gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, np.array([3, 5, 3], np.int32), DT)
+    with pytest.raises(capi.TmError):
+        gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, np.array([-1], np.int32), DT)
     # empty subset
     cg0, sg0 = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT,
                                                     subset=np.zeros(0, np.int32))
@@ -221,6 +230,11 @@ def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
         co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT)
         cg, sg = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
         assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
+        # subset + mask_: general call == list form == oracle
+        cs, ss = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT, subset=sub)
+        cp, sp = gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, sub, DT)
+        cso, _, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, subset=sub)
+        assert np.array_equal(cp, cs) and np.array_equal(sp, ss) and np.array_equal(cs, cso)
     finally:
         oracle_small["scene"].set_mask(None)
         gpu_small["scene"].set_mask(None)

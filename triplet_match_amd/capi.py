@@ -104,6 +104,7 @@ SIGNATURES = {
                                           vp]),
     "tm_score_hypotheses_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, u32p, f64p]),
     "tm_score_hypotheses_ball_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_float, C.c_float, vp, vp]),
+    "tm_score_hypotheses_on_points": (C.c_int, [vp, vp, f32p, C.c_uint32, i32p, C.c_uint32, C.c_float, u32p, f64p]),
     "tm_score_hypotheses_early_drop": (C.c_int, [vp, vp, f32p, C.c_uint32, i32p, C.c_uint32,
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
     "tm_score_hypotheses_early_drop_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, C.c_float,
@@ -680,6 +681,16 @@ class Scene:
         scores = np.zeros(n, np.float64)
         _check(lib().tm_score_hypotheses_ball(self.h, model.h, pP, n, pc, radius, dist_thres,
                                               counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p)))
+        return counts, scores
+
+    def score_hypotheses_on_points(self, model, poses16, points, dist_thres):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        pts, pp = _i(points)
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        _check(lib().tm_score_hypotheses_on_points(self.h, model.h, pP, n, pp, pts.size, dist_thres,
+                                                   counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p)))
         return counts, scores
 
     def score_hypotheses_early_drop(self, model, poses16, dist_thres, accept_prob, subset=None):

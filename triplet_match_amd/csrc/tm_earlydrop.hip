@@ -1384,6 +1384,110 @@ extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pair
     return TM_OK;
 }
 
+namespace tmx {
+/* project_ (full pass) of every pose on a short list of scene points: one thread per (pose, listed point), straight
+ * from the arrays in original order — no walk over the scene's tiles, which is what a whole-scene kernel spends
+ * its time on when the list is a few thousand points */
+__global__ __launch_bounds__(256) void k_score_points(score_args sc /* sref = original order */,
+                                                      const float4* __restrict__ opos, const float4* __restrict__ otan,
+                                                      const int32_t* __restrict__ points, uint32_t n_points) {
+    const uint32_t pos = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+    long long fx = 0;
+    uint32_t cnt = 0;
+    if (pos < n_points) {
+        const uint32_t idx = (uint32_t)points[pos];
+        if (otan[idx].w == 0.f) { /* mask_ (:434) */
+            const float4 P = opos[idx];
+            const pose12 T = load_pose(sc.poses + (size_t)h * 16);
+            uint32_t pass = 0;
+            cnt = eval_point(sc, T, make3(P.x, P.y, P.z), idx, fx, pass, nullptr, nullptr);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        fx += __shfl_down(fx, off);
+        cnt += __shfl_down(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(&sc.counts[h], cnt);
+        if (fx) atomicAdd(&sc.scores_fx[h], (unsigned long long)fx);
+    }
+}
+}  // namespace tmx
+
+extern "C" int tm_score_hypotheses_on_points(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
+                                             const int32_t* points, uint32_t n_points, float dist_thres,
+                                             uint32_t* counts, double* scores) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(counts && scores, TM_ERR_INVALID, "null outputs");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(poses16 && (points || n_points == 0), TM_ERR_INVALID, "null inputs");
+    TM_REQUIRE(n_hyp <= 65535u, TM_ERR_INVALID, "tm_score_hypotheses_on_points: at most 65,535 poses per call");
+    for (uint32_t h = 0; h < n_hyp; ++h) {
+        counts[h] = 0;
+        scores[h] = 0.0;
+    }
+    if (n_points == 0) return TM_OK;
+    /* every point at most once (a set, like the subset of tm_score_hypotheses) */
+    if (s->h_act.size() != s->n) s->h_act.assign(s->n, 0);
+    bool bad = false;
+    uint32_t k_done = 0;
+    for (; k_done < n_points; ++k_done) {
+        const int32_t i = points[k_done];
+        if (i < 0 || (uint32_t)i >= s->n || s->h_act[(uint32_t)i]) {
+            bad = true;
+            break;
+        }
+        s->h_act[(uint32_t)i] = 1;
+    }
+    for (uint32_t k = 0; k < k_done; ++k) s->h_act[(uint32_t)points[k]] = 0;
+    TM_REQUIRE(!bad, TM_ERR_INVALID, "tm_score_hypotheses_on_points: index out of range or listed twice");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure((size_t)n_hyp * 16));
+    TM_FORWARD(s->w_counts.ensure(n_hyp));
+    TM_FORWARD(s->w_scores_fx.ensure(n_hyp));
+    TM_FORWARD(s->ed_subset.ensure(n_points));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n_hyp * 64, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->ed_subset.p, points, (size_t)n_points * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, (size_t)n_hyp * 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, (size_t)n_hyp * 8, c->stream));
+    score_args sc;
+    sc.spos = nullptr;
+    sc.spos3 = nullptr;
+    sc.sref = s->oref.p;
+    sc.mpos = m->pos.p;
+    sc.mpos3 = m->pos3.p;
+    sc.mref = m->ref.p;
+    sc.vox = m->voxels.p;
+    sc.active = nullptr;
+    sc.ablate = 0;
+    sc.kind = m->metric_kind;
+    sc.radius = m->metric_radius;
+    sc.dmax = dist_thres * m->resolution;
+    sc.bx = m->bdim[0];
+    sc.by = m->bdim[1];
+    sc.poses = s->w_poses.p;
+    sc.counts = s->w_counts.p;
+    sc.scores_fx = s->w_scores_fx.p;
+    sc.stat_slots = nullptr;
+    sc.g = m->grid;
+    sc.d2max = sq_threshold(dist_thres * m->resolution);
+    sc.n_hyp = n_hyp;
+    sc.hyp_per_block = 1;
+    ed_brick_filter(m, dist_thres * m->resolution, sc);
+    hipLaunchKernelGGL(k_score_points, dim3((n_points + 255) / 256, n_hyp), dim3(256), 0, c->stream, sc, s->opos.p,
+                       s->otan.p, s->ed_subset.p, n_points);
+    TM_HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> fx(n_hyp);
+    TM_HIP_CHECK(hipMemcpyAsync(counts, s->w_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(fx.data(), s->w_scores_fx.p, (size_t)n_hyp * 8, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (uint32_t h = 0; h < n_hyp; ++h) scores[h] = (double)fx[h] * (1.0 / kFx) / (double)m->n; /* :509 */
+    return TM_OK;
+}
+
 /* radius_search_inclusive for several centres with the index lists built on the device: membership bits,
  * per-word prefix counts and an ordered scatter (the kernels of the ball mode above); only counts[k] indices
  * per centre travel back. */
