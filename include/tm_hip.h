@@ -279,6 +279,15 @@ int tm_search_batch(tm_scene* scene, tm_model* model, const uint32_t* ij_pairs, 
                     float min_diameter_factor, float max_diameter_factor, int force_up, int query_limit,
                     float radius, float dist_thres, float accept_prob, int early_drop, float sufficient,
                     tm_batch_result* result);
+/* Several independent batches in one call (the chunks of one find_parallel round, include/impl/scene.hpp:156-166:
+ * the reference runs them on concurrent threads): pairs batch_offsets[b] .. batch_offsets[b + 1] belong to batch
+ * b (offsets ascend from 0 to n_pairs), results[b] is what tm_search_batch returns for those pairs alone. The
+ * hypotheses are generated in one go, the neighbourhoods of all first points built together, every batch runs
+ * its own segments with its own stop flag, and nothing is read back before the end. */
+int tm_search_batches(tm_scene* scene, tm_model* model, const uint32_t* ij_pairs, uint32_t n_pairs,
+                      const uint32_t* batch_offsets, uint32_t n_batches, float min_diameter_factor,
+                      float max_diameter_factor, int force_up, int query_limit, float radius, float dist_thres,
+                      float accept_prob, int early_drop, float sufficient, tm_batch_result* results);
 
 /* finish_find (include/impl/scene.hpp:100-106): correspondences of one pose over all points,
  * ascending scene index; *score normalised by |model cloud| */

@@ -149,6 +149,30 @@ struct hip_backend {
         for (int k = 0; k < 16; ++k) pose.m[k] = r.pose[k];
         return true;
     }
+    /* the batches of a whole find_parallel round in one call (tm_search_batches); TM_SEARCH_PER_CHUNK=1: one call
+     * per batch as the chunks come */
+    bool supports_deferred_batches() const { return supports_fused_batch() && getenv("TM_SEARCH_PER_CHUNK") == nullptr; }
+    void search_batches(const std::vector<std::vector<uint32_t>>& batches, float radius, bool early_drop,
+                        float sufficient, std::vector<char>& found, std::vector<search::pose_t>& poses) {
+        std::vector<uint32_t> ij, offsets(1, 0u);
+        for (const auto& b : batches) {
+            ij.insert(ij.end(), b.begin(), b.end());
+            offsets.push_back((uint32_t)(ij.size() / 2));
+        }
+        found.assign(batches.size(), 0);
+        poses.resize(batches.size());
+        if (batches.empty()) return;
+        std::vector<tm_batch_result> r(batches.size());
+        check(tm_search_batches(s, m, ij.data(), (uint32_t)(ij.size() / 2), offsets.data(), (uint32_t)batches.size(),
+                                p.min_diameter_factor, p.max_diameter_factor, p.force_up ? 1 : 0, search::query_limit,
+                                radius, p.dist_thres, p.accept_prob, early_drop ? 1 : 0, sufficient, r.data()),
+              "tm_search_batches");
+        for (size_t b = 0; b < batches.size(); ++b)
+            if (r[b].index >= 0) {
+                found[b] = 1;
+                for (int k = 0; k < 16; ++k) poses[b].m[k] = r[b].pose[k];
+            }
+    }
     void score_ball(const std::vector<search::pose_t>& poses, const std::vector<uint32_t>& centers, float radius,
                     bool early_drop, std::vector<uint32_t>& counts, std::vector<double>& scores) {
         counts.assign(poses.size(), 0u);

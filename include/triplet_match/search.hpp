@@ -244,6 +244,27 @@ inline bool fused_batch(B&, const std::vector<uint32_t>&, float, bool, float, po
     return false;
 }
 
+/* can the backend take the batches of a whole round in one call? (hip_backend: tm_search_batches) */
+template <class B, class = void>
+struct has_search_batches : std::false_type {};
+template <class B>
+struct has_search_batches<B, decltype(void(std::declval<B&>().search_batches(
+                                 std::declval<const std::vector<std::vector<uint32_t>>&>(), 0.f, false, 0.f,
+                                 std::declval<std::vector<char>&>(), std::declval<std::vector<pose_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline bool deferred_batches(B& be, std::true_type) { return be.supports_deferred_batches(); }
+template <class B>
+inline bool deferred_batches(B&, std::false_type) { return false; }
+template <class B>
+inline void run_batches(B& be, const std::vector<std::vector<uint32_t>>& batches, float radius, bool early_drop,
+                        float sufficient, std::vector<char>& found, std::vector<pose_t>& poses, std::true_type) {
+    be.search_batches(batches, radius, early_drop, sufficient, found, poses);
+}
+template <class B>
+inline void run_batches(B&, const std::vector<std::vector<uint32_t>>&, float, bool, float, std::vector<char>&,
+                        std::vector<pose_t>&, std::false_type) {}
+
 /* does the backend hand out its neighbourhood lists in place? (hip_backend: a view into the lists it fetched
  * for 16 first points at once; saves a 0.4 MB copy per first point at the C2 size) */
 template <class B, class = void>
@@ -288,7 +309,11 @@ inline bool device_icp(B&, const pose_t&, float, uint32_t, pose_t&, std::false_t
 template <class Backend>
 inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     Backend& be, const std::vector<uint32_t>& firsts, const std::vector<int32_t>& mask,
-    const std::vector<int32_t>& fp_mask, const std::vector<int32_t>& tangent_mask, const params_t& p) {
+    const std::vector<int32_t>& fp_mask, const std::vector<int32_t>& tangent_mask, const params_t& p,
+    std::vector<std::vector<uint32_t>>* recorder = nullptr) {
+    /* recorder: the batches are not scored here but handed back in visit order (find_parallel runs the batches of
+     * all its chunks in one call; the first batch of a chunk with a sufficient hypothesis is the chunk's result —
+     * the same as stopping at it, because what a batch contains does not depend on earlier batches' scores) */
     std::mt19937 rng;
     rng.seed((uint32_t)p.seed);
     std::vector<pose_t> best_ts;
@@ -341,6 +366,11 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     std::vector<uint32_t> batch_ij, pair_of_hyp, centers;
     auto flush_batch = [&]() {
         if (batch_ij.empty() || !best_ts.empty()) {
+            batch_ij.clear();
+            return;
+        }
+        if (recorder) {
+            recorder->push_back(batch_ij);
             batch_ij.clear();
             return;
         }
@@ -587,6 +617,40 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             candidate_t c;
             be.extract(T, dt, c);
             cands.push_back(std::move(c));
+        }
+    } else if (!p.min_tangent_inliers &&
+               detail::deferred_batches(be, detail::has_search_batches<Backend>{})) {
+        /* the chunks' batches are gathered first (sampling on the host), scored in ONE call, then every chunk takes
+         * its first batch with a sufficient hypothesis: the reference runs the chunks on concurrent threads */
+        std::vector<std::vector<uint32_t>> chunks, batches;
+        std::vector<uint32_t> cons_of, first_batch_of;
+        for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) {
+            chunks.emplace_back(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
+            first_batch_of.push_back((uint32_t)batches.size());
+            auto res = find_in_subset(be, chunks.back(), mask, fp_mask, tangent_mask, p, &batches);
+            cons_of.push_back(res.second);
+        }
+        first_batch_of.push_back((uint32_t)batches.size());
+        std::vector<char> found;
+        std::vector<pose_t> poses;
+        {
+            TM_TIMED(generate_score);
+            detail::run_batches(be, batches, be.model_diameter(), p.early_drop,
+                                p.accept_prob * (float)n_model_all, found, poses, detail::has_search_batches<Backend>{});
+        }
+        for (size_t ci = 0; ci < chunks.size(); ++ci) {
+            for (uint32_t k = 0, seen = 0; k < chunks[ci].size() && seen < cons_of[ci]; ++k, ++seen)
+                fp_mask[chunks[ci][k]] = 1; /* :160-162 */
+            for (uint32_t b = first_batch_of[ci]; b < first_batch_of[ci + 1]; ++b)
+                if (found[b]) {
+                    candidate_t c;
+                    {
+                        TM_TIMED(extract);
+                        be.extract(poses[b], p.dist_thres, c); /* :361-364 */
+                    }
+                    cands.push_back(icp(be, c, p)); /* :169-171 */
+                    break;
+                }
         }
     } else
     for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) { /* chunks, :156-166 (run one after another) */

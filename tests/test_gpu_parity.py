@@ -955,6 +955,19 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+    # several batches in one call (the chunks of a round) == one call per batch, also with an empty batch
+    offs = np.array([0, 7, 7, 30, 64, len(pairs)], np.uint32)
+    for early_drop in (True, False):
+        for sufficient in (float(np.median(order)), float(order[-2]), 1e9):
+            many = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
+            assert len(many) == len(offs) - 1
+            for b, got in enumerate(many):
+                one = gs.search_batch(gm, pairs[offs[b]:offs[b + 1]], diam, DT, 0.5, early_drop, sufficient,
+                                      min_diameter_factor=0.2)
+                assert got[:5] == one[:5], (early_drop, sufficient, b)
+                if one[0] >= 0:
+                    assert np.array_equal(got[5], one[5])
+            assert many[1][0] == -1 and many[1][1] == 0
     # degenerate batches
     assert gs.search_batch(gm, np.zeros((0, 2), np.uint32), diam, DT, 0.5, True, 0.0)[0] == -1
     with pytest.raises(capi.TmError):

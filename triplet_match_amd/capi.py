@@ -111,6 +111,8 @@ SIGNATURES = {
                                                      u32p, f64p, i32p, u32p]),
     "tm_search_batch": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                   C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(BatchResult)]),
+    "tm_search_batches": (C.c_int, [vp, vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
+                                    C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(BatchResult)]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
@@ -732,6 +734,19 @@ class Scene:
                                      1 if force_up else 0, query_limit, radius, dist_thres, accept_prob,
                                      1 if early_drop else 0, sufficient, C.byref(r)))
         return r.index, r.n_hypotheses, r.count, r.dropped_at, r.score, np.array(r.pose, np.float32)
+
+    def search_batches(self, model, ij_pairs, batch_offsets, radius, dist_thres, accept_prob, early_drop, sufficient,
+                       min_diameter_factor=0.0, max_diameter_factor=1.0, force_up=False, query_limit=200):
+        """Several independent batches in one call: list of (index or -1, n_hypotheses, count, dropped_at, score,
+        pose16) per batch"""
+        ij, pij = _u(np.asarray(ij_pairs).reshape(-1))
+        off, poff = _u(batch_offsets)
+        nb = off.size - 1
+        res = (BatchResult * nb)()
+        _check(lib().tm_search_batches(self.h, model.h, pij, ij.size // 2, poff, nb, min_diameter_factor,
+                                       max_diameter_factor, 1 if force_up else 0, query_limit, radius, dist_thres,
+                                       accept_prob, 1 if early_drop else 0, sufficient, res))
+        return [(r.index, r.n_hypotheses, r.count, r.dropped_at, r.score, np.array(r.pose, np.float32)) for r in res]
 
     def icp_refine(self, model, pose16, dist_thres, max_iterations):
         """icp_ on the device: (pose16, count, iterations)"""

@@ -1040,7 +1040,15 @@ __global__ __launch_bounds__(1024) void k_segment_first(const uint32_t* __restri
  * (s->ed_dropped) and the saved evaluations (s->ed_saved) on the device, launched on the context's stream. */
 static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t n_hyp, const uint32_t* uniq,
                         uint32_t n_slots, float radius, float dist_thres, float accept_prob, uint32_t segment = 0,
-                        float sufficient = 0.f, uint32_t* d_found = nullptr) {
+                        float sufficient = 0.f, uint32_t* d_found = nullptr, const uint32_t* range_starts = nullptr,
+                        uint32_t n_ranges = 0) {
+    /* range_starts (n_ranges + 1 hypothesis offsets, host): independent batches, each with its own word of
+     * d_found and its own segments; null = one batch, all hypotheses */
+    const uint32_t one_range[2] = {0u, n_hyp};
+    if (!range_starts) {
+        range_starts = one_range;
+        n_ranges = 1;
+    }
     tm_ctx* c = s->ctx;
     const uint32_t mwords = (s->n + 63) / 64;
     dbuf<uint32_t>&d_slot = s->ed_slot, &d_cent = s->ed_centres, &d_wprefix = s->ed_wprefix, &d_S = s->ed_S,
@@ -1155,14 +1163,16 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         /* tm_search_batch: only the first sufficient hypothesis in visit order is wanted (reference :330-338: later
          * ones are scored without effect). The hypotheses go through in segments; after each, *d_found takes the
          * first sufficient index of the segment, and the kernels of all later segments leave at once. */
-        a.stop = d_found;
-        for (uint32_t h0 = 0; h0 < n_hyp; h0 += segment) {
-            const uint32_t nh = std::min(segment, n_hyp - h0);
-            a.h0 = h0;
-            TM_HIP_CHECK(launch_ed_fused(s, c, nh, fused_lds, a, cu, o, accept_thresh, d_tests.p, std::min(chunk, nh)));
-            hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, h0, h0 + nh,
-                               sufficient, d_found);
-            TM_HIP_CHECK(hipGetLastError());
+        for (uint32_t b = 0; b < n_ranges; ++b) {
+            a.stop = d_found + b;
+            for (uint32_t h0 = range_starts[b]; h0 < range_starts[b + 1]; h0 += segment) {
+                const uint32_t nh = std::min(segment, range_starts[b + 1] - h0);
+                a.h0 = h0;
+                TM_HIP_CHECK(launch_ed_fused(s, c, nh, fused_lds, a, cu, o, accept_thresh, d_tests.p, std::min(chunk, nh)));
+                hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, h0, h0 + nh,
+                                   sufficient, d_found + b);
+                TM_HIP_CHECK(hipGetLastError());
+            }
         }
     } else if (fused) {
         /* the whole batch at once: with ~2 % of 65,536 hypotheses pending the wide continuation has over a
@@ -1189,9 +1199,10 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         hipLaunchKernelGGL(k_ed_score, dim3((S_max + 255) / 256, nh), dim3(256), 0, c->stream, as, d_limit.p);
         TM_HIP_CHECK(hipGetLastError());
     }
-    if (d_found && !(fused && segment)) { /* no segments were used: the one look over the whole batch */
-        hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, 0u, n_hyp, sufficient,
-                           d_found);
+    if (d_found && !(fused && segment)) { /* no segments were used: one look over every batch */
+        for (uint32_t b = 0; b < n_ranges; ++b)
+            hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, range_starts[b],
+                               range_starts[b + 1], sufficient, d_found + b);
         TM_HIP_CHECK(hipGetLastError());
     }
     return TM_OK;
@@ -1262,12 +1273,13 @@ __global__ void __launch_bounds__(1024)
 k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ fx,
                    const double* __restrict__ scores, const int32_t* __restrict__ dropped, uint32_t n_hyp,
                    float sufficient, double n_model, const float* __restrict__ poses, tm_batch_result* out,
-                   const uint32_t* __restrict__ found = nullptr) {
+                   const uint32_t* __restrict__ found = nullptr, uint32_t h0 = 0) {
+    /* the batch is hypotheses [h0, h0 + n_hyp) of the arrays; the record's index counts from h0 */
     __shared__ uint32_t s_first;
     if (threadIdx.x == 0) s_first = found ? *found : 0xFFFFFFFFu; /* found: the segments have already looked */
     __syncthreads();
     uint32_t first = 0xFFFFFFFFu;
-    for (uint32_t h = threadIdx.x; h < (found ? 0u : n_hyp); h += blockDim.x) {
+    for (uint32_t h = h0 + threadIdx.x; h < (found ? 0u : h0 + n_hyp); h += blockDim.x) {
         const bool positive = fx ? fx[h] != 0ull : scores[h] > 0.0;
         if (positive && (float)counts[h] > sufficient) {
             first = h;
@@ -1278,7 +1290,7 @@ k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t h = s_first;
-        out->index = h == 0xFFFFFFFFu ? -1 : (int32_t)h;
+        out->index = h == 0xFFFFFFFFu ? -1 : (int32_t)(h - h0);
         out->n_hypotheses = n_hyp;
         out->count = 0;
         out->dropped_at = -1;
@@ -1299,47 +1311,81 @@ k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long
 
 }  // namespace tmx
 
-extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs, float minf,
-                               float maxf, int force_up, int query_limit, float radius, float dist_thres,
-                               float accept_prob, int early_drop, float sufficient, tm_batch_result* out) {
-    TM_REQUIRE(s && m && out, TM_ERR_INVALID, "tm_search_batch: null argument");
+namespace tmx {
+/* first hypothesis of every batch: provenance word 0 = pair index, ascending; starts[b] = first hypothesis whose
+ * pair is >= pair_offsets[b] */
+__global__ void k_batch_starts(const uint4* __restrict__ prov, uint32_t n_hyp, const uint32_t* __restrict__ pair_offsets,
+                               uint32_t n_batches, uint32_t* __restrict__ starts) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_batches) return;
+    const uint32_t want = pair_offsets[b];
+    uint32_t lo = 0, hi = n_hyp;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prov[mid].x < want) lo = mid + 1; else hi = mid;
+    }
+    starts[b] = lo;
+}
+}  // namespace tmx
+
+extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs,
+                                 const uint32_t* batch_offsets, uint32_t n_batches, float minf, float maxf, int force_up,
+                                 int query_limit, float radius, float dist_thres, float accept_prob, int early_drop,
+                                 float sufficient, tm_batch_result* out) {
+    TM_REQUIRE(s && m && out && batch_offsets, TM_ERR_INVALID, "tm_search_batches: null argument");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
-    TM_REQUIRE(query_limit > 0, TM_ERR_INVALID, "tm_search_batch: query_limit must be positive");
+    TM_REQUIRE(query_limit > 0, TM_ERR_INVALID, "tm_search_batches: query_limit must be positive");
     TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
-    memset(out, 0, sizeof(*out));
-    out->index = -1;
-    out->dropped_at = -1;
+    TM_REQUIRE(n_batches >= 1 && batch_offsets[0] == 0 && batch_offsets[n_batches] == n_pairs, TM_ERR_INVALID,
+               "tm_search_batches: batch offsets must run from 0 to n_pairs");
+    for (uint32_t b = 0; b < n_batches; ++b)
+        TM_REQUIRE(batch_offsets[b] <= batch_offsets[b + 1], TM_ERR_INVALID, "tm_search_batches: batch offsets must ascend");
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        memset(&out[b], 0, sizeof(out[b]));
+        out[b].index = -1;
+        out[b].dropped_at = -1;
+    }
     if (n_pairs == 0) return m->pairs_ready ? TM_OK : TM_ERR_NOT_INITIALIZED;
-    TM_REQUIRE(ij_pairs, TM_ERR_INVALID, "tm_search_batch: null pairs");
-    TM_REQUIRE((uint64_t)n_pairs * (uint64_t)query_limit <= 0x7FFFFFFFull, TM_ERR_INVALID, "tm_search_batch: batch too large");
+    TM_REQUIRE(ij_pairs, TM_ERR_INVALID, "tm_search_batches: null pairs");
+    TM_REQUIRE((uint64_t)n_pairs * (uint64_t)query_limit <= 0x7FFFFFFFull, TM_ERR_INVALID, "tm_search_batches: too many pairs");
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
     /* distinct first points -> slots (ascending, as the per-hypothesis entry point numbers them) */
     std::vector<uint32_t> uniq, slot_of_pair(n_pairs);
     for (uint32_t p = 0; p < n_pairs; ++p) {
-        TM_REQUIRE(ij_pairs[2 * p] < s->n && ij_pairs[2 * p + 1] < s->n, TM_ERR_INVALID, "tm_search_batch: index out of range");
+        TM_REQUIRE(ij_pairs[2 * p] < s->n && ij_pairs[2 * p + 1] < s->n, TM_ERR_INVALID, "tm_search_batches: index out of range");
         uniq.push_back(ij_pairs[2 * p]);
     }
     std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     for (uint32_t p = 0; p < n_pairs; ++p)
-        slot_of_pair[p] = (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), ij_pairs[2 * p]) - uniq.begin());
+        slot_of_pair[p] = early_drop ? (uint32_t)(std::lower_bound(uniq.begin(), uniq.end(), ij_pairs[2 * p]) - uniq.begin())
+                                     : ij_pairs[2 * p]; /* full pass: the centre point itself */
     const uint32_t cap = n_pairs * (uint32_t)query_limit;
     TM_FORWARD(s->sb_ij.ensure((size_t)n_pairs * 2));
-    TM_FORWARD(s->sb_pair_slot.ensure(n_pairs));
+    TM_FORWARD(s->sb_pair_slot.ensure((size_t)n_pairs + n_batches + 1)); /* + the batches' pair offsets */
     TM_FORWARD(s->sb_prov.ensure(cap));
-    TM_FORWARD(s->sb_result.ensure(1));
+    TM_FORWARD(s->sb_result.ensure(n_batches));
+    TM_FORWARD(s->sb_centres.ensure((size_t)cap + 2 * (size_t)n_batches + 2)); /* centres | found words | batch starts */
     TM_FORWARD(s->w_poses.ensure((size_t)cap * 16));
     TM_HIP_CHECK(hipMemcpyAsync(s->sb_ij.p, ij_pairs, (size_t)n_pairs * 8, hipMemcpyHostToDevice, c->stream));
-    if (early_drop)
-        TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p, slot_of_pair.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice,
-                                    c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p, slot_of_pair.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p + n_pairs, batch_offsets, ((size_t)n_batches + 1) * 4, hipMemcpyHostToDevice,
+                                c->stream));
     uint32_t n_hyp = 0, total = 0;
     TM_FORWARD(tm_generate_hypotheses_dev(s, m, s->sb_ij.p, n_pairs, minf, maxf, force_up, query_limit, s->w_poses.p,
                                           (uint32_t*)s->sb_prov.p, cap, &n_hyp, &total));
-    out->n_hypotheses = n_hyp;
     if (n_hyp == 0) return TM_OK;
+    uint32_t* d_found = s->sb_centres.p + cap;
+    uint32_t* d_starts = d_found + n_batches + 1;
+    std::vector<uint32_t> starts((size_t)n_batches + 1);
+    hipLaunchKernelGGL(k_batch_starts, dim3((n_batches + 256) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
+                       s->sb_pair_slot.p + n_pairs, n_batches, d_starts);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipMemcpyAsync(starts.data(), d_starts, starts.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_found, 0xFF, (size_t)n_batches * 4, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (early_drop) {
         TM_FORWARD(s->ed_slot.ensure(n_hyp));
         hipLaunchKernelGGL(k_batch_slots, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
@@ -1348,40 +1394,40 @@ extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pair
         /* segments of 2048 hypotheses (one resident round of the prefix kernel); TM_SEARCH_SEGMENT=0: all at once */
         const char* seg_env = getenv("TM_SEARCH_SEGMENT");
         const uint32_t segment = seg_env ? (uint32_t)atoi(seg_env) : 2048u;
-        uint32_t* d_found = nullptr;
-        if (segment) {
-            TM_FORWARD(s->sb_centres.ensure(1)); /* unused by this branch otherwise: holds the found index */
-            d_found = s->sb_centres.p;
-            TM_HIP_CHECK(hipMemsetAsync(d_found, 0xFF, 4, c->stream));
-        }
         TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
-                                accept_prob, segment, sufficient, d_found));
-        hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
-                           (const double*)nullptr, s->ed_dropped.p, n_hyp, sufficient, (double)m->n, s->w_poses.p,
-                           s->sb_result.p, (const uint32_t*)d_found);
+                                accept_prob, segment, sufficient, d_found, starts.data(), n_batches));
+        for (uint32_t b = 0; b < n_batches; ++b)
+            hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
+                               (const double*)nullptr, s->ed_dropped.p, starts[b + 1] - starts[b], sufficient, (double)m->n,
+                               s->w_poses.p, s->sb_result.p + b, (const uint32_t*)(d_found + b), starts[b]);
     } else {
-        /* centre of a hypothesis = first point of its pair: the pairs' first words, indexed through the slots */
-        TM_FORWARD(s->sb_centres.ensure(n_hyp));
+        /* full pass: centre of a hypothesis = first point of its pair */
         TM_FORWARD(s->w_counts.ensure(n_hyp));
         TM_FORWARD(s->w_scores.ensure(n_hyp));
-        std::vector<uint32_t> first_of_pair(n_pairs);
-        for (uint32_t p = 0; p < n_pairs; ++p) first_of_pair[p] = ij_pairs[2 * p];
-        TM_HIP_CHECK(hipMemcpyAsync(s->sb_pair_slot.p, first_of_pair.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice,
-                                    c->stream));
-        TM_HIP_CHECK(hipStreamSynchronize(c->stream)); /* first_of_pair leaves scope */
         hipLaunchKernelGGL(k_batch_slots, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->sb_prov.p, n_hyp,
                            s->sb_pair_slot.p, s->sb_centres.p);
         TM_HIP_CHECK(hipGetLastError());
         TM_FORWARD(tm_score_hypotheses_ball_dev(s, m, s->w_poses.p, n_hyp, s->sb_centres.p, radius, dist_thres,
                                                 s->w_counts.p, s->w_scores.p));
-        hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p,
-                           (const unsigned long long*)nullptr, s->w_scores.p, (const int32_t*)nullptr, n_hyp, sufficient,
-                           (double)m->n, s->w_poses.p, s->sb_result.p);
+        for (uint32_t b = 0; b < n_batches; ++b)
+            hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p,
+                               (const unsigned long long*)nullptr, s->w_scores.p, (const int32_t*)nullptr,
+                               starts[b + 1] - starts[b], sufficient, (double)m->n, s->w_poses.p, s->sb_result.p + b,
+                               (const uint32_t*)nullptr, starts[b]);
     }
     TM_HIP_CHECK(hipGetLastError());
-    TM_HIP_CHECK(hipMemcpyAsync(out, s->sb_result.p, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(out, s->sb_result.p, sizeof(*out) * n_batches, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return TM_OK;
+}
+
+extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs, float minf,
+                               float maxf, int force_up, int query_limit, float radius, float dist_thres,
+                               float accept_prob, int early_drop, float sufficient, tm_batch_result* out) {
+    TM_REQUIRE(out, TM_ERR_INVALID, "tm_search_batch: null argument");
+    const uint32_t offsets[2] = {0u, n_pairs};
+    return tm_search_batches(s, m, ij_pairs, n_pairs, offsets, 1, minf, maxf, force_up, query_limit, radius, dist_thres,
+                             accept_prob, early_drop, sufficient, out);
 }
 
 namespace tmx {
