@@ -138,10 +138,25 @@ def main():
         if world > 1:
             t = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=cuda_dev)
             if rank == 0:
-                t = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device=cuda_dev)
+                try:
+                    t = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device=cuda_dev)
+                except Exception as e:
+                    log("[rank 0] tm_comm_get_unique_id failed (%s)" % e)  # all-zero id = fall back, below
             dist.broadcast(t, src=0)
             uid = bytes(t.cpu().numpy().tobytes())
-        comm = capi.Comm(ctx, rank, world, uid)
+        ok = 1
+        try:
+            if world > 1 and not any(uid):
+                raise RuntimeError("no RCCL unique id")
+            comm = capi.Comm(ctx, rank, world, uid)
+        except Exception as e:  # e.g. librccl.so not loadable: the same records then travel through torch.distributed
+            log("[rank %d] tm_comm_create failed (%s): falling back to torch.distributed for the record exchange" % (rank, e))
+            comm, ok = None, 0
+        if world > 1:  # all ranks take the same route
+            flag = torch.tensor([ok], dtype=torch.int32, device=cuda_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                comm = None
     d_best = ctx.alloc(96)
 
     class _Done:
@@ -161,7 +176,8 @@ def main():
                                query_limit=200)
         if comm is not None:
             return n, _Done(comm.best_reduce(d_best, 1)[0])
-        # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device): the same records over gloo
+        # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device) or no library communicator: the same
+        # records through torch.distributed
         rec = capi.BestRecord()
         ctx.d2h(np.frombuffer(rec, dtype=np.uint8), d_best)
         return n, tmd.allgather_best_async(rec, device=cuda_dev)
