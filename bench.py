@@ -49,7 +49,16 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the 96-byte exchange goes "
                          "over gloo (RCCL refuses two ranks on one device); not a measurement")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="plumbing check without a GPU: the ranks come up over gloo, exchange one synthetic best "
+                         "record each and rank 0 prints a line with \"selftest\": true and no value (tests/)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher around it: start the N ranks here. Nothing in this process has
+    # touched HIP yet (torch is not even imported), the ranks are fresh child processes, rank 0's JSON line is
+    # relayed and the children's status becomes ours.
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one JSON line: send everything libraries print there (gloo / RCCL banners,
     # compiler output) to stderr until the line is written
@@ -60,8 +69,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log("warning: WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
+    if world != args.gpus:  # a 1-GPU figure must never be recorded under "--gpus 8" (or the reverse)
+        log("FATAL: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); no line is printed" % (args.gpus, world))
+        sys.exit(2)
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world, real_stdout)
 
     import torch
     import torch.distributed as dist
@@ -130,53 +142,67 @@ def main():
 
     cuda_dev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
 
-    # the library's own RCCL communicator (C ABI: tm_comm_create / tm_best_reduce). torch.distributed only
-    # carries the 128-byte unique id to the other ranks, the barriers and the timing reduction.
+    # the library's own RCCL communicator (C ABI: tm_comm_create / tm_best_reduce_begin / _end). torch.distributed
+    # only carries the 128-byte unique id to the other ranks, the barriers and the timing reduction.
+    # Order matters: (1) every rank probes whether RCCL is usable and the ranks agree on it, (2) rank 0 makes the id,
+    # (3) only then do all ranks enter the collective tm_comm_create — a rank that cannot load librccl never leaves
+    # the others waiting inside ncclCommInitRank.
     comm = None
-    if not args.rehearse_on_one_gpu:
-        uid = None
-        if world > 1:
-            t = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=cuda_dev)
-            if rank == 0:
-                try:
-                    t = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device=cuda_dev)
-                except Exception as e:
-                    log("[rank 0] tm_comm_get_unique_id failed (%s)" % e)  # all-zero id = fall back, below
-            dist.broadcast(t, src=0)
-            uid = bytes(t.cpu().numpy().tobytes())
-        ok = 1
-        try:
-            if world > 1 and not any(uid):
-                raise RuntimeError("no RCCL unique id")
-            comm = capi.Comm(ctx, rank, world, uid)
-        except Exception as e:  # e.g. librccl.so not loadable: the same records then travel through torch.distributed
-            log("[rank %d] tm_comm_create failed (%s): falling back to torch.distributed for the record exchange" % (rank, e))
-            comm, ok = None, 0
-        if world > 1:  # all ranks take the same route
-            flag = torch.tensor([ok], dtype=torch.int32, device=cuda_dev)
+    comm_route = "single_process"
+    if world > 1:
+        comm_route = "torch_fallback"
+    if not args.rehearse_on_one_gpu and world > 1:
+        ok = 1 if capi.comm_probe() else 0
+        t = torch.zeros(capi.COMM_ID_BYTES + 1, dtype=torch.uint8, device=cuda_dev)
+        if rank == 0 and ok:
+            try:
+                t[:capi.COMM_ID_BYTES] = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8)
+                t[capi.COMM_ID_BYTES] = 1
+            except Exception as e:
+                log("[rank 0] tm_comm_get_unique_id failed (%s)" % e)
+        dist.broadcast(t, src=0)
+        have_id = int(t[capi.COMM_ID_BYTES].item())
+        flag = torch.tensor([ok & have_id], dtype=torch.int32, device=cuda_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            uid = bytes(t[:capi.COMM_ID_BYTES].cpu().numpy().tobytes())
+            try:
+                comm = capi.Comm(ctx, rank, world, uid)
+            except Exception as e:  # past the probe this is a real RCCL failure: say so, then agree on the fallback
+                log("[rank %d] tm_comm_create failed (%s)" % (rank, e))
+                comm = None
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=cuda_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 comm = None
+        else:
+            log("[rank %d] RCCL not usable on every rank (probe here: %d): the records travel through torch.distributed"
+                % (rank, ok))
+        if comm is not None:
+            comm_route = "tm_best_reduce"
+    comm_world = int(capi.lib().tm_comm_world(comm.h)) if comm is not None else 1
     d_best = ctx.alloc(96)
 
-    class _Done:
-        def __init__(self, rec):
-            self._rec = rec
+    class _First:
+        def __init__(self, pending):
+            self._p = pending
 
         def result(self):
-            return self._rec
+            return self._p.result()[0]
 
     def step():
         n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
         gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
         # local argmax on the device with ids that do not depend on the number of ranks (global sample pair
-        # index * query_limit + entry), then ONE ncclAllGather of the 96-byte records on the library's stream
-        # and the deterministic selection (tm_best_reduce): no host hop for the payload
+        # index * query_limit + entry), then ONE ncclAllGather of the 96-byte records on the library's stream,
+        # the deterministic selection and an asynchronous copy of the winner into pinned memory
+        # (tm_best_reduce_begin): nothing here waits for the GPU. The wait (tm_best_reduce_end) happens in
+        # .result(), which the timed loop calls only after the NEXT batch has been queued.
         ctx.best_of_batch_prov(d_counts, d_scores, d_poses, d_prov, n, d_best, pair_offset=rank, pair_stride=world,
                                query_limit=200)
-        if comm is not None:
-            return n, _Done(comm.best_reduce(d_best, 1)[0])
-        # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device) or no library communicator: the same
+        if comm is not None or world == 1:
+            return n, _First(capi.best_reduce_begin(ctx, comm, d_best, 1))
+        # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device) or no usable RCCL: the same
         # records through torch.distributed
         rec = capi.BestRecord()
         ctx.d2h(np.frombuffer(rec, dtype=np.uint8), d_best)
@@ -191,8 +217,8 @@ def main():
     for _ in range(args.warmup):
         step()[1].result()
     # kernel timing = HIP events recorded on the library's own stream around each scoring launch, and the
-    # kernel's own counters reduced on the device; both are read AFTER the timed region (no host
-    # synchronisation or copy inside it)
+    # kernel's own counters reduced on the device; both are read AFTER the timed region. Inside it the host
+    # waits once per step, for the PREVIOUS step's 96-byte winner (an event behind its pinned copy).
     ctx.enable_timing(True)
     hyps = 0
     sync_all()
@@ -215,7 +241,12 @@ def main():
         log("warning: %d timed scoring launches for %d steps" % (tot["launches"], args.steps))
     evals, passing = tot["evaluations"], tot["passing"]
 
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
     if world > 1:
+        mine = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=cuda_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(x.item()), 3) for x in every]
         t = torch.tensor([elapsed], dtype=torch.float64, device=cuda_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -303,6 +334,7 @@ def main():
                        % (args.model_points, args.scene_points, H),
                        "hypotheses_per_batch_scored": int(hyps / args.steps), "dist_thres": DIST_THRES,
                        "query_limit": 200, "score_mode": args.mode, "parallelism": "hyp-shard x%d" % world},
+            "comm_route": comm_route, "comm_world": comm_world, "per_rank_ms_per_step": per_rank_ms,
             "gpoints_per_s": round(evals_all / elapsed / 1e9, 2),
             "best": {"inlier_count": int(best.inlier_count), "hyp_id": int(best.hyp_id)},
             "roofline": roofline,
@@ -317,6 +349,44 @@ def main():
             if world > 1:
                 dist.destroy_process_group()
             sys.exit(3)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def launch_ranks(n, argv):
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child process (this
+    process has not touched the GPU), passes rank 0's stdout through and returns the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args, rank, world, real_stdout):
+    """No GPU, no kernels, no figure: checks that N ranks come up, agree on a best record over gloo and that rank
+    0 alone prints the line. Used by tests/test_distributed.py to cover the `--gpus N` launcher path on the CPU."""
+    import torch.distributed as dist
+    from triplet_match_amd import dist as tmd
+    if world > 1:
+        dist.init_process_group("gloo")
+    rec = tmd.make_record(100 + rank, 7 * rank + 1, 0.5, [float(rank)] * 16)
+    best = tmd.allgather_best(rec) if world > 1 else rec
+    if rank == 0:
+        out = {"selftest": True, "metric": "launcher self-test (no measurement)", "value": None, "n_gpus": world,
+               "best": {"inlier_count": int(best.inlier_count), "hyp_id": int(best.hyp_id)},
+               "comm_route": "gloo_selftest", "comm_world": world}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

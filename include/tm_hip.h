@@ -355,6 +355,15 @@ int tm_best_of_batch_prov(tm_ctx* ctx, const uint32_t* d_counts, const double* d
  * global winners (host), identical on every rank. comm may be null (single process). */
 int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models,
                    tm_best_record* best);
+/* The same in two halves, so that the exchange overlaps the next batch: _begin queues all-gather, selection and
+ * the copy into pinned host memory on the context's stream and returns a ticket without waiting (at most 4 in
+ * flight per context, TM_ERR_CAPACITY beyond); _end waits for that reduction alone and hands out the winners.
+ * Counterpart in the reference: fut.get() of the worker futures, include/impl/scene.hpp:168-171. */
+int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models, int* ticket);
+int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best);
+/* TM_OK when RCCL can be used by this process (loaded, entry points bound), TM_ERR_UNSUPPORTED otherwise. Not a
+ * collective: ranks exchange the answers over their bootstrap channel before any of them calls tm_comm_create. */
+int tm_comm_probe(void);
 /* collective all-gather of host records (find_parallel's per-chunk candidates): all[r * n + k] */
 int tm_comm_allgather_records(tm_comm* comm, const tm_best_record* local, uint32_t n, tm_best_record* all);
 

@@ -197,3 +197,38 @@ def test_two_rank_gloo_multi_model_reduce(tmp_path, n_models):
         exp = sorted([l0[m], l1[m]], key=lambda r: (-r[0], -r[2], r[1]))[0]
         assert np.array_equal(b0[m], exp)
         assert b0[m][0] > 400  # every model finds its own instance
+
+
+# ---- bench.py's own launcher (`python bench.py --gpus N` without torchrun around it) ----
+def _run_bench(argv, env_extra=None, drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts the two ranks before
+    anything touches a GPU, rank 0's single JSON line comes through, n_gpus is 2. (--launcher-selftest: the ranks
+    exchange a synthetic record over gloo instead of running kernels — there is no GPU here.)"""
+    import json
+    r = _run_bench(["--gpus", "2", "--launcher-selftest"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm_world"] == 2 and out["selftest"] is True
+    assert out["best"] == {"inlier_count": 101, "hyp_id": 8}  # rank 1's record wins on the count
+    assert out["value"] is None  # a self-test never carries a figure
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 8 under a launcher that started one rank (or the reverse) must not print a 1-GPU line."""
+    r = _run_bench(["--gpus", "8", "--launcher-selftest"],
+                   env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode == 2 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert "--gpus 8" in r.stderr
+    r = _run_bench(["--gpus", "1", "--launcher-selftest"],
+                   env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode == 2 and r.stdout.strip() == ""

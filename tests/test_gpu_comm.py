@@ -90,3 +90,56 @@ def test_allgather_records_single_rank(gpu_ctx):
         recs.append(r)
     out = comm.allgather_records(recs)
     assert [bytes(a) for a in out] == [bytes(b) for b in recs]
+
+
+@pytest.mark.parametrize("route", ["no_comm", "one_rank_rccl"])
+def test_best_reduce_in_two_halves_overlaps_and_is_bounded(gpu_ctx, scored, route):
+    """tm_best_reduce_begin / _end: begin returns without waiting, several reductions may be in flight and are
+    handed out in any order, the fifth begin without an end is refused (TM_ERR_CAPACITY), a ticket is good once."""
+    comm = capi.Comm(gpu_ctx, 0, 1, capi.comm_unique_id()) if route == "one_rank_rccl" else None
+    d_counts, d_scores, d_poses, d_prov = scored["d"]
+    d_best = [gpu_ctx.alloc(96) for _ in range(4)]
+    params = [(0, 1), (3, 8), (1, 2), (5, 7)]
+    pend = []
+    for d, (off, stride) in zip(d_best, params):
+        gpu_ctx.best_of_batch_prov(d_counts, d_scores, d_poses, d_prov, scored["n"], d, pair_offset=off,
+                                   pair_stride=stride)
+        pend.append(capi.best_reduce_begin(gpu_ctx, comm, d, 1))
+    with pytest.raises(capi.TmError) as e:
+        capi.best_reduce_begin(gpu_ctx, comm, d_best[0], 1)
+    assert e.value.code == capi.ERR_CAPACITY
+    for k in (2, 0, 3, 1):
+        best = pend[k].result()[0]
+        cnt, hid, sc, _ = _expected(scored, *params[k])
+        assert (best.inlier_count, best.hyp_id, best.score) == (cnt, hid, sc)
+    out = (capi.BestRecord * 1)()
+    assert capi.lib().tm_best_reduce_end(gpu_ctx.h, pend[0].ticket, out) == capi.ERR_INVALID
+    # the slots are free again
+    assert capi.best_reduce_begin(gpu_ctx, comm, d_best[0], 1).result()[0].inlier_count == _expected(scored, 0, 1)[0]
+    assert capi.comm_probe() is True
+    if comm is not None:
+        comm.close()
+
+
+def test_library_communicator_before_torch_exits_cleanly():
+    """The order that once ended in `double free or corruption (!prev)` at interpreter exit (round 2,
+    gpurun_out/r02_gputests_full{,2,3,4}.log): the library dlopens RCCL first, torch (which brings its own copy)
+    is imported afterwards. librccl is now loaded RTLD_LOCAL (csrc/tm_comm.hip), so nothing interposes: the child
+    must leave with exit code 0, not a signal."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from triplet_match_amd import capi\n"
+            "ctx = capi.Context(0)\n"
+            "comm = capi.Comm(ctx, 0, 1, capi.comm_unique_id())\n"
+            "assert 'torch' not in sys.modules\n"
+            "import torch\n"
+            "x = torch.ones(8, device='cuda').sum().item()\n"
+            "assert x == 8.0\n"
+            "comm.close()\n"
+            "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    assert r.stdout.strip().endswith("ok")

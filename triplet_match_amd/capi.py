@@ -129,6 +129,9 @@ SIGNATURES = {
     "tm_comm_world": (C.c_int, [vp]),
     "tm_best_of_batch_prov": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
     "tm_best_reduce": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(BestRecord)]),
+    "tm_best_reduce_begin": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_int)]),
+    "tm_best_reduce_end": (C.c_int, [vp, C.c_int, C.POINTER(BestRecord)]),
+    "tm_comm_probe": (C.c_int, []),
     "tm_comm_allgather_records": (C.c_int, [vp, C.POINTER(BestRecord), C.c_uint32, C.POINTER(BestRecord)]),
     "tm_traits_init_from_samples": (C.c_int, [C.c_int, f32p, f32p, f32p]),
     "tm_traits_project": (C.c_int, [C.c_int, f32p, f32p, f32p]),
@@ -404,6 +407,33 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def comm_probe():
+    """True when RCCL can be used by this process (tm_comm_probe); ranks exchange this before Comm(...)."""
+    return lib().tm_comm_probe() == OK
+
+
+class PendingReduce:
+    """A tm_best_reduce in flight (tm_best_reduce_begin); result() = tm_best_reduce_end."""
+
+    def __init__(self, ctx, ticket, n_models):
+        self.ctx, self.ticket, self.n = ctx, ticket, n_models
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            out = (BestRecord * self.n)()
+            _check(lib().tm_best_reduce_end(self.ctx.h, self.ticket, out))
+            self._out = [BestRecord.from_buffer_copy(bytes(out[k])) for k in range(self.n)]
+        return self._out
+
+
+def best_reduce_begin(ctx, comm, d_local, n_models=1):
+    """Queues all-gather (comm may be None = single process) + selection + copy to pinned memory; no wait."""
+    t = C.c_int(-1)
+    _check(lib().tm_best_reduce_begin(ctx.h, comm.h if comm is not None else None, d_local, n_models, C.byref(t)))
+    return PendingReduce(ctx, t.value, n_models)
+
+
 class Comm:
     """RCCL communicator of the C ABI (tm_comm): one per process / GPU. Collective constructor."""
 
@@ -430,6 +460,9 @@ class Comm:
         out = (BestRecord * n_models)()
         _check(lib().tm_best_reduce(self.ctx.h, self.h, d_local, n_models, out))
         return [BestRecord.from_buffer_copy(bytes(out[k])) for k in range(n_models)]
+
+    def best_reduce_begin(self, d_local, n_models=1):
+        return best_reduce_begin(self.ctx, self, d_local, n_models)
 
     def allgather_records(self, records):
         n = len(records)

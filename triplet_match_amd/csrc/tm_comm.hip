@@ -168,7 +168,7 @@ struct tm_comm {
     tm_ctx* ctx = nullptr;
     int rank = 0, world = 1;
     tmx::rccl_comm_t comm = nullptr;
-    tmx::dbuf<tm_best_record> d_local, d_all, d_best;
+    tmx::dbuf<tm_best_record> d_local, d_all;
 };
 
 using namespace tmx;
@@ -225,7 +225,6 @@ int tm_comm_destroy(tm_comm* c) {
         (void)hipStreamSynchronize(c->ctx->stream);
         c->d_local.release();
         c->d_all.release();
-        c->d_best.release();
         if (c->comm) (void)rccl().CommDestroy(c->comm);
     }
     delete c;
@@ -249,45 +248,81 @@ int tm_best_of_batch_prov(tm_ctx* c, const uint32_t* d_counts, const double* d_s
     return TM_OK;
 }
 
-/* device records in, host records out: all-gather on the context's stream (no host hop for the payload),
- * selection kernel, one copy of n_models x 96 bytes back */
-int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models,
-                   tm_best_record* best) {
-    TM_REQUIRE(ctx && d_local && best, TM_ERR_INVALID, "tm_best_reduce: null argument");
-    TM_REQUIRE(n_models >= 1, TM_ERR_INVALID, "tm_best_reduce: no records");
-    TM_REQUIRE(!comm || comm->ctx == ctx, TM_ERR_INVALID, "tm_best_reduce: communicator of another context");
+/* RCCL usable in this process? (librccl.so.1 loaded and the entry points bound.) Ranks agree on the answer
+ * BEFORE any of them enters the collective tm_comm_create, so that a rank without RCCL cannot leave the others
+ * waiting inside ncclCommInitRank. */
+int tm_comm_probe(void) {
+    TM_REQUIRE(rccl().ok, TM_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded");
+    return TM_OK;
+}
+
+/* device records in, host records out, in two halves: _begin queues the all-gather on the context's stream (no
+ * host hop for the payload), the selection kernel and the copy of n_models x 96 bytes into pinned host memory,
+ * records an event and returns; _end waits for that event only. Between the two the caller may queue further
+ * work on the context (the next batch), which then overlaps the exchange. */
+int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models, int* ticket) {
+    TM_REQUIRE(ctx && d_local && ticket, TM_ERR_INVALID, "tm_best_reduce_begin: null argument");
+    TM_REQUIRE(n_models >= 1, TM_ERR_INVALID, "tm_best_reduce_begin: no records");
+    TM_REQUIRE(!comm || comm->ctx == ctx, TM_ERR_INVALID, "tm_best_reduce_begin: communicator of another context");
+    *ticket = -1;
     TM_HIP_CHECK(hipSetDevice(ctx->device));
+    reduce_slot& slot = ctx->red[ctx->red_next % kReduceSlots];
+    TM_REQUIRE(!slot.busy, TM_ERR_CAPACITY, "tm_best_reduce_begin: too many reductions in flight (tm_best_reduce_end first)");
+    const size_t bytes = (size_t)n_models * sizeof(tm_best_record);
+    if (slot.bytes < bytes) {
+        if (slot.pinned) (void)hipHostFree(slot.pinned);
+        slot.pinned = nullptr;
+        slot.bytes = 0;
+        TM_HIP_CHECK(hipHostMalloc(&slot.pinned, bytes, hipHostMallocDefault));
+        slot.bytes = bytes;
+    }
+    if (!slot.ev) TM_HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
     const uint32_t world = comm ? (uint32_t)comm->world : 1u;
     const tm_best_record* d_all = d_local;
     if (comm && comm->comm) {
-        TM_FORWARD(comm->d_all.ensure((size_t)world * n_models));
-        TM_RCCL_CHECK(rccl().AllGather(d_local, comm->d_all.p, (size_t)n_models * sizeof(tm_best_record), 1 /* ncclUint8 */,
-                                       comm->comm, ctx->stream));
+        if (comm->d_all.n < (size_t)world * n_models) { /* growing frees the old buffer: let its readers finish */
+            TM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            TM_FORWARD(comm->d_all.alloc((size_t)world * n_models));
+        }
+        TM_RCCL_CHECK(rccl().AllGather(d_local, comm->d_all.p, bytes, 1 /* ncclUint8 */, comm->comm, ctx->stream));
         d_all = comm->d_all.p;
     } else {
         TM_REQUIRE(world == 1, TM_ERR_INVALID, "tm_best_reduce: communicator without RCCL state");
     }
-    dbuf<tm_best_record> tmp;
-    tm_best_record* d_out;
-    if (comm) {
-        TM_FORWARD(comm->d_best.ensure(n_models));
-        d_out = comm->d_best.p;
-    } else {
-        TM_FORWARD(tmp.alloc(n_models));
-        d_out = tmp.p;
+    if (ctx->red_out.n < n_models) {
+        TM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        TM_FORWARD(ctx->red_out.alloc(n_models));
     }
     hipLaunchKernelGGL(k_best_select, dim3((n_models + 63) / 64), dim3(64), 0, ctx->stream, d_all, world, n_models,
-                       d_out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(best, d_out, (size_t)n_models * sizeof(tm_best_record), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    tmp.release();
-    if (e != hipSuccess) {
-        set_error("tm_best_reduce: %s", hipGetErrorString(e));
-        return TM_ERR_HIP;
-    }
+                       ctx->red_out.p);
+    TM_HIP_CHECK(hipGetLastError());
+    TM_HIP_CHECK(hipMemcpyAsync(slot.pinned, ctx->red_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TM_HIP_CHECK(hipEventRecord(slot.ev, ctx->stream));
+    slot.n = n_models;
+    slot.busy = true;
+    *ticket = (int)(ctx->red_next % kReduceSlots);
+    ++ctx->red_next;
     return TM_OK;
+}
+
+int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best) {
+    TM_REQUIRE(ctx && best, TM_ERR_INVALID, "tm_best_reduce_end: null argument");
+    TM_REQUIRE(ticket >= 0 && ticket < kReduceSlots && ctx->red[ticket].busy, TM_ERR_INVALID,
+               "tm_best_reduce_end: no reduction in flight under this ticket");
+    reduce_slot& slot = ctx->red[ticket];
+    slot.busy = false;
+    TM_HIP_CHECK(hipEventSynchronize(slot.ev));
+    memcpy(best, slot.pinned, (size_t)slot.n * sizeof(tm_best_record));
+    return TM_OK;
+}
+
+/* both halves in one call */
+int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models,
+                   tm_best_record* best) {
+    TM_REQUIRE(best, TM_ERR_INVALID, "tm_best_reduce: null argument");
+    int ticket = -1;
+    TM_FORWARD(tm_best_reduce_begin(ctx, comm, d_local, n_models, &ticket));
+    return tm_best_reduce_end(ctx, ticket, best);
 }
 
 /* host records in, host records out (the candidates of find_parallel's chunks): staged through the device

@@ -113,6 +113,11 @@ int tm_ctx_destroy(tm_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->scratch.release();
     c->stats.release();
+    c->red_out.release();
+    for (reduce_slot& r : c->red) {
+        if (r.pinned) (void)hipHostFree(r.pinned);
+        if (r.ev) (void)hipEventDestroy(r.ev);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);

@@ -77,6 +77,17 @@ struct score_timing {
 constexpr int kTimedRing = 256;
 constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, staged items, 3 spare */
 
+/* One tm_best_reduce in flight (tm_best_reduce_begin .. _end): the winners land in pinned host memory behind an
+ * event, so the caller can queue the next batch before it waits. */
+constexpr int kReduceSlots = 4;
+struct reduce_slot {
+    void* pinned = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    uint32_t n = 0;
+    bool busy = false;
+};
+
 }  // namespace tmx
 
 struct tm_ctx {
@@ -92,6 +103,9 @@ struct tm_ctx {
     uint64_t timed_evals_host[tmx::kTimedRing]; /* per ring row: evaluations known on the host (exhaustive kernel), else ~0 */
     tmx::dbuf<unsigned char> scratch;   /* rocprim temp storage */
     tmx::dbuf<unsigned long long> stats; /* device counters */
+    tmx::reduce_slot red[tmx::kReduceSlots]; /* tm_best_reduce_begin / _end */
+    tmx::dbuf<tm_best_record> red_out;        /* the selection kernel's output (stream-ordered reuse) */
+    uint32_t red_next = 0;
 };
 
 struct tm_model {
