@@ -61,6 +61,17 @@ int tm_device_alloc(tm_ctx* ctx, uint64_t bytes, void** d_ptr);
 int tm_device_free(tm_ctx* ctx, void* d_ptr);
 int tm_memcpy_h2d(tm_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+/* Switches of a context (cross-check kernels, timing comparisons; none changes a result). Every switch NAME is
+ * read once from the environment variable TM_<NAME IN UPPER CASE> inside tm_ctx_create; afterwards only these
+ * calls change it — no call of the path reads the environment. Names: debug_stats, debug_items, debug_times,
+ * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
+ * score_parts, score_slot_mib, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
+ * ed_wide, ed_bruteforce, ed_unfused, search_segment (DESIGN.md section 6 says what each selects).
+ * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
+ * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
+ * range: TM_ERR_INVALID. */
+int tm_ctx_set_option(tm_ctx* ctx, const char* name, int value);
+int tm_ctx_get_option(const tm_ctx* ctx, const char* name, int* value);
 /* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline). While timing is
  * on, every scoring launch records an event pair and one row of device counters; nothing is copied to the
  * host and nothing synchronises until one of the two read-out calls below (they synchronise the stream).

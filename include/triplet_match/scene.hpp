@@ -18,6 +18,20 @@ namespace triplet_match {
 
 namespace detail {
 
+/* Host-side cross-check switches of the search driver (three calls per batch instead of tm_search_batch, one call
+ * per chunk, the general subset call, the ICP loop on the host): same results either way. Read from the
+ * environment ONCE per process, on first use — never inside the search loops. */
+struct search_switches {
+    bool search_unfused, search_per_chunk, subset_general, icp_host_loop;
+};
+inline const search_switches& env_once() {
+    static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
+                                       std::getenv("TM_SEARCH_PER_CHUNK") != nullptr,
+                                       std::getenv("TM_SUBSET_GENERAL") != nullptr,
+                                       std::getenv("TM_ICP_HOST_LOOP") != nullptr};
+    return sw;
+}
+
 /* search.hpp backend over libtm_hip.so */
 template <typename Point>
 struct hip_backend {
@@ -137,7 +151,7 @@ struct hip_backend {
     }
     /* one batch of find_in_subset on the device (tm_search_batch); TM_SEARCH_UNFUSED=1: the three calls above
      * and below with the scan on the host (same results) */
-    bool supports_fused_batch() const { return getenv("TM_SEARCH_UNFUSED") == nullptr; }
+    bool supports_fused_batch() const { return !env_once().search_unfused; }
     bool search_batch(const std::vector<uint32_t>& ij, float radius, bool early_drop, float sufficient,
                       search::pose_t& pose) {
         tm_batch_result r;
@@ -151,7 +165,7 @@ struct hip_backend {
     }
     /* the batches of a whole find_parallel round in one call (tm_search_batches); TM_SEARCH_PER_CHUNK=1: one call
      * per batch as the chunks come */
-    bool supports_deferred_batches() const { return supports_fused_batch() && getenv("TM_SEARCH_PER_CHUNK") == nullptr; }
+    bool supports_deferred_batches() const { return supports_fused_batch() && !env_once().search_per_chunk; }
     void search_batches(const std::vector<std::vector<uint32_t>>& batches, float radius, bool early_drop,
                         float sufficient, std::vector<char>& found, std::vector<search::pose_t>& poses) {
         std::vector<uint32_t> ij, offsets(1, 0u);
@@ -207,7 +221,7 @@ struct hip_backend {
              * per pose (a list with a repeated point is refused and takes the general call) */
             int rc = TM_ERR_INVALID;
             if (n <= 65535u && !subset.empty() && (uint64_t)n * subset.size() <= (1ull << 28) &&
-                getenv("TM_SUBSET_GENERAL") == nullptr)
+                !env_once().subset_general)
                 rc = tm_score_hypotheses_on_points(s, m, &poses[0].m[0], n, subset.data(), (uint32_t)subset.size(),
                                                    p.dist_thres, counts.data(), scores.data());
             if (rc != TM_OK)
@@ -230,7 +244,7 @@ struct hip_backend {
         out.model_corrs.assign(mc_scratch.begin(), mc_scratch.begin() + count);
     }
     /* the whole ICP loop on the device (tm_icp_refine); TM_ICP_HOST_LOOP=1: one call per pass, fits on the host */
-    bool supports_icp_refine() const { return getenv("TM_ICP_HOST_LOOP") == nullptr; }
+    bool supports_icp_refine() const { return !env_once().icp_host_loop; }
     search::pose_t icp_refine(const search::pose_t& T, float dist_thres, uint32_t max_iterations) {
         search::pose_t out;
         uint32_t n = 0, it = 0;

@@ -75,13 +75,10 @@ def test_voxel_grid_full_size(gpu_ctx, full):
     if "sha256_exhaustive" in gold:
         assert sha == gold["sha256_exhaustive"]
     # kd-tree kernel == exhaustive kernel (same tie rule), whole table
-    os.environ["TM_VOXEL_BRUTEFORCE"] = "1"
-    try:
+    with gpu_ctx.option("voxel_bruteforce", 1):
         gb = capi.Model(gpu_ctx, full["model"], full["res"])
         gb.build_voxels()
         vb = gb.voxels()
-    finally:
-        del os.environ["TM_VOXEL_BRUTEFORCE"]
     assert np.array_equal(vox, vb)
     del vb
     gb.close()

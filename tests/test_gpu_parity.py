@@ -276,11 +276,8 @@ def test_early_drop_rule_bit_exact(gpu_small, oracle_small, small_case):
         cg, sg, dg, vg = gpu_small["scene"].score_hypotheses_early_drop(
             gpu_small["model"], poses, DT, 0.5, subset=subset)
         if subset is sub_shuffled:  # the tile-culled bit kernel and the one-thread-per-position kernel agree
-            os.environ["TM_ED_BRUTEFORCE"] = "1"
-            try:
+            with gpu_small["scene"].ctx.option("ed_bruteforce", 1):
                 ref = gpu_small["scene"].score_hypotheses_early_drop(gpu_small["model"], poses, DT, 0.5, subset=subset)
-            finally:
-                del os.environ["TM_ED_BRUTEFORCE"]
             assert all(np.array_equal(x, y) for x, y in zip((cg, sg, dg, vg), ref))
         for h in range(len(poses)):
             sc, mc, score, saved = oracle_small["scene"].project(
@@ -621,13 +618,10 @@ def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
     a = capi.Model(gpu_ctx, model, res)
     a.build_voxels()
     va = a.voxels()
-    os.environ["TM_VOXEL_BRUTEFORCE"] = "1"
-    try:
+    with gpu_ctx.option("voxel_bruteforce", 1):
         b = capi.Model(gpu_ctx, model, res)
         b.build_voxels()
         vb = b.voxels()
-    finally:
-        del os.environ["TM_VOXEL_BRUTEFORCE"]
     assert va.size > 4_000_000 and np.array_equal(va, vb)
     assert not np.isin(va, np.arange(15000, 15500)).any()  # duplicates never win over their originals
     poses = np.eye(4, dtype=np.float32).reshape(1, 16)
@@ -936,10 +930,11 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     centers = pairs[prov[:, 0], 0].astype(np.uint32)
     c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
     order = np.sort(c[sc > 0])
-    for env in ({"TM_SEARCH_SEGMENT": "0"}, {"TM_SEARCH_SEGMENT": "300"}, {"TM_ED_UNFUSED": "1"}, {"TM_ED_NARROW": "1"},
-                {"TM_ED_ONE_KERNEL": "1"}, {"TM_ED_WIDE": "1", "TM_SEARCH_SEGMENT": "0"}):
-        old_env = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
+    for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
+                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}):
+        old_env = {k: gs.ctx.get_option(k) for k in env}
+        for k, v in env.items():
+            gs.ctx.set_option(k, v)
         try:
             for sufficient in (float(np.median(order)), float(order[-2]), float(order[-1])):
                 ok = np.nonzero((sc > 0) & (c.astype(np.float32) > np.float32(sufficient)))[0]
@@ -951,10 +946,7 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
                     assert cnt == c[want] and score == sc[want] and dropped == dr[want], (env, sufficient)
         finally:
             for k, v in old_env.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+                gs.ctx.set_option(k, v)
     # several batches in one call (the chunks of a round) == one call per batch, also with an empty batch
     offs = np.array([0, 7, 7, 30, 64, len(pairs)], np.uint32)
     for early_drop in (True, False):
@@ -985,7 +977,7 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
             assert np.array_equal(lists[k], os_.radius_subset(int(c), r))
 
 
-def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case, monkeypatch):
+def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case):
     """The grouped kernel (16 or 32 hypotheses share the scene chunks they reach) against the exhaustive kernel
     and the oracle at the sizes where its bookkeeping has edges: fewer hypotheses than a group, one more than a
     group, a last partial group; a scene smaller than one 512-point chunk; a masked scene."""
@@ -994,18 +986,37 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
     cb, sb = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_BRUTEFORCE)
     co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, threads=8)
     assert np.array_equal(cb, co)
-    for group in ("16", "32"):
-        monkeypatch.setenv("TM_GROUP_HYPS", group)
-        for n in (1, 15, 16, 17, 31, 32, 33, 100):
-            cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
-            assert np.array_equal(cg, cb[:n]), (group, n)
-            assert np.array_equal(sg, sb[:n]), (group, n)  # fixed-point sums: identical, not merely close
-    monkeypatch.delenv("TM_GROUP_HYPS")
-    # the per-hypothesis kernel of round 1 (still used for ball / subset scoring) agrees as well
-    monkeypatch.setenv("TM_SCORE_GROUPED", "0")
-    cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
-    monkeypatch.delenv("TM_SCORE_GROUPED")
+    for group in (16, 32):
+        with gpu_ctx.option("group_hyps", group):
+            for n in (1, 15, 16, 17, 31, 32, 33, 100):
+                cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
+                assert np.array_equal(cg, cb[:n]), (group, n)
+                assert np.array_equal(sg, sb[:n]), (group, n)  # fixed-point sums: identical, not merely close
+    # the per-hypothesis kernel of round 1 (still used for subset scoring) agrees as well
+    with gpu_ctx.option("score_grouped", 0):
+        cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
     assert np.array_equal(cg, cb) and np.array_equal(sg, sb)
+    # a slot budget so small that the batch goes through in several launches of whole groups (what a 1M-hypothesis
+    # batch on a 10M-point scene does with the default 256 MiB): 1 MiB = 131,072 slots; the 20k-point scene has 40
+    # chunks, 3000 hypotheses = 188 groups x 40 = 7,520 slots, so shrink the scene side instead: many hypotheses
+    many = np.tile(poses, (40, 1))[:3990]
+    cm1, sm1 = s.score_hypotheses(g, many, DT, mode=capi.SCORE_CULLED)
+    gpu_ctx.set_option("score_slot_mib", 1)
+    try:
+        import triplet_match_amd.capi as _c
+        assert gpu_ctx.get_option("score_slot_mib") == 1
+        big = np.tile(poses, (800, 1))[:70000]  # 4,375 groups x 40 chunks = 175,000 slots > 131,072: two launches
+        cbig, sbig = s.score_hypotheses(g, big, DT, mode=capi.SCORE_CULLED)
+    finally:
+        gpu_ctx.set_option("score_slot_mib", 256)
+    assert np.array_equal(cbig[:3990], cm1) and np.array_equal(sbig[:3990], sm1)
+    assert np.array_equal(cbig[:100], cb) and np.array_equal(cbig[69900:70000], cb[:100])
+    # unknown switches and the timing experiments are refused by the product library
+    with pytest.raises(capi.TmError):
+        gpu_ctx.set_option("no_such_switch", 1)
+    with pytest.raises(capi.TmError) as e:
+        gpu_ctx.set_option("ablate", 1)
+    assert e.value.code == capi.ERR_UNSUPPORTED and b"timing" not in capi.lib().tm_version()
     # a scene of 300 points: less than one chunk
     sc = small_case["scene"]
     inst = np.nonzero(sc["instance_id"] == 0)[0][:300]

@@ -24,14 +24,14 @@ centers = pairs[prov[:, 0], 0].astype(np.uint32)
 print("hypotheses", len(poses), "distinct centres", len(np.unique(centers)))
 for n in (1024, 2048, 4096, 16384, 65536):
     n = min(n, len(poses))
-    for env in (None, "TM_BALL_UNGROUPED"):
+    for env in (None, "ball_ungrouped"):
         if env:
-            os.environ[env] = "1"
+            ctx.set_option(env, 1)
         gs.score_hypotheses_ball(gm, poses[:n], centers[:n], gm.diameter, 3.0)
         t0 = time.perf_counter()
         for _ in range(3):
             c, s = gs.score_hypotheses_ball(gm, poses[:n], centers[:n], gm.diameter, 3.0)
         dt = (time.perf_counter() - t0) / 3
         if env:
-            del os.environ[env]
+            ctx.set_option(env, 0)
         print("n %6d %-18s %.2f ms per call (%.0f hyp/s), max count %d" % (n, env or "grouped", dt * 1e3, n / dt, c.max()), flush=True)

@@ -42,16 +42,16 @@ tangent = np.nonzero(near)[0].astype(np.int32)
 print("hypotheses", len(poses), "centres", len(np.unique(centers)), "tangent points", len(tangent), flush=True)
 for n in (1600, 16000):
     n = min(n, len(poses))
-    for env in (None, "TM_BALL_UNGROUPED"):
+    for env in (None, "ball_ungrouped"):
         if env:
-            os.environ[env] = "1"
+            ctx.set_option(env, 1)
         gp.score_hypotheses_ball(gm, poses[:n], centers[:n], gm.diameter, 3.0)
         t0 = time.perf_counter()
         for _ in range(3):
             c, s = gp.score_hypotheses_ball(gm, poses[:n], centers[:n], gm.diameter, 3.0)
         dt = (time.perf_counter() - t0) / 3
         if env:
-            del os.environ[env]
+            ctx.set_option(env, 0)
         print("ball   n %6d %-18s %.2f ms per call" % (n, env or "grouped", dt * 1e3), flush=True)
 for n in (800, 8000):
     n = min(n, len(poses))

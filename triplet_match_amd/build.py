@@ -31,16 +31,29 @@ def _stale():
     return False
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link libtm_hip.so. Returns its path."""
+EXPERIMENTS_LIB = os.path.join(HERE, "libtm_hip_experiments.so")
+
+
+def build(force=False, verbose=False, timing_experiments=False):
+    """Compile every HIP translation unit for gfx950 and link libtm_hip.so. Returns its path.
+
+    timing_experiments=True builds a SEPARATE library, libtm_hip_experiments.so, with -DTM_TIMING_EXPERIMENTS:
+    the stage-ablation switches (option "ablate": wrong results, timing only) exist only there; select it with
+    TM_LIB=<path> (capi.py). The product library never contains them."""
+    if timing_experiments:
+        return _build(EXPERIMENTS_LIB, ["-DTM_TIMING_EXPERIMENTS"], ".exp.o", verbose)
     if not force and not _stale():
         return LIB
+    return _build(LIB, [], ".o", verbose)
+
+
+def _build(lib, extra, obj_suffix, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", obj_suffix))
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -51,10 +64,10 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl", "-pthread"]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, timing_experiments="--timing-experiments" in sys.argv))

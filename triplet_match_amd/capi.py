@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtm_hip.so")
+# TM_LIB selects another build of the same ABI (libtm_hip_experiments.so of `build.py --timing-experiments`)
+LIB_PATH = os.environ.get("TM_LIB") or os.path.join(_HERE, "libtm_hip.so")
 
 OK, ERR_INVALID, ERR_NOT_INITIALIZED, ERR_HIP, ERR_EMPTY, ERR_UNSUPPORTED, ERR_NO_DEVICE, \
     ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6, -7
@@ -50,6 +51,8 @@ SIGNATURES = {
     "tm_device_free": (C.c_int, [vp, vp]),
     "tm_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "tm_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "tm_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "tm_ctx_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
     "tm_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
     "tm_ctx_last_score_timing": (C.c_int, [vp, f32p, u64p, u64p, u64p]),
     "tm_ctx_score_timing_totals": (C.c_int, [vp, u32p, f32p, u64p]),
@@ -273,6 +276,29 @@ class Context:
 
     def synchronize(self):
         _check(lib().tm_ctx_synchronize(self.h))
+
+    def set_option(self, name, value):
+        """tm_ctx_set_option: a cross-check / timing switch of this context (never the environment)."""
+        _check(lib().tm_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _check(lib().tm_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def option(self, name, value):
+        """with ctx.option("score_grouped", 0): ... — sets the switch for the block and restores it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            old = self.get_option(name)
+            self.set_option(name, value)
+            try:
+                yield
+            finally:
+                self.set_option(name, old)
+        return _cm()
 
     def enable_timing(self, on=True):
         _check(lib().tm_ctx_enable_timing(self.h, int(on)))

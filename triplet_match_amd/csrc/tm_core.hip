@@ -1,6 +1,7 @@
 /* tm_core.hip — context, error text, host-side scalar API and the batched descriptor kernel. */
 #include "tm_internal.h"
 
+#include <cctype>
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -48,7 +49,11 @@ using namespace tmx;
 extern "C" {
 
 const char* tm_last_error(void) { return g_error.c_str(); }
-const char* tm_version(void) { return "triplet_match_amd 0.1 (gfx950)"; }
+#ifdef TM_TIMING_EXPERIMENTS
+const char* tm_version(void) { return "triplet_match_amd 0.3 (gfx950) +timing-experiments: NOT a product build"; }
+#else
+const char* tm_version(void) { return "triplet_match_amd 0.3 (gfx950)"; }
+#endif
 
 }  // extern "C"
 
@@ -68,7 +73,74 @@ static void mark_exit() {
 }
 }  // namespace tmx
 
+namespace tmx {
+struct opt_entry {
+    const char* name;
+    int options::*field;
+    int lo, hi;
+};
+static const opt_entry kOptions[] = {
+    {"ablate", &options::ablate, 0, 99},
+    {"debug_stats", &options::debug_stats, 0, 1},
+    {"debug_items", &options::debug_items, 0, 1},
+    {"debug_times", &options::debug_times, 0, 1},
+    {"debug_ed", &options::debug_ed, 0, 1},
+    {"score_grouped", &options::score_grouped, 0, 1},
+    {"ball_ungrouped", &options::ball_ungrouped, 0, 1},
+    {"group_hyps", &options::group_hyps, 16, 32},
+    {"item_static", &options::item_static, 0, 1},
+    {"item_nosteal", &options::item_nosteal, 0, 1},
+    {"item_run", &options::item_run, -1, 30},
+    {"score_item_wgs", &options::score_item_wgs, 0, 1 << 20},
+    {"score_parts", &options::score_parts, 1, 64},
+    {"score_slot_mib", &options::score_slot_mib, 1, 1 << 16},
+    {"near_metric", &options::near_metric, 0, 1},
+    {"model_morton", &options::model_morton, 0, 1},
+    {"scene_morton", &options::scene_morton, 0, 1},
+    {"voxel_bruteforce", &options::voxel_bruteforce, 0, 1},
+    {"ed_one_kernel", &options::ed_one_kernel, 0, 1},
+    {"ed_narrow", &options::ed_narrow, 0, 1},
+    {"ed_wide", &options::ed_wide, 0, 1},
+    {"ed_bruteforce", &options::ed_bruteforce, 0, 1},
+    {"ed_unfused", &options::ed_unfused, 0, 1},
+    {"search_segment", &options::search_segment, -1, 1 << 24},
+};
+}  // namespace tmx
+
 extern "C" {
+
+int tm_ctx_set_option(tm_ctx* c, const char* name, int value) {
+    TM_REQUIRE(c && name, TM_ERR_INVALID, "tm_ctx_set_option: null argument");
+    for (const opt_entry& o : kOptions) {
+        if (strcmp(o.name, name) != 0) continue;
+        if (value < o.lo || value > o.hi || (o.field == &options::group_hyps && value != 16 && value != 32)) {
+            set_error("tm_ctx_set_option: %s = %d is out of range [%d, %d]", name, value, o.lo, o.hi);
+            return TM_ERR_INVALID;
+        }
+#ifndef TM_TIMING_EXPERIMENTS
+        if (o.field == &options::ablate && value != 0) {
+            set_error("ablate: timing experiments return wrong results and are not compiled into this library "
+                      "(build with -DTM_TIMING_EXPERIMENTS: python -m triplet_match_amd.build --timing-experiments)");
+            return TM_ERR_UNSUPPORTED;
+        }
+#endif
+        c->opt.*(o.field) = value;
+        return TM_OK;
+    }
+    set_error("tm_ctx_set_option: unknown option '%s'", name);
+    return TM_ERR_INVALID;
+}
+
+int tm_ctx_get_option(const tm_ctx* c, const char* name, int* value) {
+    TM_REQUIRE(c && name && value, TM_ERR_INVALID, "tm_ctx_get_option: null argument");
+    for (const opt_entry& o : kOptions)
+        if (strcmp(o.name, name) == 0) {
+            *value = c->opt.*(o.field);
+            return TM_OK;
+        }
+    set_error("tm_ctx_get_option: unknown option '%s'", name);
+    return TM_ERR_INVALID;
+}
 
 int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_REQUIRE(out, TM_ERR_INVALID, "tm_ctx_create: null output");
@@ -88,8 +160,18 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_HIP_CHECK(hipEventCreate(&c->ev0));
     TM_HIP_CHECK(hipEventCreate(&c->ev1));
     TM_FORWARD(c->stats.alloc((size_t)kTimedRing * kTimedWords));
-    c->ablate = getenv("TM_ABLATE") ? atoi(getenv("TM_ABLATE")) : 0;
-    c->debug_stats = getenv("TM_DEBUG_STATS") != nullptr;
+    for (const opt_entry& o : kOptions) { /* the one place the environment is read */
+        std::string env = "TM_";
+        for (const char* p = o.name; *p; ++p) env += (char)toupper((unsigned char)*p);
+        if (const char* v = getenv(env.c_str())) {
+            int rc = tm_ctx_set_option(c, o.name, *v ? atoi(v) : 1);
+            if (rc != TM_OK) {
+                (void)hipStreamDestroy(c->stream);
+                delete c;
+                return rc;
+            }
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
         static bool registered = false;

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     uint32_t B_words = (tests[0] + 1024u + 63u) / 64u;
     if (B_words > S_words) B_words = S_words;
     if (PREFIX && B_words > a.prefix_words) B_words = a.prefix_words; /* a shorter prefix may just not decide */
-    if (!PREFIX && (pending || a.sc.ablate == 30)) B_words = 0u; /* the whole scan in the tile-culled pass */
+    if (!PREFIX && (pending || TM_ABLATE_EQ(a.sc, 30))) B_words = 0u; /* the whole scan in the tile-culled pass */
     for (uint32_t step = 0; step < (PREFIX ? 1u : 2u); ++step) {
         const uint32_t pos_lo = step == 0 ? 0u : B_words * 64u;
         const uint32_t pos_hi = step == 0 ? B_words * 64u : 0xFFFFFFFFu;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
 static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t fused_lds, const ed_args& a,
                                   const ed_cull& cu, const ed_out& o, float accept_thresh, const uint32_t* d_tests,
                                   uint32_t rows_cap = 0) {
-    if (getenv("TM_ED_ONE_KERNEL")) {
+    if (c->opt.ed_one_kernel) {
         hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh,
                            d_tests, s->oref.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
         return hipGetLastError();
@@ -794,7 +794,7 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
                        accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
-    if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !getenv("TM_ED_NARROW")) {
+    if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !c->opt.ed_narrow) {
         /* wide continuation (ball mode: the scan order is the neighbourhood list): bits of all positions of the
          * pending hypotheses, then the rule and the score terms on those rows; rows_cap rows of bit arrays */
         ed_args as = a; /* k_ed_score addresses scene points by original index */
@@ -912,7 +912,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
-    a.sc.ablate = c->ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
+    a.sc.ablate = c->opt.ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
     a.sc.kind = m->metric_kind;
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
@@ -945,7 +945,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     const float accept_thresh = accept_prob * (float)m->n; /* accept_prob * size() in float */
     /* scan position of every scene point; a subset that names a point twice (or TM_ED_BRUTEFORCE=1)
      * takes the one-thread-per-position kernel */
-    bool culled = getenv("TM_ED_BRUTEFORCE") == nullptr;
+    bool culled = !c->opt.ed_bruteforce;
     if (culled) {
         uint32_t dup = 0;
         ED_HIP(hipMemsetAsync(d_pos.p, 0xFF, (size_t)s->n * 4, c->stream));
@@ -977,7 +977,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     cu.n_tiles = s->n_tiles;
     cu.coord_max = s->coord_max;
     const size_t fused_lds = 2 * (size_t)words * 8;
-    const bool fused = culled && fused_lds <= kEdFusedLdsMax && getenv("TM_ED_UNFUSED") == nullptr;
+    const bool fused = culled && fused_lds <= kEdFusedLdsMax && !c->opt.ed_unfused;
     if (fused) { /* bits, walk and score in one kernel, bit arrays in LDS */
         ac.h0 = 0;
         ED_HIP(launch_ed_fused(s, c, n_hyp, fused_lds, ac, cu, o, accept_thresh, d_tests.p));
@@ -1110,7 +1110,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.sc.mref = m->ref.p;
     a.sc.vox = m->voxels.p;
     a.sc.active = nullptr;
-    a.sc.ablate = c->ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
+    a.sc.ablate = c->opt.ablate == 30 ? 30 : 0; /* TM_ABLATE=30: one-step evaluation of the fused kernel (timing comparison) */
     a.sc.kind = m->metric_kind;
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
@@ -1158,7 +1158,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
      * continuation keep the two-step rule at any neighbourhood size */
     const bool big_lds = fused_lds > kEdFusedLdsMax;
     const bool fused = (!big_lds || n_hyp <= 4096u || (segment && segment <= 4096u && d_found)) &&
-                       getenv("TM_ED_UNFUSED") == nullptr && !(big_lds && (getenv("TM_ED_NARROW") || getenv("TM_ED_ONE_KERNEL")));
+                       !c->opt.ed_unfused && !(big_lds && (c->opt.ed_narrow || c->opt.ed_one_kernel));
     if (fused && segment && d_found) {
         /* tm_search_batch: only the first sufficient hypothesis in visit order is wanted (reference :330-338: later
          * ones are scored without effect). The hypotheses go through in segments; after each, *d_found takes the
@@ -1180,8 +1180,8 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
          * pays for the few rows of a segment (end-to-end search 0.030 against 0.034 s) */
         a.h0 = 0;
         TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p,
-                                     n_hyp <= 4096u || big_lds || getenv("TM_ED_WIDE") ? chunk : 0u));
-        if (getenv("TM_DEBUG_ED")) { /* how many hypotheses the prefix kernel could not decide */
+                                     n_hyp <= 4096u || big_lds || c->opt.ed_wide ? chunk : 0u));
+        if (c->opt.debug_ed) { /* how many hypotheses the prefix kernel could not decide */
             uint32_t n_pend = 0;
             TM_HIP_CHECK(hipMemcpyAsync(&n_pend, s->ed_pending.p + n_hyp, 4, hipMemcpyDeviceToHost, c->stream));
             TM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1392,8 +1392,7 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
                            s->sb_pair_slot.p, s->ed_slot.p);
         TM_HIP_CHECK(hipGetLastError());
         /* segments of 2048 hypotheses (one resident round of the prefix kernel); TM_SEARCH_SEGMENT=0: all at once */
-        const char* seg_env = getenv("TM_SEARCH_SEGMENT");
-        const uint32_t segment = seg_env ? (uint32_t)atoi(seg_env) : 2048u;
+        const uint32_t segment = s->ctx->opt.search_segment >= 0 ? (uint32_t)s->ctx->opt.search_segment : 2048u;
         TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
                                 accept_prob, segment, sufficient, d_found, starts.data(), n_batches));
         for (uint32_t b = 0; b < n_batches; ++b)

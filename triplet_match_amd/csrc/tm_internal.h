@@ -77,6 +77,32 @@ struct score_timing {
 constexpr int kTimedRing = 256;
 constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, staged items, 3 spare */
 
+/* Switches of a context: cross-checks (a second kernel for the same result) and timing comparisons. Read ONCE
+ * from the environment when the context is created (TM_<NAME> in upper case) and changed afterwards only through
+ * tm_ctx_set_option; no call of the path reads the environment. None of them changes a result, except `ablate`,
+ * which exists only in a library built with -DTM_TIMING_EXPERIMENTS. */
+struct options {
+    int ablate = 0;           /* TM_ABLATE (timing-experiments build only) */
+    int debug_stats = 0;      /* per-launch stage counts on stderr */
+    int debug_items = 0;      /* + item statistics of the grouped kernel */
+    int debug_times = 0;      /* laps of tm_cloud_curvature */
+    int debug_ed = 0;         /* pending counts of the early-drop prefix kernel */
+    int score_grouped = 1;    /* 0: the per-hypothesis kernel (k_score_culled) for every launch */
+    int ball_ungrouped = 0;   /* 1: k_score_culled for ball-restricted scoring */
+    int group_hyps = 16;      /* 16 or 32 hypotheses per group */
+    int item_static = 0;      /* 1: fixed item share per wave */
+    int item_nosteal = 0;     /* 1: no continuation in other XCDs' items */
+    int item_run = -1;        /* log2 of the run of items one XCD owns; -1 = from the item count */
+    int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
+    int score_parts = 3;      /* workgroups per hypothesis of k_score_culled */
+    int score_slot_mib = 256; /* byte budget of the grouped kernel's (group, chunk) slots per launch */
+    int near_metric = 1;      /* 0: plane2 / cylinder models score with sphere culling only (no brick filter) */
+    int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
+    int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
+    int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
+    int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
+};
+
 /* One tm_best_reduce in flight (tm_best_reduce_begin .. _end): the winners land in pinned host memory behind an
  * event, so the caller can queue the next batch before it waits. */
 constexpr int kReduceSlots = 4;
@@ -94,8 +120,7 @@ struct tm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    int ablate = 0;          /* TM_ABLATE: timing experiments only */
-    bool debug_stats = false; /* TM_DEBUG_STATS: per-launch stage counts on stderr */
+    tmx::options opt;        /* switches, see tmx::options */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_ring;      /* 2 * kTimedRing, created on first use */
     uint64_t n_timed = 0;                 /* timed launches since tm_ctx_enable_timing(ctx, 1) */

@@ -755,7 +755,7 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
      * space are neighbours in the arrays, so the scoring kernel's gathers of model points share lines.
      * TM_MODEL_MORTON=1 selects the plain Morton order (timing comparisons). */
     {
-        const bool hilbert = getenv("TM_MODEL_MORTON") == nullptr;
+        const bool hilbert = !ctx->opt.model_morton;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (uint32_t i = 0; i < n; ++i) {
             const float* s = surfels + (size_t)i * 12;
@@ -934,7 +934,7 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
     TM_REQUIRE(k >= 1 && k <= (uint32_t)kCurvK, TM_ERR_UNSUPPORTED, "tm_cloud_curvature: k must be in 1..32");
     if (n == 0) return TM_OK;
     TM_HIP_CHECK(hipSetDevice(ctx->device));
-    const bool dbg = getenv("TM_DEBUG_TIMES") != nullptr; /* where the call's time goes, on stderr */
+    const bool dbg = ctx->opt.debug_times != 0; /* where the call's time goes, on stderr */
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
@@ -1071,7 +1071,7 @@ int tm_model_build_voxels(tm_model* m) {
     TM_REQUIRE(blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
     /* default: kd-tree descent per voxel; TM_VOXEL_BRUTEFORCE=1 selects the LDS-tiled exhaustive scan
      * (same table, kept as the cross-check and for degenerate clouds without a tree) */
-    const bool brute = getenv("TM_VOXEL_BRUTEFORCE") != nullptr || m->kd_n_nodes == 0;
+    const bool brute = c->opt.voxel_bruteforce || m->kd_n_nodes == 0;
     if (brute) {
         hipLaunchKernelGGL(k_voxel_nn, dim3((uint32_t)blocks), dim3(256), 0, c->stream, m->vpos.p, m->n,
                            m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);

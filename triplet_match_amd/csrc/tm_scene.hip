@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
         h = x * q + min(x, r) + i;
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (a.ablate == 6) return;
+    if (TM_ABLATE_EQ(a, 6)) return;
     const pose12 T = load_pose(a.poses + (size_t)h * 16);
     const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
                               ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
         const unsigned long long smask = s_smask;
         /* level 2: wave w owns super-tiles w, w+4, ... of the chunk: wave-uniform skip */
         for (uint32_t r = wave; r < (uint32_t)(kCullChunk / 64); r += 4) {
-            if (a.ablate == 5) break;
+            if (TM_ABLATE_EQ(a, 5)) break;
             if (!((smask >> r) & 1ull)) continue;
             const uint32_t t = t0 + r * 64u + lane;
             bool hit = false;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
             if (hit) s_list[atomicAdd(&s_n, 1u)] = sub;
         }
         __syncthreads();
-        const uint32_t n = a.ablate == 4 ? 0u : s_n;
+        const uint32_t n = TM_ABLATE_EQ(a, 4) ? 0u : s_n;
         tiles_done += n;
         /* a wave's 64 lanes take four sub-tiles at a time (lane >> 4 picks the sub-tile), four such groups
          * in flight: 16 list entries per iteration */
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 const bool have = e < n;
                 sidx[k] = (have ? s_list[e] : s_list[i]) * 16u + (lane & 15u);
                 const float* sp = a.spos3 + 3u * (size_t)sidx[k]; /* 12 B per point: 12 lines per tile, not 16 */
-                if (a.ablate >= 8) { /* timing experiment: no per-point loads (one broadcast sphere per 16 lanes) */
+                if (TM_ABLATE_GE(a, 8)) { /* timing experiment: no per-point loads (one broadcast sphere per 16 lanes) */
                     const float4 sb = ca.subs[sidx[k] >> 4];
                     P[k] = make_float4(sb.x + 1e-4f * (float)(lane & 3u), sb.y + 1e-4f * (float)((lane >> 2) & 3u), sb.z, 0.f);
                 } else
@@ -281,13 +281,13 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 n_in += in[k] ? 1u : 0u;
                 n_near += near[k] ? 1u : 0u;
                 lin[k] = near[k] ? lin[k] : 0u;
-                if (a.ablate == 7 || a.ablate == 9) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
+                if (TM_ABLATE_EQ(a, 7) || TM_ABLATE_EQ(a, 9)) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
             }
-            if (a.ablate == 3) { cnt += near[0] + near[1] + near[2] + near[3]; continue; }
+            if (TM_ABLATE_EQ(a, 3)) { cnt += near[0] + near[1] + near[2] + near[3]; continue; }
             /* stage 2: voxel gathers */
 #pragma unroll
             for (int k = 0; k < 4; ++k) m[k] = a.vox[lin[k]];
-            if (a.ablate == 2) { cnt += m[0] + m[1] + m[2] + m[3]; continue; }
+            if (TM_ABLATE_EQ(a, 2)) { cnt += m[0] + m[1] + m[2] + m[3]; continue; }
             /* stage 3: model point gathers + distance test */
             bool ok[4];
 #pragma unroll
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                     ok[k] = near[k] & !(dist > a.dmax);
                 }
             }
-            if (a.ablate == 1) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
+            if (TM_ABLATE_EQ(a, 1)) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
             /* stage 4: orientation term for the distance-passing points; the eight loads are issued before
              * the first use so that they overlap */
             if (__ballot(ok[0] | ok[1] | ok[2] | ok[3])) {
@@ -390,6 +390,7 @@ typedef uint32_t group_mask_t; /* up to 32 hypotheses per group */
 /* LDS of one wave of k_score_items<G>: chunk xyz + poses (3 float4 each) + (rnorm, abs_eps) + entries + sums */
 constexpr int item_lds(int G, bool ball = false) { return 6144 + G * 48 + G * 8 + G * 32 * 2 + G * 8 + (ball ? G * 16 : 0); }
 constexpr int kChunkPts = 512; /* 8 tiles = 32 quarter-tiles, 6 KB of packed xyz */
+static_assert(kScoreTile % kChunkPts == 0, "the padded scene (a multiple of kScoreTile) must be whole chunks");
 constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budget is set for (127 VGPRs). Five
                                  waves = 96 VGPRs spill and lose: four chains 100 bytes per lane, 18.3 ms against
                                  14.8; three chains 72 bytes, 16.8 ms against 12.9 */
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 ent[o++] = (unsigned short)((g << 5) | lane);
             }
         }
-        if (n == 0u || a.ablate == 10) { /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
+        if (n == 0u || TM_ABLATE_EQ(a, 10)) { /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
             if (!ga.heads) it += waves_per_xcd;
             continue;
         }
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 n_in += in[k] ? 1u : 0u;
                 n_near += near[k] ? 1u : 0u;
                 lin[k] = near[k] ? lin[k] : 0u;
-                if (a.ablate == 7) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
+                if (TM_ABLATE_EQ(a, 7)) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) mi[k] = a.vox[lin[k]];
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 }
                 any_ok |= ok[k];
             }
-            if (a.ablate == 1) { pass += any_ok ? 1u : 0u; continue; } /* timing experiment: no orientation stage */
+            if (TM_ABLATE_EQ(a, 1)) { pass += any_ok ? 1u : 0u; continue; } /* timing experiment: no orientation stage */
             if (__ballot(any_ok)) {
 #pragma unroll
                 for (int k0 = 0; k0 < NC; k0 += 2) {
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < (uint32_t)G) {
             const unsigned long long v = acc[lane];
-            if (v && a.ablate != 11) {
+            if (v && !TM_ABLATE_EQ(a, 11)) {
                 const uint32_t h = group * G + lane;
                 atomicAdd(&a.counts[h], (uint32_t)(v >> 52));
                 atomicAdd(&a.scores_fx[h], v & 0xFFFFFFFFFFFFFull);
@@ -1171,6 +1172,25 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     if (n_hyp == 0) return TM_OK;
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
+    /* The grouped kernels keep two words per (group of hypotheses, 512-point chunk) slot. A large batch on a
+     * large scene (1M hypotheses x 10M points = 1.3e9 slots = 10 GB) is therefore scored in several launches
+     * of whole groups, each within the slot budget (score_slot_mib, 256 MiB); the sums are integers per
+     * hypothesis, so the split changes nothing in the results. */
+    const size_t slot_budget = (size_t)c->opt.score_slot_mib * (1u << 20) / (2 * sizeof(uint32_t));
+    if (mode != TM_SCORE_BRUTEFORCE && !d_active && c->opt.score_grouped && !(d_centers && c->opt.ball_ungrouped)) {
+        const uint32_t gh = (c->opt.group_hyps == 32 && !d_centers) ? 32u : 16u;
+        const size_t n_chunks = s->n_sorted / kChunkPts;
+        const size_t groups = (n_hyp + gh - 1) / gh;
+        const size_t groups_per = n_chunks ? slot_budget / n_chunks : groups;
+        if (groups * n_chunks > slot_budget && groups_per >= 1) {
+            const size_t step = std::min<size_t>(groups_per * gh, 0x7FFFFFF0u);
+            for (size_t off = 0; off < n_hyp; off += step)
+                TM_FORWARD(score_device(s, m, traits_kind, d_poses + off * 16, (uint32_t)std::min<size_t>(step, n_hyp - off),
+                                        d_active, n_active, dist_thres, mode, d_counts + off, d_scores + off,
+                                        d_centers ? d_centers + off : nullptr, ball_radius));
+            return TM_OK;
+        }
+    }
     TM_FORWARD(s->w_scores_fx.ensure(n_hyp));
     TM_HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)n_hyp * 4, c->stream));
     TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, (size_t)n_hyp * 8, c->stream));
@@ -1190,7 +1210,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     const float thres = dist_thres * m->resolution; /* reference :413 */
     a.d2max = sq_threshold(thres);
     a.n_hyp = n_hyp;
-    a.ablate = c->ablate;
+    a.ablate = c->opt.ablate;
     a.kind = m->metric_kind;
     a.radius = m->metric_radius;
     a.dmax = thres;
@@ -1246,8 +1266,8 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ca.active_sorted = s->w_active_sorted.p;
         }
         bool grouped = !d_active; /* with or without the neighbourhood restriction (d_centers) */
-        if (const char* e = getenv("TM_SCORE_GROUPED")) grouped = grouped && atoi(e) != 0;
-        if (d_centers && getenv("TM_BALL_UNGROUPED")) grouped = false;
+        grouped = grouped && c->opt.score_grouped != 0;
+        if (d_centers && c->opt.ball_ungrouped) grouped = false;
         /* groups of consecutive hypotheses share the scene chunks they reach */
         group_args ga;
         ga.chunks = s->chunks.p;
@@ -1256,12 +1276,13 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
          * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
          * as that saves: 13.05 ms against 12.90 ms in the same run. */
         ga.group_hyps = 16u;
-        if (const char* e = getenv("TM_GROUP_HYPS")) ga.group_hyps = atoi(e) == 32 && !d_centers ? 32u : 16u;
+        if (c->opt.group_hyps == 32 && !d_centers) ga.group_hyps = 32u;
         ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
         const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
         /* slots are addressed with 32 bits and the chunks ride in blockIdx.y: beyond that (billions of points,
          * or hundreds of millions of (group, chunk) slots in one call) the per-hypothesis kernel takes the launch */
         if (n_slots_g >= 0xFFFFFFFFull || (ga.n_chunks + 255) / 256 > 65535u) grouped = false;
+        if (n_slots_g > slot_budget) grouped = false; /* one group alone exceeds the budget (>1e9-point scene) */
         if (grouped) {
             TM_FORWARD(s->w_masks.ensure(n_slots_g));
             TM_FORWARD(s->w_items.ensure(n_slots_g + 1));
@@ -1276,12 +1297,12 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.heads = nullptr;
             ga.steal = 0;
             ga.run_shift = 0;
-            if (!getenv("TM_ITEM_STATIC")) { /* dynamic hand-out of the items: eight head words, 128 B apart */
+            if (!c->opt.item_static) { /* dynamic hand-out of the items: eight head words, 128 B apart */
                 TM_FORWARD(s->w_heads.ensure(8 * 32));
                 TM_HIP_CHECK(hipMemsetAsync(s->w_heads.p, 0, 8 * 32 * 4, c->stream));
                 ga.heads = s->w_heads.p;
-                ga.steal = getenv("TM_ITEM_NOSTEAL") ? 0u : 1u;
-                ga.run_shift = getenv("TM_ITEM_RUN") ? (uint32_t)atoi(getenv("TM_ITEM_RUN")) : 0xFFFFFFFFu;
+                ga.steal = c->opt.item_nosteal ? 0u : 1u;
+                ga.run_shift = c->opt.item_run >= 0 ? (uint32_t)c->opt.item_run : 0xFFFFFFFFu;
             }
             hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, (ga.n_chunks + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
@@ -1304,15 +1325,15 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
             uint32_t wgs = (uint32_t)cus * (uint32_t)per_cu;
-            if (const char* e = getenv("TM_SCORE_ITEM_WGS")) wgs = (uint32_t)std::max(8, atoi(e));
+            if (c->opt.score_item_wgs > 0) wgs = (uint32_t)std::max(8, c->opt.score_item_wgs);
             wgs &= ~7u;
             TM_FORWARD(s->w_stats.ensure(std::max<size_t>(n_slots, wgs)));
             a.stat_slots = s->w_stats.p;
             n_stat_slots = wgs;
-            if (c->debug_stats)
+            if (c->opt.debug_stats)
                 fprintf(stderr, "[tm] grouped: %u persistent workgroups (%d per CU)\n", wgs, per_cu);
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, a, ca, ga);
-            if (c->debug_stats && getenv("TM_DEBUG_ITEMS")) {
+            if (c->opt.debug_stats && c->opt.debug_items) {
                 std::vector<group_mask_t> hm(n_slots_g);
                 TM_HIP_CHECK(hipMemcpyAsync(hm.data(), s->w_masks.p, n_slots_g * sizeof(group_mask_t), hipMemcpyDeviceToHost,
                                             c->stream));
@@ -1328,8 +1349,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         } else {
         /* split every hypothesis over `parts` workgroups (rounds of 1024 tiles taken in turn): shorter
          * workgroups even out the tail of the launch; TM_SCORE_PARTS overrides (1 = no split) */
-        uint32_t parts = 3;
-        if (const char* e = getenv("TM_SCORE_PARTS")) parts = (uint32_t)std::max(1, atoi(e));
+        uint32_t parts = (uint32_t)std::max(1, c->opt.score_parts);
         parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (s->n_tiles + kCullChunk - 1) / kCullChunk));
         if (parts > 1) TM_HIP_CHECK(hipMemsetAsync(s->w_stats.p, 0, n_slots * sizeof(uint4), c->stream));
         const dim3 cgrid(n_hyp, parts);
@@ -1360,7 +1380,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         c->timed_hyp[trow] = n_hyp;
         c->timed_evals_host[trow] = culled ? ~0ull : (uint64_t)n_hyp * n_active;
         ++c->n_timed;
-        if (c->debug_stats) {
+        if (c->opt.debug_stats) {
             score_timing t;
             uint32_t nl = 0;
             TM_FORWARD(read_timed(c, c->n_timed - 1, &t, &nl));

@@ -392,7 +392,7 @@ int scene_build(tm_scene* s, bool resort) {
             return rc;
         }
         hipLaunchKernelGGL(k_scene_morton, grid_n, blk, 0, c->stream, s->d_cloud.p, n, bnd,
-                           getenv("TM_SCENE_MORTON") ? 0 : 1, k_in.p, v_in.p);
+                           c->opt.scene_morton ? 0 : 1, k_in.p, v_in.p);
         size_t tmp = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, k_in.p, k_out.p, v_in.p, s->d_order.p, (size_t)n, 0,
                                                  64, c->stream);

@@ -15,6 +15,18 @@ constexpr int kScorePPT = 4;               /* points per thread held in register
 constexpr int kScoreTile = 256 * kScorePPT; /* points per workgroup */
 constexpr double kFx = 1099511627776.0;     /* 2^40: fixed-point scale of the score sum */
 
+/* Timing experiments (stage ablation, folded gathers) return WRONG results by design. They exist only in a
+ * library built with -DTM_TIMING_EXPERIMENTS (python -m triplet_match_amd.build --timing-experiments writes
+ * libtm_hip_experiments.so); in the product build the tests below are the constant false and the code behind them
+ * is not compiled into the kernels. */
+#ifdef TM_TIMING_EXPERIMENTS
+#define TM_ABLATE_EQ(a, v) ((a).ablate == (v))
+#define TM_ABLATE_GE(a, v) ((a).ablate >= (v))
+#else
+#define TM_ABLATE_EQ(a, v) false
+#define TM_ABLATE_GE(a, v) false
+#endif
+
 struct score_args {
     const float4* spos;
     const float* spos3; /* culled kernel: packed xyz, 12 B per point */
@@ -27,7 +39,7 @@ struct score_args {
     const unsigned char* bcode;  /* brick distance codes, or null (filter off) */
     int bx, by;                  /* brick grid dims (x, y) */
     uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
-    int ablate;                  /* timing experiments only (TM_ABLATE): 0 = full kernel */
+    int ablate;                  /* read only under TM_TIMING_EXPERIMENTS (see TM_ABLATE_EQ); 0 = full kernel */
     int kind;                    /* traits whose intrinsic_distance applies (0 = 3-D L2) */
     float radius;                /* cylinder radius (wrap-around in u) */
     float dmax;                  /* thres itself, for the non-Euclidean metrics */
