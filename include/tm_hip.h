@@ -129,6 +129,34 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
  * |tangent| > 0.7 && pc_min / pc_max < 0.2 (include/impl/scene.hpp:50, model.hpp:96-99). */
 int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5);
 
+/* ---- neighbour queries of pointcloud<Point> (include/pointcloud:38-63, include/impl/pointcloud.hpp:100-210) ----
+ * tm_cloud = the cloud's search structure: kdtree() / build_tree_ (:100-136, :224-240), over all finite points or
+ * over `subset` (set_indices, include/pointcloud:95-103). The reference builds it lazily under a mutex and its
+ * workers query it concurrently; the handle's queries are serialised by a mutex of its own, so a handle may be
+ * shared by threads. Results are ordered by (squared distance, index) ascending with squared distance =
+ * (dx*dx + dy*dy) + dz*dz in f32, d = point - query (FLANN's tie order is unpinned; this is the order of
+ * tm_cloud_curvature and of the oracle); distances are SQUARED, as PCL's nearestKSearch / radiusSearch return. */
+typedef struct tm_cloud tm_cloud;
+int tm_cloud_create(tm_ctx* ctx, const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                    tm_cloud** cloud);
+int tm_cloud_destroy(tm_cloud* cloud);
+uint32_t tm_cloud_tree_size(const tm_cloud* cloud); /* points in the tree (finite, in the subset) */
+/* knn_inclusive(k, point) for a batch (include/impl/pointcloud.hpp:138-146): queries_xyz = n_queries x 3 floats;
+ * indices / sq_dists = n_queries x k, rows padded with -1 / +inf when the tree holds fewer than k points;
+ * counts (optional) = entries per row. k <= 32: one kd-tree launch for the batch; larger k: one pass over the
+ * points per query. knn_exclusive(k, .) = the row of k + 1 without its first entry (:154-160). */
+int tm_cloud_knn(tm_cloud* cloud, const float* queries_xyz, uint32_t n_queries, uint32_t k, int32_t* indices,
+                 float* sq_dists, uint32_t* counts);
+/* radius_search_inclusive(r, point) (:168-176): members = sq dist <= r*r; *count = total, the first
+ * min(cap, total) are written (TM_ERR_CAPACITY if cap is too small; indices and sq_dists may both be NULL to
+ * count). radius_search_exclusive = the same without its first entry (:184-190). */
+int tm_cloud_radius_search(tm_cloud* cloud, const float query_xyz[3], float radius, int32_t* indices,
+                           float* sq_dists, uint32_t cap, uint32_t* count);
+/* principal_curvatures(cloud, idx, neighbours) (:3-44) over an explicit neighbour list, as curvature(float r, idx)
+ * feeds it with radius_search_inclusive(r, idx).first (:206-209); curv5 as tm_cloud_curvature */
+int tm_cloud_curvature_of(const tm_cloud* cloud, uint32_t idx, const int32_t* neighbours, uint32_t n_neighbours,
+                          float curv5[5]);
+
 /* ---- model: replaces model<Point> (include/model:15-66, include/impl/model.hpp) ---- */
 /* model(cloud, discretization_params); `resolution` = cloud->resolution() (mean 1-NN distance) */
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,

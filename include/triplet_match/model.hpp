@@ -7,11 +7,59 @@
 #ifndef TRIPLET_MATCH_MODEL_HPP_
 #define TRIPLET_MATCH_MODEL_HPP_
 
+#include <algorithm>
+#include <iterator>
+#include <mutex>
+
 #include "feature.hpp"
 
 namespace triplet_match {
 
 constexpr int voxel_multiplicity = 1; /* include/model:13 */
+
+namespace detail {
+/* What query() hands out in place of the reference's unordered_multimap const_iterator (include/model:25-26):
+ * a random-access iterator over one key's entries in the host mirror of the table; `it->second` is the (i, j)
+ * tuple, `it->first` the key, as with the reference's nodes. It points into storage owned by the model that is
+ * written once (after init) and never again, so ranges of concurrent queries never touch each other. */
+template <typename Key, typename Result>
+class table_iterator {
+public:
+    typedef std::pair<Key, Result> value_type;
+    typedef value_type reference;
+    typedef std::ptrdiff_t difference_type;
+    typedef std::random_access_iterator_tag iterator_category;
+    struct pointer { /* arrow proxy: keeps the synthesised entry alive for the `->` expression */
+        value_type e;
+        const value_type* operator->() const { return &e; }
+    };
+    table_iterator() = default;
+    table_iterator(const uint32_t* ij, const Key& key) : p_(ij), key_(key) {}
+    value_type operator*() const { return {key_, Result{p_[0], p_[1]}}; }
+    pointer operator->() const { return pointer{**this}; }
+    value_type operator[](difference_type k) const { return *(*this + k); }
+    table_iterator& operator++() { p_ += 2; return *this; }
+    table_iterator operator++(int) { table_iterator t = *this; p_ += 2; return t; }
+    table_iterator& operator--() { p_ -= 2; return *this; }
+    table_iterator operator--(int) { table_iterator t = *this; p_ -= 2; return t; }
+    table_iterator& operator+=(difference_type k) { p_ += 2 * k; return *this; }
+    table_iterator& operator-=(difference_type k) { p_ -= 2 * k; return *this; }
+    friend table_iterator operator+(table_iterator a, difference_type k) { return a += k; }
+    friend table_iterator operator+(difference_type k, table_iterator a) { return a += k; }
+    friend table_iterator operator-(table_iterator a, difference_type k) { return a -= k; }
+    friend difference_type operator-(const table_iterator& a, const table_iterator& b) { return (a.p_ - b.p_) / 2; }
+    friend bool operator==(const table_iterator& a, const table_iterator& b) { return a.p_ == b.p_; }
+    friend bool operator!=(const table_iterator& a, const table_iterator& b) { return a.p_ != b.p_; }
+    friend bool operator<(const table_iterator& a, const table_iterator& b) { return a.p_ < b.p_; }
+    friend bool operator>(const table_iterator& a, const table_iterator& b) { return a.p_ > b.p_; }
+    friend bool operator<=(const table_iterator& a, const table_iterator& b) { return a.p_ <= b.p_; }
+    friend bool operator>=(const table_iterator& a, const table_iterator& b) { return a.p_ >= b.p_; }
+
+private:
+    const uint32_t* p_ = nullptr;
+    Key key_{};
+};
+}  // namespace detail
 
 template <typename Point>
 class scene;
@@ -21,12 +69,14 @@ class model {
 public:
     typedef std::unique_ptr<model<Point>> uptr_t;
     typedef std::shared_ptr<model<Point>> sptr_t;
+    typedef std::weak_ptr<model<Point>> wptr_t;
     typedef std::shared_ptr<const model<Point>> const_sptr_t;
+    typedef std::weak_ptr<const model<Point>> const_wptr_t;
     typedef pointcloud<Point> cloud_t;
     typedef std::tuple<uint32_t, uint32_t> result_t;
     /* the reference iterates unordered_multimap nodes: `it->second` is the (i, j) tuple */
     typedef std::pair<discrete_feature_t, result_t> entry_t;
-    typedef typename std::vector<entry_t>::const_iterator pair_iter_t;
+    typedef detail::table_iterator<discrete_feature_t, result_t> pair_iter_t;
     typedef std::array<uint32_t, voxel_multiplicity> voxel_data_t;
 
     model(typename cloud_t::ConstPtr cloud, discretization_params params, int device = 0)
@@ -90,20 +140,37 @@ public:
         uint64_t entries = 0;
         tm_model_get_pair_counts(h_, &entries, nullptr, nullptr);
         pair_count_ = entries;
+        {
+            std::lock_guard<std::mutex> lk(table_mutex_);
+            table_ready_ = false; /* a second init() rebuilds the mirror on the next query */
+        }
         init_ = true;
     }
 
-    /* include/impl/model.hpp:169-178; throws like the reference when called before init() */
+    /* include/impl/model.hpp:169-178; throws like the reference when called before init(). The reference's
+     * workers call query() concurrently (include/impl/scene.hpp:304) and get iterators into the model's own
+     * multimap. Here the range points into a host mirror of the device table (8 bytes per entry, canonical
+     * order), downloaded once on the first query under a mutex and read-only from then on: query() is
+     * re-entrant and a returned range stays valid until the model is re-initialised or destroyed. (The search
+     * itself never comes here: it probes the table on the device.) */
     std::pair<pair_iter_t, pair_iter_t> query(const feature_t& f, bool = false) {
         if (!init_) throw std::runtime_error("Cannot query uninitialized model");
-        uint32_t total = 0;
-        detail::check(tm_model_query(h_, f.data(), nullptr, 0, &total), "tm_model_query");
-        std::vector<uint32_t> raw(2 * (size_t)total);
-        if (total) detail::check(tm_model_query(h_, f.data(), raw.data(), total, &total), "tm_model_query");
-        discrete_feature_t key = discretize_feature<Point>(f, bounds_, params_);
-        last_query_.resize(total);
-        for (uint32_t k = 0; k < total; ++k) last_query_[k] = {key, result_t{raw[2 * k], raw[2 * k + 1]}};
-        return {last_query_.cbegin(), last_query_.cend()};
+        ensure_table();
+        const discrete_feature_t key = discretize_feature<Point>(f, bounds_, params_);
+        /* keys are sorted lexicographically (tm_model_download_table) */
+        size_t lo = 0, hi = t_keys_.size() / 4;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (std::lexicographical_compare(t_keys_.begin() + 4 * mid, t_keys_.begin() + 4 * mid + 4, key.begin(),
+                                             key.end()))
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const bool hit = lo < t_keys_.size() / 4 && std::equal(key.begin(), key.end(), t_keys_.begin() + 4 * lo);
+        const uint32_t* base = t_pairs_.data();
+        if (!hit) return {pair_iter_t(base, key), pair_iter_t(base, key)};
+        return {pair_iter_t(base + 2 * (size_t)t_offsets_[lo], key), pair_iter_t(base + 2 * (size_t)t_offsets_[lo + 1], key)};
     }
 
     /* include/impl/model.hpp:180-192 */
@@ -132,6 +199,20 @@ public:
     tm_ctx* context() const { return ctx_->ctx; }
 
 protected:
+    void ensure_table() {
+        std::lock_guard<std::mutex> lk(table_mutex_);
+        if (table_ready_) return;
+        uint64_t entries = 0;
+        uint32_t n_keys = 0;
+        detail::check(tm_model_get_pair_counts(h_, &entries, nullptr, &n_keys), "tm_model_get_pair_counts");
+        t_keys_.assign(4 * (size_t)n_keys, 0u);
+        t_offsets_.assign((size_t)n_keys + 1, 0u);
+        t_pairs_.assign(2 * (size_t)entries + 2, 0u);
+        detail::check(tm_model_download_table(h_, t_keys_.data(), t_offsets_.data(), n_keys, t_pairs_.data(), entries),
+                      "tm_model_download_table");
+        table_ready_ = true;
+    }
+
     typename cloud_t::ConstPtr cloud_;
     discretization_params params_;
     std::shared_ptr<detail::context_holder> ctx_;
@@ -144,7 +225,9 @@ protected:
     feature_bounds_t bounds_;
     uint64_t pair_count_ = 0;
     uint32_t curvature_k_ = 30;
-    std::vector<entry_t> last_query_;
+    std::mutex table_mutex_;
+    bool table_ready_ = false;
+    std::vector<uint32_t> t_keys_, t_offsets_, t_pairs_; /* host mirror of the key table (CSR, canonical order) */
 };
 
 }  // namespace triplet_match

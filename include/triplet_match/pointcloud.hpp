@@ -4,15 +4,20 @@
  * Mirrors the parts of the reference's pointcloud<Point> (include/pointcloud:13-93) the hot path
  * consumes: points, size(), from_pcd() (include/impl/pointcloud.hpp:58-64), resolution() (mean 1-NN
  * distance, :66-82; tm_cloud_resolution, GPU kd-tree 2-NN, unless set_resolution() supplied a value),
- * diameter() (:84-97) and curvature(k, idx) (:200-204; tm_cloud_curvature). The generic knn_* and
- * radius_search_* accessors and the range-v3 view adaptors are not on the path and are not provided
- * (the search's radius neighbourhood lives in scene.hpp).
+ * diameter() (:84-97), curvature(k, idx) (:200-204; tm_cloud_curvature), and the neighbour accessors
+ * knn_inclusive / knn_exclusive / radius_search_inclusive / radius_search_exclusive for an index or a point,
+ * curvature(float r, idx), set_indices(), reset_tree() (include/pointcloud:38-63, impl :100-210) over a tm_cloud
+ * handle (kd-tree on the device, built lazily under a mutex like the reference's tree). Result order =
+ * (squared distance, index) ascending, distances squared (as PCL returns). Not provided: kdtree() / native()
+ * (they hand out PCL objects) and the range-v3 view adaptors (unused; one of them does not compile upstream).
  */
 #ifndef TRIPLET_MATCH_POINTCLOUD_HPP_
 #define TRIPLET_MATCH_POINTCLOUD_HPP_
 
 #include <algorithm>
 #include <limits>
+#include <mutex>
+#include <utility>
 
 #include "common.hpp"
 #include "pcd_io.hpp"
@@ -47,18 +52,74 @@ public:
         return self;
     }
 
+    pointcloud() = default;
+    pointcloud(const pointcloud& o) : points(o.points), subset_(o.subset_) {}
+    pointcloud& operator=(const pointcloud& o) {
+        if (this != &o) {
+            points = o.points;
+            subset_ = o.subset_;
+            touch();
+        }
+        return *this;
+    }
+    ~pointcloud() { tm_cloud_destroy(tree_); }
+
     size_t size() const { return points.size(); }
     void push_back(const Point& p) {
         points.push_back(p);
-        resolution_ = diameter_ = -1.f;
+        touch();
+    }
+    /* Call after changing `points` in place: forgets resolution, diameter, curvature and the search tree. (The
+     * reference recomputes nothing either — its caches are just as sticky — but scene<Point> re-reads the cloud on
+     * every find_all_parallel; content_hash() below is how our scene notices an edit.) */
+    void touch() {
+        std::lock_guard<std::mutex> lk(mutex_);
+        if (!resolution_fixed_) resolution_ = -1.f;
+        diameter_ = -1.f;
         curv_k_ = 0;
+        tm_cloud_destroy(tree_);
+        tree_ = nullptr;
+    }
+    /* forgets the caches if they were filled for other content than `hash` (= content_hash() of now) */
+    void sync(uint64_t hash) {
+        if (curv_k_ != 0 && curv_hash_ != hash) touch();
+    }
+    /* 64-bit hash of the raw surfel bytes (four interleaved multiply-xorshift lanes; ~5 ms per million points):
+     * scene<Point> keys its device copy on it, so an in-place edit of the points is never searched stale */
+    uint64_t content_hash() const {
+        const size_t n_words = points.size() * (sizeof(Point) / 8);
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(points.data());
+        uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+        size_t i = 0;
+        for (; i + 4 <= n_words; i += 4)
+            for (int l = 0; l < 4; ++l) {
+                uint64_t v;
+                std::memcpy(&v, w + i + l, 8);
+                h[l] = (h[l] ^ v) * 0xFF51AFD7ED558CCDull;
+                h[l] ^= h[l] >> 29;
+            }
+        for (; i < n_words; ++i) {
+            uint64_t v;
+            std::memcpy(&v, w + i, 8);
+            h[0] = (h[0] ^ v) * 0xFF51AFD7ED558CCDull;
+            h[0] ^= h[0] >> 29;
+        }
+        uint64_t r = (uint64_t)points.size();
+        for (int l = 0; l < 4; ++l) {
+            r = (r ^ h[l]) * 0xC4CEB9FE1A85EC53ull;
+            r ^= r >> 32;
+        }
+        return r;
     }
     const Point& operator[](size_t i) const { return points[i]; }
     Point& operator[](size_t i) { return points[i]; }
     typename std::vector<Point>::const_iterator begin() const { return points.begin(); }
     typename std::vector<Point>::const_iterator end() const { return points.end(); }
 
-    void set_resolution(float r) { resolution_ = r; }
+    void set_resolution(float r) { /* a value supplied by the caller survives touch() */
+        resolution_ = r;
+        resolution_fixed_ = true;
+    }
 
     /* mean distance to the nearest other point (include/impl/pointcloud.hpp:66-82): 2-NN distances from
      * a kd-tree kernel on the GPU, running mean accum + (val - accum)/(++i) in f32 in point order as the
@@ -84,11 +145,98 @@ public:
                 detail::check(tm_cloud_curvature(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, curv_.data()),
                               "tm_cloud_curvature");
             curv_k_ = k;
+            curv_hash_ = content_hash();
         }
         curvature_info_t c;
         c.pc_max_dir = {curv_[5 * (size_t)idx], curv_[5 * (size_t)idx + 1], curv_[5 * (size_t)idx + 2]};
         c.pc_min = curv_[5 * (size_t)idx + 3];
         c.pc_max = curv_[5 * (size_t)idx + 4];
+        return c;
+    }
+
+    /* ---- neighbour accessors (include/pointcloud:38-63) ---- */
+    typedef std::pair<std::vector<int>, std::vector<float>> neighbours_t; /* (indices, squared distances) */
+
+    /* set_indices(subset): the tree is rebuilt over these points only (include/pointcloud:95-103, impl :224-240) */
+    void set_indices(subset_t subset) {
+        std::lock_guard<std::mutex> lk(mutex_);
+        subset_ = std::move(subset);
+        tm_cloud_destroy(tree_);
+        tree_ = nullptr;
+    }
+    void reset_tree() { /* include/impl/pointcloud.hpp:105-111 */
+        std::lock_guard<std::mutex> lk(mutex_);
+        tm_cloud_destroy(tree_);
+        tree_ = nullptr;
+    }
+
+    /* knn_inclusive(k, point), include/impl/pointcloud.hpp:138-146: the k nearest points of the tree, the query's
+     * own point included when it is one of them */
+    neighbours_t knn_inclusive(uint32_t k, const Point& point) const {
+        neighbours_t out;
+        if (k == 0) return out;
+        tm_cloud* t = tree();
+        const float q[3] = {point.x, point.y, point.z};
+        out.first.assign(k, -1);
+        out.second.assign(k, 0.f);
+        uint32_t count = 0;
+        detail::check(tm_cloud_knn(t, q, 1, k, out.first.data(), out.second.data(), &count), "tm_cloud_knn");
+        out.first.resize(count); /* PCL resizes to what it found */
+        out.second.resize(count);
+        return out;
+    }
+    neighbours_t knn_inclusive(uint32_t k, uint32_t idx) const { return knn_inclusive(k, points[idx]); } /* :148-152 */
+    /* knn_exclusive: k + 1 neighbours without the first (:154-166) */
+    neighbours_t knn_exclusive(uint32_t k, const Point& point) const { return tail(knn_inclusive(k + 1, point)); }
+    neighbours_t knn_exclusive(uint32_t k, uint32_t idx) const { return knn_exclusive(k, points[idx]); }
+    /* several queries in one launch (no counterpart in the reference, whose callers loop): row-major k columns,
+     * rows padded with -1 / +inf */
+    void knn_batch(uint32_t k, const std::vector<uint32_t>& queries, std::vector<int>& indices,
+                   std::vector<float>& sq_dists) const {
+        indices.assign((size_t)queries.size() * k, -1);
+        sq_dists.assign((size_t)queries.size() * k, 0.f);
+        if (queries.empty() || k == 0) return;
+        std::vector<float> q(3 * queries.size());
+        for (size_t i = 0; i < queries.size(); ++i) {
+            q[3 * i] = points[queries[i]].x;
+            q[3 * i + 1] = points[queries[i]].y;
+            q[3 * i + 2] = points[queries[i]].z;
+        }
+        detail::check(tm_cloud_knn(tree(), q.data(), (uint32_t)queries.size(), k, indices.data(), sq_dists.data(),
+                                   nullptr),
+                      "tm_cloud_knn");
+    }
+
+    /* radius_search_inclusive(r, point), :168-176 */
+    neighbours_t radius_search_inclusive(float r, const Point& point) const {
+        neighbours_t out;
+        tm_cloud* t = tree();
+        const float q[3] = {point.x, point.y, point.z};
+        uint32_t count = 0;
+        detail::check(tm_cloud_radius_search(t, q, r, nullptr, nullptr, 0, &count), "tm_cloud_radius_search");
+        out.first.resize(count);
+        out.second.resize(count);
+        if (count)
+            detail::check(tm_cloud_radius_search(t, q, r, out.first.data(), out.second.data(), count, &count),
+                          "tm_cloud_radius_search");
+        return out;
+    }
+    neighbours_t radius_search_inclusive(float r, uint32_t idx) const { return radius_search_inclusive(r, points[idx]); }
+    neighbours_t radius_search_exclusive(float r, const Point& point) const { /* :184-190 */
+        return tail(radius_search_inclusive(r, point));
+    }
+    neighbours_t radius_search_exclusive(float r, uint32_t idx) const { return radius_search_exclusive(r, points[idx]); }
+
+    /* curvature(float r, idx), :206-209: principal curvatures over radius_search_inclusive(r, idx).first */
+    curvature_info_t curvature(float r, uint32_t idx) const {
+        const neighbours_t nb = radius_search_inclusive(r, idx);
+        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        detail::check(tm_cloud_curvature_of(tree(), idx, nb.first.data(), (uint32_t)nb.first.size(), c5),
+                      "tm_cloud_curvature_of");
+        curvature_info_t c;
+        c.pc_max_dir = {c5[0], c5[1], c5[2]};
+        c.pc_min = c5[3];
+        c.pc_max = c5[4];
         return c;
     }
 
@@ -108,10 +256,35 @@ public:
     }
 
 private:
+    static neighbours_t tail(neighbours_t nb) { /* vw::tail of both lists (:157-158) */
+        if (!nb.first.empty()) {
+            nb.first.erase(nb.first.begin());
+            nb.second.erase(nb.second.begin());
+        }
+        return nb;
+    }
+    /* kdtree() const (:120-128): built on first use, under the mutex */
+    tm_cloud* tree() const {
+        std::lock_guard<std::mutex> lk(mutex_);
+        if (!tree_) {
+            static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
+            auto ctx = detail::default_context(0);
+            detail::check(tm_cloud_create(ctx->ctx, points.empty() ? nullptr : points[0].raw(), (uint32_t)points.size(),
+                                          subset_.empty() ? nullptr : subset_.data(), (uint32_t)subset_.size(), &tree_),
+                          "tm_cloud_create");
+        }
+        return tree_;
+    }
+
+    mutable tm_cloud* tree_ = nullptr;
+    mutable std::mutex mutex_;
+    subset_t subset_;
     mutable float resolution_ = -1.f;
+    bool resolution_fixed_ = false;
     mutable float diameter_ = -1.f;
     mutable std::vector<float> curv_;
     mutable uint32_t curv_k_ = 0;
+    mutable uint64_t curv_hash_ = 0;
 };
 
 }  // namespace triplet_match

@@ -279,6 +279,8 @@ class scene {
 public:
     typedef std::unique_ptr<scene<Point>> uptr_t;
     typedef std::shared_ptr<scene<Point>> sptr_t;
+    typedef std::weak_ptr<scene<Point>> wptr_t;
+    typedef std::weak_ptr<const scene<Point>> const_wptr_t;
     typedef model<Point> model_t;
     typedef pointcloud<Point> cloud_t;
 
@@ -544,10 +546,18 @@ public:
 
 protected:
     /* tangent_mask_ (include/impl/scene.hpp:46-54) and the device copy of the scene: the prepared scene (56 MB
-     * upload + sort for 1M points) is reused while cloud size and tangent mask are unchanged; the searches
-     * reset mask_ themselves */
+     * upload + sort for 1M points) is reused while the cloud's CONTENT (a 64-bit hash of the raw surfel bytes,
+     * ~5 ms per million points) and the mask settings are unchanged — the reference re-reads cloud_ on every call,
+     * so an in-place edit of the points between two calls must be seen; the searches reset mask_ themselves */
     void ensure_scene(std::vector<int32_t>& tangent_mask) {
         const uint32_t n = (uint32_t)cloud_->size();
+        const uint64_t hash = cloud_->content_hash();
+        cloud_->sync(hash); /* curvature computed for other content is forgotten */
+        if (h_ && hash != cached_hash_) invalidate();
+        if (h_ && cached_n_ == n && cached_curv_k_ == curvature_k_ && cached_curv_ok_ == curvature_ok_) {
+            tangent_mask = cached_tmask_; /* same content, same settings: the mask is the one already built */
+            return;
+        }
         tangent_mask.assign(n, 0);
         for (uint32_t i = 0; i < n; ++i) {
             bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
@@ -562,9 +572,12 @@ protected:
         if (!h_) {
             detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
                           "tm_scene_create");
-            cached_n_ = n;
-            cached_tmask_ = tangent_mask;
         }
+        cached_n_ = n;
+        cached_tmask_ = tangent_mask;
+        cached_hash_ = hash;
+        cached_curv_k_ = curvature_k_;
+        cached_curv_ok_ = curvature_ok_;
     }
     void fill_params(search::params_t& p, float dist_thres, float model_match_factor, float early_out_factor,
                      const sample_parameters& sample_params, uint32_t max_icp_iterations) {
@@ -591,6 +604,9 @@ protected:
     tm_comm* comm_ = nullptr;
     uint32_t cached_n_ = 0;
     std::vector<int32_t> cached_tmask_;
+    uint64_t cached_hash_ = 0;
+    uint32_t cached_curv_k_ = 0;
+    std::vector<uint8_t> cached_curv_ok_;
     bool early_drop_ = true;
     bool verbose_ = false;
     search::stats_t stats_;

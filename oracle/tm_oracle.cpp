@@ -600,6 +600,95 @@ void tmo_cloud_curvature(const float* surfels, uint32_t n, uint32_t k, float* cu
     });
 }
 
+/* pointcloud<Point>::knn_inclusive(k, point) (include/impl/pointcloud.hpp:138-146) and
+ * radius_search_inclusive(r, point) (:168-176) restated exhaustively: every finite point of the cloud (or of
+ * `subset`, set_indices / build_tree_ :224-240) against the query, order (squared distance, index) ascending —
+ * FLANN leaves ties open, this is the order the restatement defines. Distances are squared, as PCL returns. */
+static void cloud_candidates(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                             const float q[3], std::vector<std::pair<float, uint32_t>>& nb) {
+    nb.clear();
+    if (!finite3(v3{q[0], q[1], q[2]})) return;
+    auto add = [&](uint32_t j) {
+        const float* p = surfels + (size_t)j * 12;
+        if (!finite3(s_pos(p))) return;
+        float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        nb.push_back({(dx * dx + dy * dy) + dz * dz, j});
+    };
+    if (n_subset)
+        for (uint32_t k = 0; k < n_subset; ++k) add(subset[k]);
+    else
+        for (uint32_t j = 0; j < n; ++j) add(j);
+}
+
+uint32_t tmo_cloud_knn(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                       const float query[3], uint32_t k, int32_t* indices, float* sq_dists) {
+    std::vector<std::pair<float, uint32_t>> nb;
+    cloud_candidates(surfels, n, subset, n_subset, query, nb);
+    const uint32_t kk = std::min<uint32_t>(k, (uint32_t)nb.size());
+    std::partial_sort(nb.begin(), nb.begin() + kk, nb.end());
+    for (uint32_t j = 0; j < kk; ++j) {
+        indices[j] = (int32_t)nb[j].second;
+        sq_dists[j] = nb[j].first;
+    }
+    return kk;
+}
+
+uint32_t tmo_cloud_radius_search(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                                 const float query[3], float radius, int32_t* indices, float* sq_dists,
+                                 uint32_t cap) {
+    std::vector<std::pair<float, uint32_t>> nb, in;
+    cloud_candidates(surfels, n, subset, n_subset, query, nb);
+    const float r2 = radius * radius;
+    for (const auto& c : nb)
+        if (c.first <= r2) in.push_back(c);
+    std::sort(in.begin(), in.end());
+    for (uint32_t j = 0; j < in.size() && j < cap; ++j) {
+        if (indices) indices[j] = (int32_t)in[j].second;
+        if (sq_dists) sq_dists[j] = in[j].first;
+    }
+    return (uint32_t)in.size();
+}
+
+/* principal_curvatures(cloud, p_idx, indices) (include/impl/pointcloud.hpp:3-44) over an explicit neighbour list:
+ * what curvature(float r, idx) evaluates on radius_search_inclusive(r, idx).first (:206-209) */
+void tmo_cloud_curvature_of(const float* surfels, uint32_t p_idx, const int32_t* indices, uint32_t n_idx,
+                            float curv5[5]) {
+    for (int c = 0; c < 5; ++c) curv5[c] = 0.f;
+    if (n_idx == 0) return;
+    v3 n0 = s_nrm(surfels + (size_t)p_idx * 12);
+    float n0a[3] = {n0.x, n0.y, n0.z};
+    float M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = (r == c ? 1.f : 0.f) - n0a[r] * n0a[c]; /* :8-10 */
+    float cen[3] = {0, 0, 0};
+    std::vector<std::array<float, 3>> proj(n_idx);
+    for (uint32_t j = 0; j < n_idx; ++j) { /* :13-16 */
+        v3 nj = s_nrm(surfels + (size_t)indices[j] * 12);
+        for (int r = 0; r < 3; ++r) {
+            proj[j][r] = (M[r][0] * nj.x + M[r][1] * nj.y) + M[r][2] * nj.z;
+            cen[r] = cen[r] + (proj[j][r] - cen[r]) / (float)(j + 1);
+        }
+    }
+    float cov[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t j = 0; j < n_idx; ++j) { /* :19-35 */
+        float d[3] = {proj[j][0] - cen[0], proj[j][1] - cen[1], proj[j][2] - cen[2]};
+        cov[0] += d[0] * d[0];
+        cov[1] += d[0] * d[1];
+        cov[2] += d[0] * d[2];
+        cov[3] += d[1] * d[1];
+        cov[4] += d[1] * d[2];
+        cov[5] += d[2] * d[2];
+    }
+    float ev[3], vmax[3];
+    oracle_jacobi3(cov, ev, vmax);
+    float area_inv = 1.0f / (float)n_idx; /* :42 */
+    curv5[0] = vmax[0];
+    curv5[1] = vmax[1];
+    curv5[2] = vmax[2];
+    curv5[3] = ev[1] * area_inv;
+    curv5[4] = ev[2] * area_inv;
+}
+
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step) {
     tmo_model* m = new tmo_model();

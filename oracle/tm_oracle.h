@@ -56,6 +56,17 @@ float    tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, 
 /* cloud->curvature(k, i) for all i (pointcloud.hpp:3-44,200-204): curv5 = (dir xyz, pc_min, pc_max) */
 void     tmo_cloud_curvature(const float* surfels, uint32_t n, uint32_t k, float* curv5, int threads);
 
+/* knn_inclusive(k, point) / radius_search_inclusive(r, point) (pointcloud.hpp:138-146,168-176), exhaustive,
+ * order (squared distance, index); subset = set_indices (NULL, 0 = the whole cloud). Return the number found. */
+uint32_t tmo_cloud_knn(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                       const float query[3], uint32_t k, int32_t* indices, float* sq_dists);
+uint32_t tmo_cloud_radius_search(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
+                                 const float query[3], float radius, int32_t* indices, float* sq_dists,
+                                 uint32_t cap);
+/* principal_curvatures over an explicit neighbour list (pointcloud.hpp:3-44; curvature(float r, idx) :206-209) */
+void     tmo_cloud_curvature_of(const float* surfels, uint32_t p_idx, const int32_t* indices, uint32_t n_idx,
+                                float curv5[5]);
+
 /* ---- model (a6..a9) ---- */
 tmo_model* tmo_model_create(const float* surfels, uint32_t n, float resolution,
                             float distance_step_count, float angle_step);

@@ -63,6 +63,12 @@ def lib():
         L.tmo_cloud_resolution.restype = C.c_float
         L.tmo_cloud_resolution.argtypes = [f32p, C.c_uint32, f32p, C.c_int]
         L.tmo_cloud_curvature.argtypes = [f32p, C.c_uint32, C.c_uint32, f32p, C.c_int]
+        L.tmo_cloud_knn.restype = C.c_uint32
+        L.tmo_cloud_knn.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, f32p, C.c_uint32, i32p, f32p]
+        L.tmo_cloud_radius_search.restype = C.c_uint32
+        L.tmo_cloud_radius_search.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, f32p, C.c_float, i32p, f32p,
+                                              C.c_uint32]
+        L.tmo_cloud_curvature_of.argtypes = [f32p, C.c_uint32, i32p, C.c_uint32, f32p]
         L.tmo_model_create.restype = C.c_void_p
         L.tmo_model_create.argtypes = [f32p, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.tmo_model_destroy.argtypes = [C.c_void_p]
@@ -163,6 +169,36 @@ def cloud_curvature(surfels, k=30, threads=8):
     s, p = _f(np.asarray(surfels).reshape(-1, 12))
     out = np.zeros((s.shape[0], 5), np.float32)
     lib().tmo_cloud_curvature(p, s.shape[0], k, out.ctypes.data_as(f32p), threads)
+    return out
+
+
+def cloud_knn(surfels, query, k, subset=None):
+    """knn_inclusive(k, point): (indices, squared distances), order (d2, index)"""
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    q, qp = _f(np.asarray(query, np.float32).reshape(3))
+    sub, sp, ns = (None, None, 0) if subset is None else (*_u(subset), len(subset))
+    idx = np.zeros(k, np.int32)
+    d2 = np.zeros(k, np.float32)
+    n = lib().tmo_cloud_knn(p, s.shape[0], sp, ns, qp, k, idx.ctypes.data_as(i32p), d2.ctypes.data_as(f32p))
+    return idx[:n], d2[:n]
+
+
+def cloud_radius_search(surfels, query, radius, subset=None):
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    q, qp = _f(np.asarray(query, np.float32).reshape(3))
+    sub, sp, ns = (None, None, 0) if subset is None else (*_u(subset), len(subset))
+    n = lib().tmo_cloud_radius_search(p, s.shape[0], sp, ns, qp, radius, None, None, 0)
+    idx = np.zeros(n, np.int32)
+    d2 = np.zeros(n, np.float32)
+    lib().tmo_cloud_radius_search(p, s.shape[0], sp, ns, qp, radius, idx.ctypes.data_as(i32p), d2.ctypes.data_as(f32p), n)
+    return idx, d2
+
+
+def cloud_curvature_of(surfels, p_idx, indices):
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    nb = np.ascontiguousarray(indices, np.int32)
+    out = np.zeros(5, np.float32)
+    lib().tmo_cloud_curvature_of(p, p_idx, nb.ctypes.data_as(i32p), len(nb), out.ctypes.data_as(f32p))
     return out
 
 

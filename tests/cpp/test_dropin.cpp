@@ -6,7 +6,10 @@
  */
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <fstream>
+#include <functional>
+#include <thread>
 
 #include "triplet_match/cylinder_traits.hpp"
 #include "triplet_match/identity_traits.hpp"
@@ -145,7 +148,7 @@ int main(int argc, char** argv) {
     /* curvature(k, idx) through the cloud (GPU kNN-30); the curvature-ratio filter is on by default (as in the
      * reference) and can be switched off */
     {
-        curvature_info_t ci = mcloud->curvature(30, 0);
+        curvature_info_t ci = mcloud->curvature(30u, 0u);
         CHECK(ci.pc_max >= ci.pc_min && ci.pc_min >= -1e-6f, "pointcloud::curvature(30, i): pc_max >= pc_min >= 0");
         model<P> mc(mcloud, dp);
         mc.disable_curvature_filter();
@@ -153,6 +156,135 @@ int main(int argc, char** argv) {
         CHECK(mc.point_count() >= m.point_count(), "curvature filter can only shrink the tangent subset");
         printf("     tangent subset: %u points with the reference's curvature-ratio filter, %u without\n", m.point_count(),
                mc.point_count());
+    }
+
+    /* neighbour accessors of the cloud (include/pointcloud:38-63) against an exhaustive scan with the same f32
+     * expression: order (squared distance, index), squared distances, exclusive = inclusive without the first */
+    {
+        auto brute = [&](const pointcloud<P>& c, const P& q) {
+            std::vector<std::pair<float, int>> nb;
+            for (size_t j = 0; j < c.size(); ++j) {
+                float dx = c.points[j].x - q.x, dy = c.points[j].y - q.y, dz = c.points[j].z - q.z;
+                nb.push_back({(dx * dx + dy * dy) + dz * dz, (int)j});
+            }
+            std::sort(nb.begin(), nb.end());
+            return nb;
+        };
+        bool knn_ok = true, rad_ok = true, ex_ok = true;
+        for (uint32_t idx : {0u, 17u, 500u, (uint32_t)mcloud->size() - 1u}) {
+            auto ref = brute(*mcloud, mcloud->points[idx]);
+            for (uint32_t k : {1u, 7u, 30u, 40u}) { /* 40 > 32: the one-pass route */
+                auto nb = mcloud->knn_inclusive(k, idx);
+                knn_ok = knn_ok && nb.first.size() == k && nb.second.size() == k;
+                for (uint32_t j = 0; j < k && knn_ok; ++j)
+                    knn_ok = nb.first[j] == ref[j].second && nb.second[j] == ref[j].first;
+                auto ex = mcloud->knn_exclusive(k, idx);
+                ex_ok = ex_ok && ex.first.size() == k;
+                for (uint32_t j = 0; j < k && ex_ok; ++j) ex_ok = ex.first[j] == ref[j + 1].second;
+            }
+            const float r = 4.f * res;
+            auto rn = mcloud->radius_search_inclusive(r, idx);
+            size_t want = 0;
+            while (want < ref.size() && ref[want].first <= r * r) ++want;
+            rad_ok = rad_ok && rn.first.size() == want;
+            for (size_t j = 0; j < want && rad_ok; ++j) rad_ok = rn.first[j] == ref[j].second && rn.second[j] == ref[j].first;
+            auto rx = mcloud->radius_search_exclusive(r, idx);
+            ex_ok = ex_ok && rx.first.size() + 1 == want && (want < 2 || rx.first[0] == ref[1].second);
+        }
+        CHECK(knn_ok, "knn_inclusive(k, idx): k nearest, (squared distance, index) order, squared distances");
+        CHECK(rad_ok, "radius_search_inclusive(r, idx): exactly the points with d2 <= r*r, ordered");
+        CHECK(ex_ok, "knn_exclusive / radius_search_exclusive: the inclusive result without its first entry");
+        P off = mcloud->points[3];
+        off.x += 0.37f * res;
+        auto nbp = mcloud->knn_inclusive(5, off);
+        auto refp = brute(*mcloud, off);
+        bool pt_ok = nbp.first.size() == 5;
+        for (uint32_t j = 0; j < 5 && pt_ok; ++j) pt_ok = nbp.first[j] == refp[j].second;
+        CHECK(pt_ok, "knn_inclusive(k, point): a query that is not a cloud point");
+        /* curvature(float r, idx) = principal curvatures over radius_search_inclusive(r, idx); with the radius of
+         * the 30th neighbour it must equal curvature(30u, idx) whenever no tie straddles that radius */
+        auto n30 = mcloud->knn_inclusive(31, 11u);
+        if (n30.second[30] > n30.second[29]) {
+            const float r30 = std::sqrt(0.5f * (n30.second[29] + n30.second[30]));
+            curvature_info_t a = mcloud->curvature(30u, 11u), b = mcloud->curvature(r30, 11u);
+            CHECK(a.pc_min == b.pc_min && a.pc_max == b.pc_max, "curvature(float r, idx) == curvature(k, idx) on the same neighbours");
+        }
+        /* set_indices: the tree holds the subset only; reset */
+        auto sub_cloud = pointcloud<P>::empty();
+        sub_cloud->points = mcloud->points;
+        subset_t evens;
+        for (uint32_t i = 0; i < sub_cloud->size(); i += 2) evens.push_back(i);
+        sub_cloud->set_indices(evens);
+        auto se = sub_cloud->knn_inclusive(6, 1u); /* point 1 itself is not in the tree */
+        bool sub_ok = se.first.size() == 6;
+        for (int i : se.first) sub_ok = sub_ok && (i % 2 == 0);
+        sub_cloud->set_indices(subset_t());
+        sub_ok = sub_ok && sub_cloud->knn_inclusive(1, 1u).first[0] == 1;
+        CHECK(sub_ok, "set_indices(subset): queries answer from the subset; empty subset = whole cloud again");
+    }
+
+    /* query() is re-entrant (the reference's workers call it concurrently, include/impl/scene.hpp:304): ranges
+     * of earlier calls stay valid, threads do not disturb each other */
+    {
+        std::vector<uint32_t> tang;
+        for (uint32_t i = 0; i < mcloud->size(); ++i)
+            if (tangent(mcloud->points[i]).norm() > 0.7f) tang.push_back(i);
+        std::vector<feature_t> fs;
+        for (size_t a = 0; a + 1 < tang.size() && fs.size() < 64; a += 2) {
+            auto fij = feature<P>(mcloud->points[tang[a]], mcloud->points[tang[a + 1]]);
+            if (valid<P>(*fij, m.feature_bounds())) fs.push_back(*fij);
+        }
+        auto r0 = m.query(fs[0]);
+        std::vector<std::pair<uint32_t, uint32_t>> first;
+        for (auto it = r0.first; it != r0.second; ++it) first.push_back({std::get<0>(it->second), std::get<1>(it->second)});
+        std::vector<uint64_t> sums(4, 0), sums_serial(4, 0);
+        auto work = [&](int t, std::vector<uint64_t>& out) {
+            uint64_t acc = 0;
+            for (int rep = 0; rep < 20; ++rep)
+                for (size_t k = t; k < fs.size(); k += 4) {
+                    auto r = m.query(fs[k]);
+                    for (auto it = r.first; it != r.second; ++it)
+                        acc = acc * 1099511628211ull + std::get<0>(it->second) * 65537ull + std::get<1>(it->second);
+                }
+            out[t] = acc;
+        };
+        for (int t = 0; t < 4; ++t) work(t, sums_serial);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 4; ++t) th.emplace_back(work, t, std::ref(sums));
+        for (auto& x : th) x.join();
+        bool same = sums == sums_serial;
+        size_t k = 0;
+        for (auto it = r0.first; it != r0.second; ++it, ++k) /* the first range, after 5,000 other queries */
+            same = same && k < first.size() && first[k].first == std::get<0>(it->second) && first[k].second == std::get<1>(it->second);
+        CHECK(same && k == first.size() && !first.empty(), "query(): concurrent callers, and a range outlives later queries");
+        CHECK((size_t)(r0.second - r0.first) == first.size(), "pair_iter_t: random-access distance");
+    }
+
+    /* an in-place edit of the scene cloud between two searches is seen (the reference re-reads cloud_ per call):
+     * shift every point; the matches must move with them */
+    if (!matches.empty()) {
+        const vec3f_t shift(0.25f, -0.5f, 0.125f);
+        for (auto& p : scloud->points) {
+            p.x += shift[0];
+            p.y += shift[1];
+            p.z += shift[2];
+        }
+        auto moved = s.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, 2);
+        bool ok_moved = moved.size() == matches.size();
+        for (size_t k = 0; k < moved.size() && ok_moved; ++k) {
+            double worst = 1e30;
+            for (const auto& old : matches) {
+                double e = 0;
+                for (size_t q = 0; q < mcloud->size(); q += 97) {
+                    vec4f_t a = moved[k].transform * homogeneous(mcloud->points[q].getVector3fMap());
+                    vec4f_t b = old.transform * homogeneous(mcloud->points[q].getVector3fMap());
+                    e = std::max(e, (double)(a.head3() - (b.head3() + shift)).norm());
+                }
+                worst = std::min(worst, e);
+            }
+            ok_moved = worst < 2.0 * res;
+        }
+        CHECK(ok_moved, "find_all_parallel(): points edited in place between two calls are searched as edited");
     }
 
     /* traits statics */

@@ -26,7 +26,7 @@ def _compile(name, extra=()):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wno-comment", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            "-L" + os.path.join(ROOT, "triplet_match_amd"), "-ltm_hip",
-           "-Wl,-rpath," + os.path.join(ROOT, "triplet_match_amd")] + list(extra)
+           "-Wl,-rpath," + os.path.join(ROOT, "triplet_match_amd"), "-pthread"] + list(extra)
     subprocess.check_call(cmd)
     return out
 
@@ -56,6 +56,16 @@ def _oracle_link():
 def test_dropin_headers_compile_with_host_compiler():
     _compile("test_dropin")
     _compile("test_search", _oracle_link())
+
+
+def test_reference_header_names_compile():
+    """a caller written against the reference's installed headers (extension-less names, CMakeLists.txt:18) compiles
+    unchanged, as <triplet_match/scene> and — with that directory on the include path, as the reference's own app
+    does (apps/triplet_match.cpp:7) — as <scene>"""
+    _compile("test_refnames")
+    exe = _compile("test_refnames", ["-DTM_TEST_BARE_NAMES", "-I" + os.path.join(ROOT, "include", "triplet_match")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)  # no GPU call in it
+    assert r.returncode == 0 and "PASSED" in r.stdout
 
 
 def test_host_orchestration_over_oracle_backend(tmp_path):

@@ -1033,3 +1033,68 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
         assert np.array_equal(cm, cmb) and np.array_equal(sm, smb) and cm.max() < cb.max()
     finally:
         s.set_mask(None)
+
+
+def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case):
+    """tm_cloud (the neighbour accessors of pointcloud<Point>, include/pointcloud:38-63): kNN (kd-tree route k <= 32,
+    one-pass route k > 32) and radius search against the oracle's exhaustive scan — indices and squared distances
+    bit for bit, order (d2, index) — and, independently of both, against scipy's cKDTree (same neighbour SETS up to
+    ties at the last distance). Includes duplicated points (ties), a non-finite point, a subset tree, queries that
+    are not cloud points, and curvature over an explicit neighbour list."""
+    from oracle import tmo
+    from scipy.spatial import cKDTree
+    cloud = small_case["scene"]["surfels"][:6000].copy()
+    cloud[700:720, 0:3] = cloud[100:120, 0:3]  # exact duplicates: ties broken by index
+    cloud[33, 0] = np.nan
+    gc = capi.Cloud(gpu_ctx, cloud)
+    assert gc.tree_size() == 5999
+    rng = np.random.default_rng(5)
+    qidx = np.concatenate([[0, 100, 700, 5999], rng.integers(0, 6000, 60)])
+    queries = cloud[qidx, 0:3].copy()
+    queries[-10:] += rng.normal(size=(10, 3)).astype(np.float32) * 0.01  # not cloud points
+    queries = queries[np.isfinite(queries).all(axis=1)]
+    finite = np.isfinite(cloud[:, 0:3]).all(axis=1)
+    tree = cKDTree(cloud[finite, 0:3].astype(np.float64))
+    orig = np.nonzero(finite)[0]
+    for k in (1, 2, 30, 32, 33, 100):
+        idx, d2, cnt = gc.knn(queries, k)
+        assert (cnt == k).all()
+        for t, q in enumerate(queries):
+            oi, od = tmo.cloud_knn(cloud, q, k)
+            assert np.array_equal(idx[t], oi) and np.array_equal(d2[t].view(np.uint32), od.view(np.uint32)), (k, t)
+        # scipy: same distances (f64 vs f32: compare sorted distances loosely, sets exactly where no tie at the edge)
+        sd, si = tree.query(queries.astype(np.float64), k=k)
+        sd = sd.reshape(len(queries), k)
+        assert np.allclose(np.sqrt(d2.astype(np.float64)), sd, rtol=1e-5, atol=1e-6)
+    r = 6.0 * small_case["resolution"]
+    for t, q in enumerate(queries[:20]):
+        gi, gd = gc.radius_search(q, r)
+        oi, od = tmo.cloud_radius_search(cloud, q, r)
+        assert np.array_equal(gi, oi) and np.array_equal(gd.view(np.uint32), od.view(np.uint32))
+        assert (np.diff(gd) >= 0).all() and (gd <= np.float32(r) * np.float32(r)).all()
+        si = orig[np.array(tree.query_ball_point(q.astype(np.float64), r * (1 - 1e-6)), dtype=np.int64)]
+        assert set(si.tolist()) <= set(gi.tolist())  # everything clearly inside is there
+        si_out = orig[np.array(tree.query_ball_point(q.astype(np.float64), r * (1 + 1e-6)), dtype=np.int64)]
+        assert set(gi.tolist()) <= set(si_out.tolist())  # nothing clearly outside is
+        # curvature over that neighbour list == the oracle's principal_curvatures on the same list
+        if len(gi) >= 3:
+            p_idx = int(gi[0])
+            assert np.array_equal(gc.curvature_of(p_idx, gi).view(np.uint32),
+                                  tmo.cloud_curvature_of(cloud, p_idx, gi).view(np.uint32))
+    # a non-finite query has no neighbours; radius 0 around a cloud point returns its duplicates
+    idx, d2, cnt = gc.knn(np.array([[np.inf, 0, 0]], np.float32), 4)
+    assert cnt[0] == 0 and (idx == -1).all()
+    gi, gd = gc.radius_search(cloud[100, 0:3], 0.0)
+    assert gi.tolist() == [100, 700] and (gd == 0).all()
+    # set_indices: a tree over a subset
+    sub = np.arange(0, 6000, 3, dtype=np.uint32)
+    gs = capi.Cloud(gpu_ctx, cloud, subset=sub)
+    assert gs.tree_size() == len(sub) - 1  # point 33 is in the subset and not finite
+    idx, d2, cnt = gs.knn(queries[:16], 8)
+    for t, q in enumerate(queries[:16]):
+        oi, od = tmo.cloud_knn(cloud, q, 8, subset=sub)
+        assert np.array_equal(idx[t], oi) and np.array_equal(d2[t].view(np.uint32), od.view(np.uint32))
+    # fewer points than k: padded rows
+    tiny = capi.Cloud(gpu_ctx, cloud[:5])
+    idx, d2, cnt = tiny.knn(cloud[:2, 0:3], 9)
+    assert (cnt == 5).all() and (idx[:, 5:] == -1).all() and np.isinf(d2[:, 5:]).all()

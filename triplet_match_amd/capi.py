@@ -71,6 +71,12 @@ SIGNATURES = {
                                     C.c_float, f32p, u32p, u32p]),
     "tm_cloud_resolution": (C.c_int, [vp, f32p, C.c_uint32, f32p, f32p]),
     "tm_cloud_curvature": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, f32p]),
+    "tm_cloud_create": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, C.POINTER(vp)]),
+    "tm_cloud_destroy": (C.c_int, [vp]),
+    "tm_cloud_tree_size": (C.c_uint32, [vp]),
+    "tm_cloud_knn": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, i32p, f32p, u32p]),
+    "tm_cloud_radius_search": (C.c_int, [vp, f32p, C.c_float, i32p, f32p, C.c_uint32, u32p]),
+    "tm_cloud_curvature_of": (C.c_int, [vp, C.c_uint32, i32p, C.c_uint32, f32p]),
     "tm_model_create": (C.c_int, [vp, f32p, C.c_uint32, C.c_float, C.c_float, C.c_float,
                                   C.POINTER(vp)]),
     "tm_model_destroy": (C.c_int, [vp]),
@@ -503,6 +509,60 @@ def best_select(records):
     out = BestRecord()
     _check(lib().tm_best_select(arr, len(records), C.byref(out)))
     return out
+
+
+class Cloud:
+    """tm_cloud: the neighbour queries of pointcloud<Point> (kd-tree on the device)."""
+
+    def __init__(self, ctx, surfels, subset=None):
+        self.ctx = ctx
+        s, p = _f(surfels)
+        self.n = s.shape[0]
+        self.h = vp()
+        if subset is None:
+            _check(lib().tm_cloud_create(ctx.h, p, self.n, None, 0, C.byref(self.h)))
+        else:
+            sub, sp = _u(subset)
+            _check(lib().tm_cloud_create(ctx.h, p, self.n, sp, len(sub), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().tm_cloud_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def tree_size(self):
+        return int(lib().tm_cloud_tree_size(self.h))
+
+    def knn(self, queries_xyz, k):
+        """(indices [nq, k] int32, squared distances [nq, k] f32, counts [nq])"""
+        q, qp = _f(np.asarray(queries_xyz, np.float32).reshape(-1, 3))
+        nq = q.shape[0]
+        idx = np.zeros((nq, k), np.int32)
+        d2 = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().tm_cloud_knn(self.h, qp, nq, k, idx.ctypes.data_as(i32p), d2.ctypes.data_as(f32p),
+                                  cnt.ctypes.data_as(u32p)))
+        return idx, d2, cnt
+
+    def radius_search(self, query_xyz, radius):
+        q, qp = _f(np.asarray(query_xyz, np.float32).reshape(3))
+        n = C.c_uint32(0)
+        _check(lib().tm_cloud_radius_search(self.h, qp, radius, None, None, 0, C.byref(n)))
+        idx = np.zeros(n.value, np.int32)
+        d2 = np.zeros(n.value, np.float32)
+        if n.value:
+            _check(lib().tm_cloud_radius_search(self.h, qp, radius, idx.ctypes.data_as(i32p), d2.ctypes.data_as(f32p),
+                                                n.value, C.byref(n)))
+        return idx, d2
+
+    def curvature_of(self, idx, neighbours):
+        nb, nbp = _i(neighbours)
+        out = np.zeros(5, np.float32)
+        _check(lib().tm_cloud_curvature_of(self.h, idx, nbp, len(nb), out.ctypes.data_as(f32p)))
+        return out
 
 
 class Model:
