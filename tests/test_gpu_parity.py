@@ -551,6 +551,23 @@ def test_projected_traits_pipeline(gpu_ctx, kind):
     cg, sg = gs.score_hypotheses(gm, poses, DT, traits=K)
     assert np.array_equal(cg, co) and np.allclose(sg, so, rtol=SCORE_RTOL, atol=1e-15)
     assert co.max() > 0
+    # the brick filters under the model's metric (near_metric: 0 never, 1 auto, 2 always), grouped and per-hypothesis
+    # kernel, ball-restricted and exhaustive: one answer. A larger threshold moves the codes' cut.
+    centers = rng.choice(tidx, size=len(poses)).astype(np.uint32)
+    for dt in (DT, 1.0, 9.0):
+        cb, sb = gs.score_hypotheses(gm, poses, dt, traits=K, mode=capi.SCORE_BRUTEFORCE)
+        cball = None
+        for nm in (0, 1, 2):
+            with gpu_ctx.option("near_metric", nm):
+                c1, s1 = gs.score_hypotheses(gm, poses, dt, traits=K, mode=capi.SCORE_CULLED)
+                with gpu_ctx.option("score_grouped", 0):
+                    c2, s2 = gs.score_hypotheses(gm, poses, dt, traits=K, mode=capi.SCORE_CULLED)
+                c3, s3 = gs.score_hypotheses_ball(gm, poses, centers, gm.diameter, dt)
+            assert np.array_equal(c1, cb) and np.array_equal(s1, sb), (kind, dt, nm)
+            assert np.array_equal(c2, cb) and np.array_equal(s2, sb), (kind, dt, nm)
+            if cball is None:
+                cball = (c3, s3)
+            assert np.array_equal(c3, cball[0]) and np.array_equal(s3, cball[1]), (kind, dt, nm)
     with pytest.raises(capi.TmError):  # the metric is part of the model: a mismatching kind is refused
         gs.score_hypotheses(gm, poses, DT, traits=capi.IDENTITY)
     if kind == "cylinder":

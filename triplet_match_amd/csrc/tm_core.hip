@@ -94,7 +94,7 @@ static const opt_entry kOptions[] = {
     {"score_item_wgs", &options::score_item_wgs, 0, 1 << 20},
     {"score_parts", &options::score_parts, 1, 64},
     {"score_slot_mib", &options::score_slot_mib, 1, 1 << 16},
-    {"near_metric", &options::near_metric, 0, 1},
+    {"near_metric", &options::near_metric, 0, 2},
     {"model_morton", &options::model_morton, 0, 1},
     {"scene_morton", &options::scene_morton, 0, 1},
     {"voxel_bruteforce", &options::voxel_bruteforce, 0, 1},

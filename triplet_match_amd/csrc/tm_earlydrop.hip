@@ -829,6 +829,7 @@ using namespace tmx;
  * whose brick code exceeds code_max has no model point within thres; Euclidean metrics only */
 static void ed_brick_filter(const tm_model* m, float thres, score_args& sc) {
     sc.bcode = nullptr;
+    sc.bcode_tile = nullptr;
     sc.code_max = 255u;
     if (m->metric_kind > TM_TRAITS_PLANE || !(thres >= 0.f)) return;
     const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
@@ -836,6 +837,7 @@ static void ed_brick_filter(const tm_model* m, float thres, score_args& sc) {
     const float cm = std::floor((thres + slack) / m->brick_q) + 1.f;
     if (cm < 255.f) {
         sc.bcode = m->brick_code.p;
+        sc.bcode_tile = m->brick_code.p;
         sc.code_max = (uint32_t)cm;
     }
 }
@@ -917,6 +919,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
     a.sc.bcode = nullptr; /* bx/by still address the bricked voxel table */
+    a.sc.bcode_tile = nullptr;
     a.sc.bx = m->bdim[0];
     a.sc.by = m->bdim[1];
     a.sc.code_max = 255u;
@@ -1115,6 +1118,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.sc.radius = m->metric_radius;
     a.sc.dmax = dist_thres * m->resolution;
     a.sc.bcode = nullptr;
+    a.sc.bcode_tile = nullptr;
     a.sc.bx = m->bdim[0];
     a.sc.by = m->bdim[1];
     a.sc.code_max = 255u;

@@ -96,7 +96,8 @@ struct options {
     int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
     int score_parts = 3;      /* workgroups per hypothesis of k_score_culled */
     int score_slot_mib = 256; /* byte budget of the grouped kernel's (group, chunk) slots per launch */
-    int near_metric = 1;      /* 0: plane2 / cylinder models score with sphere culling only (no brick filter) */
+    int near_metric = 1;      /* brick filters under a plane2 / cylinder metric: 0 never, 1 when at least a tenth of
+                                 the grid's bricks lies beyond the threshold (auto), 2 always */
     int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
     int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
@@ -171,6 +172,13 @@ struct tm_model {
      * touching the big voxel table. */
     tmx::dbuf<uint32_t> brick_min_bits; /* f32 bits of min d2 per brick */
     tmx::dbuf<unsigned char> brick_code; /* floor(sqrt(min d2) / brick_q), clamped to 255 */
+    /* the same two filters under a projector's intrinsic_distance (plane2: 2-D, cylinder: wrap-around in u), built
+     * by tm_model_set_metric: per brick the quantised minimum over its voxels of (a) the intrinsic distance from the
+     * voxel centre to the voxel's STORED nearest point (what a query in that voxel is tested against) and (b) the
+     * intrinsic distance from the centre to the nearest of ALL model points (a 1-Lipschitz field: tile tests) */
+    tmx::dbuf<unsigned char> brick_code_metric_pt, brick_code_metric_tile;
+    float metric_coord_max = 0.f; /* max |coordinate| of the model's points: rounding slack of the metric filters */
+    uint64_t metric_code_hist[256] = {0}; /* bricks inside the grid per point-level code: how much the filter can remove */
     int bdim[3] = {0, 0, 0}; /* super-bricks (16^3 voxels = 64 bricks) per axis, see brick_of() */
     float brick_q = 0.f;
     std::vector<uint32_t> grid_subset; /* points the bounding box / diameter / grid are taken over; empty = all */

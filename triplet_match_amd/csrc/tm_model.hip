@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "tm_internal.h"
+#include "tm_traits_math.h"
 #include "tm_table.h"
 
 #include <rocprim/rocprim.hpp>
@@ -383,6 +384,92 @@ __global__ void k_brick_codes(const uint32_t* __restrict__ bits, uint32_t n, flo
     float d = sqrtf(d2) * 0.99999f;
     float c = floorf(d / q);
     code[t] = (unsigned char)(c >= 255.f ? 255u : (c > 0.f ? (uint32_t)c : 0u));
+}
+
+/* ---- brick codes under a projector's intrinsic_distance (tm_model_set_metric) ----
+ * The scoring kernels test a query q that falls into voxel v against ONE model point, m_v = the voxel's stored
+ * nearest neighbour (reference voxel_query, include/impl/model.hpp:180-192), with the traits' intrinsic_distance
+ * (plane2: 2-D distance in (u, v), include/impl/plane2_traits.hpp:112-116; cylinder: the same with wrap-around
+ * in u, include/impl/cylinder_traits.hpp:176-189). Both distances are 1-Lipschitz in q for a fixed m (they are
+ * norms of 1-Lipschitz maps of q - m), and q is within sqrt(3) cells of the voxel's reference corner c_v, so
+ *     d(q, m_v) >= d(c_v, m_v) - sqrt(3) cell:
+ * the minimum of d(c_v, m_v) over a brick's voxels, quantised, is the point-level code (k_metric_voxel_min).
+ * For whole tiles the field D(x) = min over ALL model points of d(x, m) is used: it is 1-Lipschitz in x and a
+ * lower bound of every d(x, m_v(x)); it does not depend on w, so it is computed once per (i, j) column of the
+ * grid (k_metric_column_min, exhaustive with LDS-staged model tiles) and reduced per brick column. */
+__global__ __launch_bounds__(256) void k_metric_voxel_min(const uint32_t* __restrict__ voxels,
+                                                          const float4* __restrict__ pos, grid_t g, uint64_t voxel_slots,
+                                                          int bx, int by, int kind, float radius,
+                                                          uint32_t* __restrict__ brick_bits) {
+    const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
+    uint32_t bi, bj, bk;
+    brick_coords(brick, (uint32_t)bx, (uint32_t)by, bi, bj, bk);
+    const uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
+    const bool live = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
+    uint32_t bits = 0x7F7F7F7Fu; /* a large finite float: voxels outside the grid are never asked */
+    if (live) {
+        const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
+        const f3 c = make3(isx * (float)i + (-(g.tx * isx)), isy * (float)j + (-(g.ty * isy)),
+                           isz * (float)k + (-(g.tz * isz)));
+        const float4 P = pos[voxels[slot]];
+        const float d = traits_distance(kind, radius, c, make3(P.x, P.y, P.z));
+        bits = d == d ? __float_as_uint(fmaxf(d, 0.f)) : 0u; /* NaN (a non-finite model point): no bound */
+    }
+    for (int off = 32; off > 0; off >>= 1) bits = min(bits, (uint32_t)__shfl_down((int)bits, off));
+    if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_bits[slot >> 6] = bits;
+}
+
+constexpr int kMetricTile = 2048;
+__global__ __launch_bounds__(256) void k_metric_column_min(const float4* __restrict__ pos, uint32_t n, grid_t g,
+                                                           int kind, float radius, uint32_t* __restrict__ col_bits) {
+    __shared__ float2 s_uv[kMetricTile];
+    const uint32_t col = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n_cols = (uint32_t)g.ex * (uint32_t)g.ey;
+    const uint32_t j = col / (uint32_t)g.ex, i = col - j * (uint32_t)g.ex;
+    const float isx = 1.0f / g.sx, isy = 1.0f / g.sy;
+    const f3 c = make3(isx * (float)i + (-(g.tx * isx)), isy * (float)j + (-(g.ty * isy)), 0.f);
+    float best = 3.0e38f;
+    for (uint32_t t0 = 0; t0 < n; t0 += kMetricTile) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < (uint32_t)kMetricTile; t += 256) {
+            const float4 P = t0 + t < n ? pos[t0 + t] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+            s_uv[t] = make_float2(P.x, P.y);
+        }
+        __syncthreads();
+        if (col < n_cols) {
+            const uint32_t m = min((uint32_t)kMetricTile, n - t0);
+            for (uint32_t t = 0; t < m; ++t) {
+                const float2 P = s_uv[t];
+                const float d = traits_distance(kind, radius, c, make3(P.x, P.y, 0.f));
+                best = d < best ? d : best; /* NaN never wins */
+            }
+        }
+    }
+    if (col < n_cols) col_bits[col] = __float_as_uint(fmaxf(best, 0.f));
+}
+
+/* code of every brick from a per-brick (linear = 0) or per-column (linear = 1: the brick's 4x4 columns) field of
+ * DISTANCES (not squared): floor(lower bound / q), clamped to 255 */
+__global__ void k_metric_codes(const uint32_t* __restrict__ bits, int per_column, grid_t g, int bx, int by,
+                               uint32_t n_bricks, float q, unsigned char* __restrict__ code) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bricks) return;
+    float d;
+    if (!per_column) {
+        d = __uint_as_float(bits[b]);
+    } else {
+        uint32_t bi, bj, bk;
+        brick_coords(b, (uint32_t)bx, (uint32_t)by, bi, bj, bk);
+        d = 3.0e38f;
+        for (uint32_t dj = 0; dj < 4; ++dj)
+            for (uint32_t di = 0; di < 4; ++di) {
+                const uint32_t i = (bi << 2) + di, j = (bj << 2) + dj;
+                if (i < (uint32_t)g.ex && j < (uint32_t)g.ey) d = fminf(d, __uint_as_float(bits[j * (uint32_t)g.ex + i]));
+            }
+    }
+    const float c = floorf(d * 0.99999f / q);
+    code[b] = (unsigned char)(c >= 255.f ? 255u : (c > 0.f ? (uint32_t)c : 0u));
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1022,6 +1109,8 @@ int tm_model_destroy(tm_model* m) {
     m->voxels.release();
     m->brick_min_bits.release();
     m->brick_code.release();
+    m->brick_code_metric_pt.release();
+    m->brick_code_metric_tile.release();
     m->seg_key.release();
     m->seg_begin.release();
     m->entries.release();
@@ -1089,6 +1178,8 @@ int tm_model_build_voxels(tm_model* m) {
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     m->voxels_ready = true;
     m->h_voxels_cache.clear();
+    /* a metric declared before the grid existed: its brick codes are due now */
+    if (m->metric_kind > TM_TRAITS_PLANE) TM_FORWARD(tm_model_set_metric(m, m->metric_kind, m->metric_radius));
     return TM_OK;
 }
 
@@ -1274,6 +1365,53 @@ int tm_model_set_metric(tm_model* m, int traits_kind, float radius) {
     TM_REQUIRE(traits_kind != TM_TRAITS_CYLINDER || radius > 0.f, TM_ERR_INVALID, "cylinder metric needs a radius");
     m->metric_kind = traits_kind;
     m->metric_radius = radius;
+    m->brick_code_metric_pt.release();
+    m->brick_code_metric_tile.release();
+    if (traits_kind <= TM_TRAITS_PLANE || !m->voxels_ready) return TM_OK; /* 3-D L2: the codes of the voxel build */
+    /* brick codes of the near filter and of the tile test under this metric (see k_metric_voxel_min) */
+    tm_ctx* c = m->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    const uint32_t n_bricks = (uint32_t)(m->voxel_slots >> 6);
+    const uint32_t n_cols = (uint32_t)m->extents[0] * (uint32_t)m->extents[1];
+    dbuf<uint32_t> brick_bits, col_bits;
+    int rc;
+    if ((rc = brick_bits.alloc(n_bricks)) || (rc = col_bits.alloc(n_cols)) ||
+        (rc = m->brick_code_metric_pt.alloc(n_bricks)) || (rc = m->brick_code_metric_tile.alloc(n_bricks))) {
+        brick_bits.release();
+        col_bits.release();
+        return rc;
+    }
+    hipLaunchKernelGGL(k_metric_voxel_min, dim3((uint32_t)((m->voxel_slots + 255) / 256)), dim3(256), 0, c->stream,
+                       m->voxels.p, m->pos.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], traits_kind, radius,
+                       brick_bits.p);
+    hipLaunchKernelGGL(k_metric_column_min, dim3((n_cols + 255) / 256), dim3(256), 0, c->stream, m->pos.p, m->n, m->grid,
+                       traits_kind, radius, col_bits.p);
+    hipLaunchKernelGGL(k_metric_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream, brick_bits.p, 0, m->grid,
+                       m->bdim[0], m->bdim[1], n_bricks, m->brick_q, m->brick_code_metric_pt.p);
+    hipLaunchKernelGGL(k_metric_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream, col_bits.p, 1, m->grid,
+                       m->bdim[0], m->bdim[1], n_bricks, m->brick_q, m->brick_code_metric_tile.p);
+    hipError_t e = hipGetLastError();
+    /* how many of the grid's bricks carry which code: tells a scoring call whether the filter can remove anything
+     * at its threshold (a dense sheet — an unrolled pipe — has no far bricks, and the filter would only cost) */
+    std::vector<uint32_t> h_bits(n_bricks);
+    std::vector<unsigned char> h_code(n_bricks);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h_bits.data(), brick_bits.p, (size_t)n_bricks * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h_code.data(), m->brick_code_metric_pt.p, n_bricks, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    brick_bits.release();
+    col_bits.release();
+    if (e != hipSuccess) {
+        set_error("tm_model_set_metric: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    for (uint64_t& v : m->metric_code_hist) v = 0;
+    for (uint32_t b = 0; b < n_bricks; ++b)
+        if (h_bits[b] != 0x7F7F7F7Fu) ++m->metric_code_hist[h_code[b]]; /* bricks with a voxel inside the grid */
+    float cm = 0.f;
+    for (int d = 0; d < 3; ++d) cm = std::max(cm, std::max(std::fabs(m->bbmin[d]), std::fabs(m->bbmax[d])));
+    m->metric_coord_max = cm;
     return TM_OK;
 }
 

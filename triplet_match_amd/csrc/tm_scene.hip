@@ -112,7 +112,7 @@ __device__ __forceinline__ bool tile_hits(const score_args& a, const pose12& T, 
      * the tile can become a correspondence (slack and the +1 code of safety are inside tcode). */
     if ((vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez)) {
         const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-        const float code = (float)a.bcode[brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by)];
+        const float code = (float)a.bcode_tile[brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by)];
         if (code > ca_tcode + rho * ca_inv_q * 1.0001f) return false;
     }
     return true;
@@ -146,11 +146,12 @@ __device__ __forceinline__ bool tile_decide(const tile_probe_t& r, uint32_t code
     return r.hit & !(r.need & ((float)code > r.lim));
 }
 
-/* L2 = the model's metric is the 3-D Euclidean one (identity / plane): distance-field tile test, brick
- * near-filter and the squared-distance comparison apply. Otherwise (plane2 / cylinder: the traits'
- * intrinsic_distance can be small where the Euclidean one is not) only the sphere-vs-box test culls.
+/* L2 = the model's metric is the 3-D Euclidean one (identity / plane): squared-distance comparison; otherwise the
+ * traits' intrinsic_distance (plane2 / cylinder). NEAR = the distance-field tile test and the brick near-filter
+ * apply: always for L2 (codes of the voxel build), for the other metrics with the codes tm_model_set_metric builds
+ * under that metric (a.bcode / a.bcode_tile); NEAR = false leaves the sphere-vs-box test as the only culling.
  * SUBSET = only the points flagged in ca.active_sorted (sorted order) take part. */
-template <bool L2, bool SUBSET>
+template <bool L2, bool SUBSET, bool NEAR = L2>
 __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args ca) {
     __shared__ uint32_t s_list[4 * kCullChunk]; /* surviving sub-tiles (16 points each) of the round */
     __shared__ uint32_t s_tiles[kCullChunk];    /* surviving tiles of the round */
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
             bool hit = false;
             if (t < ca.n_tiles) {
                 float4 tb = ca.tiles[t];
-                hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb)
-                         : sphere_hits_box(a, T, rnorm, abs_eps, tb);
+                hit = NEAR ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, tb)
+                           : sphere_hits_box(a, T, rnorm, abs_eps, tb);
                 if (ball) hit = hit && !(len(make3(tb.x, tb.y, tb.z) - bc) > ca.ball_r + tb.w * 1.00001f + ball_margin);
             }
             if (hit) s_tiles[atomicAdd(&s_nt, 1u)] = t;
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
         for (uint32_t idx = threadIdx.x; idx < n_quarters; idx += 256) {
             const uint32_t sub = s_tiles[idx >> 2] * 4u + (idx & 3u);
             const float4 sb = ca.subs[sub];
-            bool hit = L2 ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, sb)
-                          : sphere_hits_box(a, T, rnorm, abs_eps, sb);
+            bool hit = NEAR ? tile_hits(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, sb)
+                            : sphere_hits_box(a, T, rnorm, abs_eps, sb);
             if (ball) hit = hit && !(len(make3(sb.x, sb.y, sb.z) - bc) > ca.ball_r + sb.w * 1.00001f + ball_margin);
             if (hit) s_list[atomicAdd(&s_n, 1u)] = sub;
         }
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
             }
             uint32_t code[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) code[k] = L2 ? (uint32_t)a.bcode[brick[k]] : 0u;
+            for (int k = 0; k < 4; ++k) code[k] = NEAR ? (uint32_t)a.bcode[brick[k]] : 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 near[k] = in[k] & (code[k] <= a.code_max);
@@ -297,9 +298,9 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                     float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
                     float d2 = (dx * dx + dy * dy) + dz * dz;
                     ok[k] = near[k] & (d2 <= a.d2max);
-                } else { /* reference voxel_distance: !(intrinsic_distance > thres) */
-                    float dist = traits_distance(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
-                    ok[k] = near[k] & !(dist > a.dmax);
+                } else { /* reference voxel_distance: !(intrinsic_distance > thres), on the square (see below) */
+                    float d2 = traits_distance2(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
+                    ok[k] = near[k] & !(d2 > a.d2max);
                 }
             }
             if (TM_ABLATE_EQ(a, 1)) { cnt += ok[0] + ok[1] + ok[2] + ok[3]; continue; }
@@ -490,7 +491,7 @@ __device__ __forceinline__ f3 lds_xform_dir(const float4 A, const float4 B, cons
 /* BALL: every hypothesis scores only the scene points within ca.ball_r of its own centre point (the reference's
  * nn = radius_search_inclusive(diameter, p1)): quarter-tiles conservatively by a sphere-sphere test, points exactly
  * by (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point, as k_score_culled does */
-template <bool L2, int NC, int G, bool BALL = false>
+template <bool L2, int NC, int G, bool BALL = false, bool NEAR = L2>
 __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, cull_args ca, group_args ga) {
     /* 8 KiB of LDS per wave, private to it: no workgroup barrier inside the loop */
     __shared__ __align__(16) unsigned char s_raw[4][item_lds(G, BALL)];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     const pose12 T = lds_pose(poses + 3u * g);
                     const float2 ax = auxl[g];
                     const float rnorm = ax.x, abs_eps = ax.y;
-                    if (L2) {
+                    if (NEAR) {
                         pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
                     } else {
                         pr[r].hit = sphere_hits_box(a, T, rnorm, abs_eps, qs);
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) code[r] = L2 ? (uint32_t)a.bcode[pr[r].brick] : 0u;
+                for (int r = 0; r < 8; ++r) code[r] = NEAR ? (uint32_t)a.bcode_tile[pr[r].brick] : 0u;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const unsigned long long qm = __ballot(tile_decide(pr[r], code[r]));
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                          iz = in[k] ? (uint32_t)(int)vz : 0u;
                 brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
                 lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
-                code[k] = L2 ? (uint32_t)a.bcode[brick[k]] : 0u;
+                code[k] = NEAR ? (uint32_t)a.bcode[brick[k]] : 0u;
                 __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
             }
 #pragma unroll
@@ -706,8 +707,11 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     float d2 = (dx * dx + dy * dy) + dz * dz;
                     ok[k] = near[k] & (d2 <= a.d2max);
                 } else {
-                    float dist = traits_distance(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
-                    ok[k] = near[k] & !(dist > a.dmax);
+                    /* !(sqrtf(d2) > thres) without the square root: sqrtf is correctly rounded and monotone and
+                     * d2max is the largest float whose root is <= thres, so sqrtf(d2) > thres <=> d2 > d2max; a
+                     * NaN fails both comparisons alike. The exhaustive kernel keeps the literal form (eval_point). */
+                    float d2 = traits_distance2(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
+                    ok[k] = near[k] & !(d2 > a.d2max);
                 }
                 any_ok |= ok[k];
             }
@@ -1218,18 +1222,33 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
      * than thres + (largest distance from a voxel's centre to a point of its cell = sqrt(3) cells,
      * the int cast truncates) from the model: then no model point is within thres of the query. */
     const float cell_max = std::max(std::max(1.f / m->grid.sx, 1.f / m->grid.sy), 1.f / m->grid.sz);
-    const float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
+    float slack = 1.7320508f * cell_max * 1.0001f + thres * 1e-5f + 1e-7f;
+    /* the intrinsic distances are formed from coordinate differences (and 2 pi r): their f32 rounding scales with
+     * the coordinates' magnitude, not with the distance */
+    if (m->metric_kind > TM_TRAITS_PLANE)
+        slack += 1e-5f * (m->metric_coord_max + 6.2831855f * m->metric_radius + 8.f * cell_max);
     /* the distance-field tile test and the brick filter reason with 3-D Euclidean distances: L2 metrics
      * only; the other metrics keep the sphere-vs-box culling */
     const bool culled = mode != TM_SCORE_BRUTEFORCE;
     const bool l2 = m->metric_kind <= TM_TRAITS_PLANE;
-    a.bcode = (culled && l2) ? m->brick_code.p : nullptr;
+    /* plane2 / cylinder: the same two filters with the codes built under the model's metric */
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     {
         float cm = std::floor((thres + slack) / m->brick_q) + 1.f;
         a.code_max = (thres >= 0.f && cm < 255.f) ? (uint32_t)cm : 255u;
     }
+    bool near_metric = !l2 && c->opt.near_metric && m->brick_code_metric_pt.p && m->brick_code_metric_tile.p;
+    if (near_metric && c->opt.near_metric == 1) { /* auto: worth it only where there is something to remove */
+        uint64_t all = 0, far = 0;
+        for (uint32_t k = 0; k < 256u; ++k) {
+            all += m->metric_code_hist[k];
+            if (k > a.code_max) far += m->metric_code_hist[k];
+        }
+        near_metric = all > 0 && far * 10 >= all;
+    }
+    a.bcode = !culled ? nullptr : l2 ? m->brick_code.p : near_metric ? m->brick_code_metric_pt.p : nullptr;
+    a.bcode_tile = !culled ? nullptr : l2 ? m->brick_code.p : near_metric ? m->brick_code_metric_tile.p : nullptr;
     const uint32_t tiles = s->n_sorted / kScoreTile;
     /* aim for >= ~8 workgroups per CU; keep chunks long enough to amortise the tile load */
     uint32_t want_chunks = std::max(1u, (256u * 16u + tiles - 1) / tiles);
@@ -1321,6 +1340,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             auto kern = ga.group_hyps == 16u ? (l2 ? k_score_items<true, 4, 16> : k_score_items<false, 4, 16>)
                                              : (l2 ? k_score_items<true, 4, 32> : k_score_items<false, 4, 32>);
             if (d_centers) kern = l2 ? k_score_items<true, 4, 16, true> : k_score_items<false, 4, 16, true>;
+            if (near_metric)
+                kern = d_centers               ? k_score_items<false, 4, 16, true, true>
+                       : ga.group_hyps == 16u ? k_score_items<false, 4, 16, false, true>
+                                              : k_score_items<false, 4, 32, false, true>;
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
@@ -1357,6 +1380,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             hipLaunchKernelGGL((k_score_culled<true, false>), cgrid, dim3(256), 0, c->stream, a, ca);
         else if (l2)
             hipLaunchKernelGGL((k_score_culled<true, true>), cgrid, dim3(256), 0, c->stream, a, ca);
+        else if (near_metric && !d_active)
+            hipLaunchKernelGGL((k_score_culled<false, false, true>), cgrid, dim3(256), 0, c->stream, a, ca);
+        else if (near_metric)
+            hipLaunchKernelGGL((k_score_culled<false, true, true>), cgrid, dim3(256), 0, c->stream, a, ca);
         else if (!d_active)
             hipLaunchKernelGGL((k_score_culled<false, false>), cgrid, dim3(256), 0, c->stream, a, ca);
         else
@@ -1839,6 +1866,7 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     a.dmax = dist_thres * m->resolution;
     a.stat_slots = nullptr;
     a.bcode = nullptr; /* no brick filter here; bx/by still address the bricked voxel table */
+    a.bcode_tile = nullptr;
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     a.code_max = 255u;
@@ -1902,6 +1930,7 @@ static void icp_score_args(const tm_scene* s, const tm_model* m, float dist_thre
     a.dmax = dist_thres * m->resolution;
     a.stat_slots = nullptr;
     a.bcode = nullptr;
+    a.bcode_tile = nullptr;
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     a.code_max = 255u;

@@ -36,7 +36,9 @@ struct score_args {
     const float4* mref;
     const uint32_t* vox;
     const unsigned char* active; /* per original index, or null */
-    const unsigned char* bcode;  /* brick distance codes, or null (filter off) */
+    const unsigned char* bcode;  /* brick distance codes of the per-point near filter, or null (filter off) */
+    const unsigned char* bcode_tile; /* brick codes of the tile-level distance-field test (= bcode for 3-D L2; the
+                                        all-points field under a projector's metric), or null */
     int bx, by;                  /* brick grid dims (x, y) */
     uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
     int ablate;                  /* read only under TM_TIMING_EXPERIMENTS (see TM_ABLATE_EQ); 0 = full kernel */

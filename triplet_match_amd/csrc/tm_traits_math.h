@@ -185,6 +185,17 @@ TM_HD f3 traits_normal(int kind, const frame_t& f, f3 pos, f3 nrm, f3 tgt) {
     return unit(cross3(t1, t2));
 }
 
+/* the argument of traits_distance's square root for the projector metrics (kind 2, 3): same operations */
+TM_HD float traits_distance2(int kind, float radius, f3 a, f3 b) {
+    if (kind == 2) {
+        float dx = b.x - a.x, dy = b.y - a.y;
+        return dx * dx + dy * dy;
+    }
+    float du = fabsf(b.x - a.x), dv = fabsf(b.y - a.y);
+    du = fminf(du, (float)(6.283185307179586 * (double)radius) - du);
+    return du * du + dv * dv;
+}
+
 TM_HD float traits_distance(int kind, float radius, f3 a, f3 b) {
     if (kind == 0 || kind == 1) return len(b - a);
     if (kind == 2) { /* plane2_traits.hpp:112-116 */
