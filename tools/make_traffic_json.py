@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Turns the PMC passes of tools/pmc_rdreq.sh into profiles/r02/traffic.json (what bench.py quotes as
-roofline.traffic).  usage: tools/make_traffic_json.py <pmc outdir> [kernel substring] [out path]
+"""Turns the PMC passes of tools/pmc_rdreq.sh into profiles/r03/traffic.json (what bench.py quotes as
+roofline.traffic).  usage: tools/make_traffic_json.py <pmc outdir> [kernel substring] [out path] [folded outdir]
+<folded outdir> = the pass-1 counters of the same command on the timing-experiments build with TM_ABLATE=7 (voxel
+index folded into 1 MB): the difference of the line counts = the lines the voxel gathers fetch.
 
 HBM-side bytes per launch = sum over the L2's fabric read requests by size (TCC_EA0_RDREQ_32B/64B/128B;
 rocprofv3's FETCH_SIZE prices every non-32B request at 64 B, which is why it reads half of the real
@@ -17,7 +19,8 @@ import bench  # noqa: E402  (source_hash)
 
 out = sys.argv[1]
 kern = sys.argv[2] if len(sys.argv) > 2 else "k_score"
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02", "traffic.json")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03", "traffic.json")
+folded_dir = sys.argv[4] if len(sys.argv) > 4 else None
 summ = json.load(open(os.path.join(out, "summary.json")))
 name = [k for k in summ if kern in k]
 if not name:
@@ -51,6 +54,14 @@ res = {
     "sq_insts_vmem_rd": c.get("SQ_INSTS_VMEM_RD"), "sq_insts_valu": c.get("SQ_INSTS_VALU"),
     "ta_busy_sum": c.get("TA_TA_BUSY_sum"),
 }
+if folded_dir:
+    fs = json.load(open(os.path.join(folded_dir, "summary.json")))
+    fname = [k for k in fs if kern in k]
+    if fname:
+        fname = max(fname, key=lambda k: fs[k].get("TCC_EA0_RDREQ_sum", {}).get("mean", 0))
+        folded = fs[fname]["TCC_EA0_RDREQ_sum"]["mean"]
+        res["l2_fabric_read_requests_voxel_index_folded"] = folded
+        res["voxel_lines_per_launch"] = max(c["TCC_EA0_RDREQ_sum"] - folded, 0.0)
 if cycles and res["tcp_cache_accesses"]:
     # L1 (TCP): one 64-B tag lookup per cache access, 64 B/clk per CU, 256 CUs
     res["l1_frac_of_peak_at_profiled_ms"] = res["tcp_cache_accesses"] / (256.0 * cycles)

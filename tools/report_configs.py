@@ -2,8 +2,8 @@
 """Scoring-pass figures for BASELINE configs 3 / 4 / 5 (cylinder 500k, plane2 1M, 32 models x 4M) on one GPU:
 kernel time grouped / culled vs exhaustive, hypotheses/s, Gpoints/s, the BASELINE formula (40E + 32P + 64H) next
 to the bytes the evaluations really request (physical model, as bench.py), and the oracle's project_ on a
-sample of the same hypotheses on the host cores. A formula fraction above 1 is not evidence (the 40-B price
-over-charges evaluations that end at the in-grid test): `frac` then falls back to the physical model.
+sample of the same hypotheses on the host cores. `frac` = measured L2->fabric bytes / kernel time / 8 TB/s (the one
+basis of bench.py; null without --traffic); the formula and the requested-bytes model are side fields only.
 Prints one JSON object per config.
   --only 3|4|5.0|5.15|5.31   one configuration only (tools/pmc_configs.sh profiles them one at a time)
   --traffic FILE             L2->fabric bytes per launch of the grouped kernel from those PMC passes
@@ -92,10 +92,13 @@ def report(name, gscene, gm, poses, K, S, tmask, M, res, radius, extra, key=None
     if measured:
         extra = dict(extra, measured_fabric_GB=round(measured / 1e9, 2),
                      frac_measured_hbm=round(measured / (out["culled"] * 1e-3) / 8e12, 4))
-    # neither byte model is evidence once it exceeds the peak (the bytes come out of LDS / L1 / L2): no fraction then
-    frac, basis = (frac_formula, "baseline_formula_40E+32P+64H") if frac_formula <= 1.0 else \
-        (frac_physical, "physical_model") if frac_physical <= 1.0 else \
-        (extra.get("frac_measured_hbm"), "measured_l2_fabric_bytes" if measured else "none: both byte models exceed the HBM peak")
+    # one basis, as bench.py: measured L2->fabric bytes / kernel time / 8 TB/s (Infinity Cache + HBM: an upper bound
+    # of the HBM traffic); null without a --traffic file. The formula and the requested-bytes model are side fields.
+    frac = extra.get("frac_measured_hbm") if measured else None
+    basis = ("measured_l2_fabric_bytes: Infinity Cache + HBM, upper bound of HBM" if measured else
+             "unavailable: no PMC pass for this configuration (tools/pmc_configs.sh)")
+    if measured:
+        extra = dict(extra, infinity_cache_frac=round(measured / (out["culled"] * 1e-3) / 8.6e12, 4))
     rec = {"config": name, "hypotheses": H, "scene_points": int(len(S)), "model_points": int(len(M)),
            "kernel_ms_culled": round(out["culled"], 3), "kernel_ms_exhaustive": round(out["exhaustive"], 3),
            "hypotheses_per_s": round(H / (out["culled"] * 1e-3), 1),
