@@ -497,7 +497,7 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
         libdir = os.path.join(ROOT, "triplet_match_amd")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tools", "e2e_demo.cpp"), "-o", exe, "-L" + libdir, "-ltm_hip",
-                               "-Wl,-rpath," + libdir])
+                               "-Wl,-rpath," + libdir, "-pthread"])
         r = subprocess.run([exe, fx, "1", "10"], capture_output=True, text=True, timeout=300)
         os.unlink(fx)
         os.unlink(exe)

@@ -66,7 +66,7 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * calls change it — no call of the path reads the environment. Names: debug_stats, debug_items, debug_times,
  * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
  * score_parts, score_slot_mib, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
- * ed_wide, ed_bruteforce, ed_unfused, search_segment (DESIGN.md section 6 says what each selects).
+ * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */
@@ -228,6 +228,17 @@ int tm_scene_radius_subset(tm_scene* scene, uint32_t center_idx, float radius, i
 int tm_scene_radius_lists(tm_scene* scene, const uint32_t* centers, uint32_t n_centers, float radius,
                           int32_t* lists, uint32_t stride, uint32_t* counts);
 
+/* What the sampling loop of find_in_subset (include/impl/scene.hpp:273-302) uses of those neighbourhoods: the size
+ * of nn (inner_bound, :276-281; the range of the shuffle's draws, :285) and its members with tangent_mask_ set —
+ * every other member fails the first filter of :290 whatever its index is. counts[k] = size of the neighbourhood
+ * of centers[k]; triples = (k, rank, index) per tangent member, rank = its position in that neighbourhood's
+ * ascending order (the order tm_scene_radius_lists hands out); 3 x uint32 each, in no defined order;
+ * *n_triples = how many. TM_ERR_CAPACITY (counts and *n_triples valid) when cap_triples is too small; it never
+ * exceeds n_centers x (tangent points of the scene). A 60,000-point neighbourhood with 4 % tangent points
+ * travels as 29 KB instead of 240 KB. */
+int tm_scene_radius_tangent_lists(tm_scene* scene, const uint32_t* centers, uint32_t n_centers, float radius,
+                                  uint32_t* counts, uint32_t* triples, uint32_t cap_triples, uint32_t* n_triples);
+
 /* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
  * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same
  * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */
@@ -350,6 +361,13 @@ int tm_icp_accumulate(tm_scene* scene, tm_model* model, const float pose16[16], 
  * (tm_extract_correspondences). Same poses as a host loop over tm_icp_accumulate + tm_rigid_fit. */
 int tm_icp_refine(tm_scene* scene, tm_model* model, const float pose16[16], float dist_thres,
                   uint32_t max_iterations, float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations);
+/* The same for n independent candidates side by side (the candidates of one find_parallel round, which the
+ * reference refines one after the other, include/impl/scene.hpp:169-171): poses16 = n x 16 floats; every pass is one
+ * launch over (scene blocks, candidates), so the chain of launches is max_iterations + 1 passes long whatever n is.
+ * out_poses16 / out_counts / out_iterations (optional) per candidate, each equal to what tm_icp_refine returns for
+ * that candidate alone. */
+int tm_icp_refine_batch(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n, float dist_thres,
+                        uint32_t max_iterations, float* out_poses16, uint32_t* out_counts, uint32_t* out_iterations);
 /* The rigid fit itself, on the host: Horn's closed form on the sums of tm_icp_accumulate (count >= 3) */
 int tm_rigid_fit(const long long sums15[15], uint32_t count, float pose16[16]);
 

@@ -7,6 +7,7 @@
 #ifndef TRIPLET_MATCH_SCENE_HPP_
 #define TRIPLET_MATCH_SCENE_HPP_
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 
@@ -22,13 +23,15 @@ namespace detail {
  * per chunk, the general subset call, the ICP loop on the host): same results either way. Read from the
  * environment ONCE per process, on first use — never inside the search loops. */
 struct search_switches {
-    bool search_unfused, search_per_chunk, subset_general, icp_host_loop;
+    bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods;
 };
 inline const search_switches& env_once() {
     static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
                                        std::getenv("TM_SEARCH_PER_CHUNK") != nullptr,
                                        std::getenv("TM_SUBSET_GENERAL") != nullptr,
-                                       std::getenv("TM_ICP_HOST_LOOP") != nullptr};
+                                       std::getenv("TM_ICP_HOST_LOOP") != nullptr,
+                                       std::getenv("TM_ICP_PER_CANDIDATE") != nullptr,
+                                       std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr};
     return sw;
 }
 
@@ -62,9 +65,81 @@ struct hip_backend {
     std::vector<uint32_t> count_cache;
     size_t cache_lo = 0, cache_hi = 0, cache_stride = 0;
     float cache_radius = -1.f;
+    bool round_announced = false; /* announce_round(): the first points of ALL chunks of a find_parallel round */
     void announce_firsts(const std::vector<uint32_t>& firsts) {
+        if (round_announced && !firsts.empty() &&
+            std::find(upcoming.begin(), upcoming.end(), firsts[0]) != upcoming.end())
+            return; /* a chunk of the announced round: its points are already in the queue */
+        round_announced = false;
         upcoming = firsts;
         cache_lo = cache_hi = 0;
+        t_lo = t_hi = 0;
+    }
+    /* every chunk's first points up front, in visit order: the neighbourhoods are then fetched for up to 64 first
+     * points per call across chunk borders (an empty list ends the round) */
+    void announce_round(const std::vector<uint32_t>& firsts) {
+        upcoming = firsts;
+        cache_lo = cache_hi = 0;
+        t_lo = t_hi = 0;
+        round_announced = !firsts.empty();
+    }
+    /* The sampling loop's view of nn = radius_search_inclusive(radius, i) (include/impl/scene.hpp:273-302): its
+     * size and (rank, index) of its members with tangent_mask set (tm_scene_radius_tangent_lists) — every other
+     * member fails the first filter of :290. Fetched for i and up to 63 announced first points after it. */
+    std::vector<uint32_t> t_counts, t_offsets, t_pairs, t_triples; /* per cached first point: |nn|, CSR of (rank, index) */
+    size_t t_lo = 0, t_hi = 0;
+    float t_radius = -1.f;
+    bool supports_tangent_view() const { return !env_once().dense_neighbourhoods; }
+    void fetch_tangent_lists(uint32_t i, float radius) {
+        size_t pos = 0;
+        while (pos < upcoming.size() && upcoming[pos] != i) ++pos;
+        std::vector<uint32_t> batch;
+        if (pos < upcoming.size()) {
+            for (size_t q = pos; q < upcoming.size() && batch.size() < 64; ++q) batch.push_back(upcoming[q]);
+            t_lo = pos;
+        } else {
+            batch.push_back(i);
+            upcoming.assign(1, i);
+            round_announced = false;
+            t_lo = 0;
+        }
+        t_hi = t_lo + batch.size();
+        t_radius = radius;
+        t_counts.assign(batch.size(), 0u);
+        uint32_t n_tri = 0;
+        if (t_triples.size() < 3 * 4096) t_triples.resize(3 * 4096);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int rc = tm_scene_radius_tangent_lists(s, batch.data(), (uint32_t)batch.size(), radius, t_counts.data(),
+                                                         t_triples.data(), (uint32_t)(t_triples.size() / 3), &n_tri);
+            if (rc == TM_ERR_CAPACITY && attempt == 0) {
+                t_triples.resize(3 * ((size_t)n_tri + n_tri / 4 + 16));
+                continue;
+            }
+            check(rc, "tm_scene_radius_tangent_lists");
+            break;
+        }
+        /* bucket the triples by slot (counting sort): t_pairs[2 * (t_offsets[k] + e)] = rank, [+ 1] = index */
+        t_offsets.assign(batch.size() + 1, 0u);
+        for (uint32_t e = 0; e < n_tri; ++e) ++t_offsets[t_triples[3 * (size_t)e] + 1];
+        for (size_t k = 0; k < batch.size(); ++k) t_offsets[k + 1] += t_offsets[k];
+        t_pairs.resize(2 * (size_t)n_tri + 2);
+        std::vector<uint32_t> cur(t_offsets.begin(), t_offsets.end() - 1);
+        for (uint32_t e = 0; e < n_tri; ++e) {
+            const uint32_t k = t_triples[3 * (size_t)e], d = cur[k]++;
+            t_pairs[2 * (size_t)d] = t_triples[3 * (size_t)e + 1];
+            t_pairs[2 * (size_t)d + 1] = t_triples[3 * (size_t)e + 2];
+        }
+    }
+    void tangent_view(uint32_t i, float radius, size_t& n_nn, const uint32_t*& rank_index_pairs, size_t& n_pairs) {
+        size_t k = t_lo;
+        while (k < t_hi && upcoming[k] != i) ++k;
+        if (k >= t_hi || t_radius != radius) {
+            fetch_tangent_lists(i, radius);
+            k = t_lo;
+        }
+        n_nn = t_counts[k - t_lo];
+        rank_index_pairs = t_pairs.data() + 2 * (size_t)t_offsets[k - t_lo];
+        n_pairs = t_offsets[k - t_lo + 1] - t_offsets[k - t_lo];
     }
     void fetch_lists(uint32_t i, float radius) { /* i and the announced firsts that follow it */
         {
@@ -250,6 +325,18 @@ struct hip_backend {
         uint32_t n = 0, it = 0;
         check(tm_icp_refine(s, m, T.m, dist_thres, max_iterations, out.m, &n, &it), "tm_icp_refine");
         return out;
+    }
+    /* the candidates of one find_parallel round refined side by side (tm_icp_refine_batch); TM_ICP_PER_CANDIDATE=1:
+     * one tm_icp_refine call per candidate, as the reference's loop goes (include/impl/scene.hpp:169-171) */
+    bool supports_icp_refine_batch() const { return supports_icp_refine() && !env_once().icp_per_candidate; }
+    void icp_refine_batch(const std::vector<search::pose_t>& starts, float dist_thres, uint32_t max_iterations,
+                          std::vector<search::pose_t>& out) {
+        out.resize(starts.size());
+        if (starts.empty()) return;
+        std::vector<uint32_t> counts(starts.size()), iters(starts.size());
+        check(tm_icp_refine_batch(s, m, &starts[0].m[0], (uint32_t)starts.size(), dist_thres, max_iterations,
+                                  &out[0].m[0], counts.data(), iters.data()),
+              "tm_icp_refine_batch");
     }
     search::detail::icp_sums_t icp_sums(const search::pose_t& T, float dist_thres) {
         search::detail::icp_sums_t r;

@@ -50,6 +50,9 @@ struct candidate_t { /* match_t with the scene->model transform (inverted once a
 struct stats_t {
     double radius = 0, shuffle = 0, sample = 0, generate_score = 0, extract = 0, icp = 0, arbitration = 0,
            mask = 0, total = 0;
+    /* how much sampling a search did: first points whose neighbourhood was sampled, positions drawn from the
+     * shuffled neighbourhoods, neighbourhood entries the backend handed over, find_parallel rounds */
+    uint64_t firsts_sampled = 0, draws = 0, neighbours = 0, rounds = 0;
 };
 
 /* What one chunk of first points (one worker of the reference, include/impl/scene.hpp:156-166) hands to
@@ -285,6 +288,91 @@ inline void neighbourhood(B& be, uint32_t i, float radius, std::vector<int32_t>&
     n = store.size();
 }
 
+/* does the backend hand out the sampling loop's view of a neighbourhood — its size and its tangent members with
+ * their ranks — instead of the whole list? (hip_backend: tm_scene_radius_tangent_lists) */
+template <class B, class = void>
+struct has_tangent_view : std::false_type {};
+template <class B>
+struct has_tangent_view<B, decltype(void(std::declval<B&>().tangent_view(0u, 0.f, std::declval<size_t&>(),
+                                                                         std::declval<const uint32_t*&>(),
+                                                                         std::declval<size_t&>())))> : std::true_type {};
+template <class B>
+inline bool tangent_neighbourhood(B& be, uint32_t i, float radius, size_t& n_nn, const uint32_t*& pairs, size_t& n_pairs,
+                                  std::true_type) {
+    if (!be.supports_tangent_view()) return false;
+    be.tangent_view(i, radius, n_nn, pairs, n_pairs);
+    return true;
+}
+template <class B>
+inline bool tangent_neighbourhood(B&, uint32_t, float, size_t&, const uint32_t*&, size_t&, std::false_type) {
+    return false;
+}
+template <class B, class = void>
+struct has_announce_round : std::false_type {};
+template <class B>
+struct has_announce_round<B, decltype(void(std::declval<B&>().announce_round(std::declval<const std::vector<uint32_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline void announce_round(B& be, const std::vector<uint32_t>& firsts, std::true_type) { be.announce_round(firsts); }
+template <class B>
+inline void announce_round(B&, const std::vector<uint32_t>&, std::false_type) {}
+
+/* The shuffled copy of a neighbourhood list, kept sparse: position -> scene index for the positions that hold a
+ * point with tangent_mask set; every other position holds a point the sampling loop skips whatever its index is
+ * (first filter of include/impl/scene.hpp:290) and is simply absent (get() = -1). A swap of the lazy Fisher-Yates
+ * shuffle moves the (at most two) entries involved; swapping two absent positions is nothing. Open addressing,
+ * cleared per first point. */
+struct sparse_list {
+    std::vector<uint32_t> key;
+    std::vector<int32_t> val;
+    uint32_t shift = 32, used = 0;
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    void reset(size_t expect) {
+        uint32_t bits = 10;
+        while (((size_t)1 << bits) < 4 * expect + 64) ++bits;
+        key.assign((size_t)1 << bits, kEmpty);
+        val.resize((size_t)1 << bits);
+        shift = 32 - bits;
+        used = 0;
+    }
+    uint32_t slot_of(uint32_t pos) const { return (pos * 0x9E3779B1u) >> shift; }
+    int32_t get(uint32_t pos) const {
+        const uint32_t mask = (uint32_t)key.size() - 1;
+        for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
+            if (key[h] == pos) return val[h];
+            if (key[h] == kEmpty) return -1;
+        }
+    }
+    void put(uint32_t pos, int32_t v) {
+        const uint32_t mask = (uint32_t)key.size() - 1;
+        for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
+            if (key[h] == pos) {
+                val[h] = v;
+                return;
+            }
+            if (key[h] == kEmpty) {
+                if (v < 0) return; /* absent already means "not a tangent point" */
+                key[h] = pos;
+                val[h] = v;
+                if (++used * 2 > key.size()) grow();
+                return;
+            }
+        }
+    }
+    void grow() {
+        std::vector<uint32_t> k2;
+        std::vector<int32_t> v2;
+        k2.swap(key);
+        v2.swap(val);
+        key.assign(k2.size() * 2, kEmpty);
+        val.resize(k2.size() * 2);
+        --shift;
+        used = 0;
+        for (size_t h = 0; h < k2.size(); ++h)
+            if (k2[h] != kEmpty && v2[h] >= 0) put(k2[h], v2[h]);
+    }
+};
+
 /* does the backend run the whole ICP loop itself? (hip_backend: tm_icp_refine) */
 template <class B, class = void>
 struct has_icp_refine : std::false_type {};
@@ -300,6 +388,24 @@ inline bool device_icp(B& be, const pose_t& start, float dist_thres, uint32_t ma
 }
 template <class B>
 inline bool device_icp(B&, const pose_t&, float, uint32_t, pose_t&, std::false_type) {
+    return false;
+}
+/* does the backend refine several independent candidates in one call? (hip_backend: tm_icp_refine_batch) */
+template <class B, class = void>
+struct has_icp_refine_batch : std::false_type {};
+template <class B>
+struct has_icp_refine_batch<B, decltype(void(std::declval<B&>().icp_refine_batch(std::declval<const std::vector<pose_t>&>(), 0.f, 0u,
+                                                                                   std::declval<std::vector<pose_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline bool device_icp_batch(B& be, const std::vector<pose_t>& starts, float dist_thres, uint32_t max_iterations,
+                             std::vector<pose_t>& out, std::true_type) {
+    if (!be.supports_icp_refine_batch()) return false;
+    be.icp_refine_batch(starts, dist_thres, max_iterations, out);
+    return true;
+}
+template <class B>
+inline bool device_icp_batch(B&, const std::vector<pose_t>&, float, uint32_t, std::vector<pose_t>&, std::false_type) {
     return false;
 }
 
@@ -321,6 +427,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     const uint32_t n_model_all = be.model_size();
     const float sufficient = p.accept_prob * (float)n_model_all; /* :331, size_t > float in float */
     std::vector<int32_t> nn, inner0;
+    detail::sparse_list shuffled;
     const int32_t* nn_ptr = nullptr; /* the neighbourhood of the current first point (in nn, or the backend's) */
     size_t n_nn = 0;
     std::vector<uint32_t> ij;
@@ -405,9 +512,15 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
     for (uint32_t i : firsts) {
         if (fp_mask[i] || mask[i]) continue; /* :268 */
         ++cons;
+        const uint32_t* t_pairs = nullptr; /* sparse view: (rank, index) of the tangent members of nn */
+        size_t n_t_pairs = 0;
+        bool sparse = false;
         {
             TM_TIMED(radius);
-            detail::neighbourhood(be, i, be.model_diameter(), nn, nn_ptr, n_nn, detail::has_radius_view<Backend>{}); /* :273 */
+            sparse = detail::tangent_neighbourhood(be, i, be.model_diameter(), n_nn, t_pairs, n_t_pairs,
+                                                   detail::has_tangent_view<Backend>{});
+            if (!sparse)
+                detail::neighbourhood(be, i, be.model_diameter(), nn, nn_ptr, n_nn, detail::has_radius_view<Backend>{}); /* :273 */
         }
         if (n_nn == 0) continue;
         double prob = (double)n_model_all / (double)n_nn;
@@ -425,8 +538,40 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         uint32_t valid_samples = 0;
         {
         TM_TIMED(sample);
+        if (p.stats) {
+            ++p.stats->firsts_sampled;
+            p.stats->neighbours += sparse ? n_t_pairs : n_nn;
+        }
+        if (sparse) {
+            /* the same shuffle on the sparse copy: the draws depend on the list's LENGTH only (rng() % (n - k)), and
+             * a position's content matters only if it is a tangent point; same r, same j at every step as below */
+            shuffled.reset(n_t_pairs);
+            for (size_t e = 0; e < n_t_pairs; ++e) shuffled.put(t_pairs[2 * e], (int32_t)t_pairs[2 * e + 1]);
+            for (size_t k = 0; k < n_nn; ++k) {
+                if (p.stats) ++p.stats->draws;
+                if (k + 1 < n_nn) {
+                    const size_t r = k + (size_t)(rng() % (uint32_t)(n_nn - k));
+                    if (r != k) {
+                        const int32_t vk = shuffled.get((uint32_t)k), vr = shuffled.get((uint32_t)r);
+                        if (vk >= 0 || vr >= 0) {
+                            shuffled.put((uint32_t)k, vr);
+                            shuffled.put((uint32_t)r, vk);
+                        }
+                    }
+                }
+                const int32_t j = shuffled.get((uint32_t)k);
+                if (j < 0) continue;                                             /* :290, tangent_mask_[j] is false */
+                if (!tangent_mask[j] || mask[j] || i == (uint32_t)j) continue; /* :290 */
+                if (!be.pair_is_valid_sample(i, (uint32_t)j)) continue;         /* :293-302 */
+                ij.push_back(i);
+                ij.push_back((uint32_t)j);
+                ++valid_samples;
+                if (valid_samples > inner_bound) break; /* :350 */
+            }
+        } else {
         inner0.assign(nn_ptr, nn_ptr + n_nn); /* a copy is shuffled (:284-285): project_ scans nn in its own order */
         for (size_t k = 0; k < n_nn; ++k) {
+            if (p.stats) ++p.stats->draws;
             if (k + 1 < n_nn) {
                 const size_t r = k + (size_t)(rng() % (uint32_t)(n_nn - k));
                 std::swap(inner0[k], inner0[r]);
@@ -438,6 +583,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             ij.push_back((uint32_t)j);
             ++valid_samples;
             if (valid_samples > inner_bound) break; /* :350 */
+        }
         }
         }
         if (ij.empty()) continue;
@@ -452,7 +598,10 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         TM_TIMED(generate_score);
         be.generate(ij, poses); /* :304-319, visit order */
         if (poses.empty()) continue;
-        if (nn_ptr != nn.data() || nn.size() != n_nn) nn.assign(nn_ptr, nn_ptr + n_nn);
+        if (sparse) /* one-first-point-at-a-time scoring scans the whole neighbourhood: fetch it now */
+            be.radius_subset(i, be.model_diameter(), nn);
+        else if (nn_ptr != nn.data() || nn.size() != n_nn)
+            nn.assign(nn_ptr, nn_ptr + n_nn);
         be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
         /* :330-338: score > best_score(=0) and #corrs > accept_prob * |model cloud| */
         const long h = first_sufficient(poses, counts, scores);
@@ -514,31 +663,34 @@ inline std::vector<candidate_t> arbitrate(std::vector<candidate_t> cands, uint32
     });
     std::vector<candidate_t> result;
     std::vector<unsigned char> used(n_scene_points, 0); /* the reference's std::set<uint32_t> used, :198 */
-    std::vector<uint32_t> newly;
     for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
         candidate_t out;
         out.transform = cand.transform;
         out.signed_score = cand.signed_score;
-        newly.clear(); /* what this candidate adds to `used`; undone if it is rejected (used_copy, :203) */
-        for (size_t k = 0; k < cand.scene_corrs.size(); ++k) {
-            const uint32_t idx = cand.scene_corrs[k];
-            if (!used[idx]) {
-                out.scene_corrs.push_back(idx);
-                out.model_corrs.push_back(cand.model_corrs[k]);
-                used[idx] = 1;
-                newly.push_back(idx);
-            }
+        /* one pass: the points no accepted candidate holds yet, and how many of them are tangent points; `used`
+         * is only written once the candidate is accepted (a rejected one gives its points back, used_copy :203) */
+        const size_t n_c = cand.scene_corrs.size();
+        out.scene_corrs.resize(n_c);
+        out.model_corrs.resize(n_c);
+        uint32_t score = 0, kept = 0;
+        const uint32_t* sc = cand.scene_corrs.data();
+        const uint32_t* mc = cand.model_corrs.data();
+        for (size_t k = 0; k < n_c; ++k) {
+            const uint32_t idx = sc[k];
+            if (used[idx]) continue;
+            out.scene_corrs[kept] = idx;
+            out.model_corrs[kept] = mc[k];
+            ++kept;
+            score += tangent_mask[idx] ? 1u : 0u;
         }
-        uint32_t score = 0, score_all = (uint32_t)out.scene_corrs.size();
-        for (uint32_t idx : out.scene_corrs)
-            if (tangent_mask[idx]) ++score;
+        out.scene_corrs.resize(kept);
+        out.model_corrs.resize(kept);
+        const uint32_t score_all = kept;
         if (verbose)
             fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
                     cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
-        if (score < min_points || score_all < min_points_all) { /* :227 */
-            for (uint32_t idx : newly) used[idx] = 0;
-            continue;
-        }
+        if (score < min_points || score_all < min_points_all) continue; /* :227 */
+        for (uint32_t idx : out.scene_corrs) used[idx] = 1;
         result.push_back(std::move(out));
     }
     return result;
@@ -624,6 +776,12 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
          * its first batch with a sufficient hypothesis: the reference runs the chunks on concurrent threads */
         std::vector<std::vector<uint32_t>> chunks, batches;
         std::vector<uint32_t> cons_of, first_batch_of;
+        {   /* every chunk's first points are known now: the backend may fetch their neighbourhoods across chunks */
+            std::vector<uint32_t> live;
+            for (uint32_t i : outer)
+                if (!fp_mask[i] && !mask[i]) live.push_back(i);
+            detail::announce_round(be, live, detail::has_announce_round<Backend>{});
+        }
         for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) {
             chunks.emplace_back(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
             first_batch_of.push_back((uint32_t)batches.size());
@@ -631,6 +789,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             cons_of.push_back(res.second);
         }
         first_batch_of.push_back((uint32_t)batches.size());
+        detail::announce_round(be, std::vector<uint32_t>(), detail::has_announce_round<Backend>{});
         std::vector<char> found;
         std::vector<pose_t> poses;
         {
@@ -638,19 +797,39 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             detail::run_batches(be, batches, be.model_diameter(), p.early_drop,
                                 p.accept_prob * (float)n_model_all, found, poses, detail::has_search_batches<Backend>{});
         }
+        std::vector<pose_t> starts; /* every chunk's first sufficient hypothesis, in chunk order */
         for (size_t ci = 0; ci < chunks.size(); ++ci) {
             for (uint32_t k = 0, seen = 0; k < chunks[ci].size() && seen < cons_of[ci]; ++k, ++seen)
                 fp_mask[chunks[ci][k]] = 1; /* :160-162 */
             for (uint32_t b = first_batch_of[ci]; b < first_batch_of[ci + 1]; ++b)
                 if (found[b]) {
-                    candidate_t c;
-                    {
-                        TM_TIMED(extract);
-                        be.extract(poses[b], p.dist_thres, c); /* :361-364 */
-                    }
-                    cands.push_back(icp(be, c, p)); /* :169-171 */
+                    starts.push_back(poses[b]);
                     break;
                 }
+        }
+        /* icp_ of every candidate (:169-171). The candidates do not depend on one another, so a backend that can
+         * refines them side by side in one call; icp_ itself only reads the candidate's transform (:375), so the
+         * correspondence lists of finish_find (:361-364) are extracted once, for the refined pose. */
+        std::vector<pose_t> refined;
+        bool batched = false;
+        if (p.max_icp_iterations > 0 && !starts.empty()) {
+            TM_TIMED(icp);
+            batched = detail::device_icp_batch(be, starts, 2.f * p.dist_thres, p.max_icp_iterations, refined,
+                                               detail::has_icp_refine_batch<Backend>{});
+        }
+        for (size_t k = 0; k < starts.size(); ++k) {
+            candidate_t c;
+            if (batched) {
+                TM_TIMED(extract);
+                be.extract(refined[k], 2.f * p.dist_thres, c);
+                cands.push_back(std::move(c));
+                continue;
+            }
+            {
+                TM_TIMED(extract);
+                be.extract(starts[k], p.dist_thres, c); /* :361-364 */
+            }
+            cands.push_back(icp(be, c, p)); /* :169-171 */
         }
     } else
     for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) { /* chunks, :156-166 (run one after another) */
@@ -686,6 +865,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     be.set_mask(mask);
     std::vector<candidate_t> results;
     for (;;) {
+        if (p.stats) ++p.stats->rounds;
         auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p, ex);
         if (matches.empty()) break;
         for (auto& mt : matches) {

@@ -102,6 +102,27 @@ struct oracle_backend {
     }
 };
 
+/* The same backend handing the sampling loop its SPARSE view of a neighbourhood (size + (rank, index) of the tangent
+ * members, what tm_scene_radius_tangent_lists gives the HIP backend) instead of the whole list: the search must not
+ * notice — same draws, same samples, same candidates (mode "oracle_sparse"). */
+struct oracle_backend_sparse : oracle_backend {
+    std::vector<int32_t> dense;
+    std::vector<uint32_t> pairs;
+    bool supports_tangent_view() const { return true; }
+    void tangent_view(uint32_t i, float radius, size_t& n_nn, const uint32_t*& rank_index_pairs, size_t& n_pairs) {
+        radius_subset(i, radius, dense);
+        pairs.clear();
+        for (size_t r = 0; r < dense.size(); ++r)
+            if (tmask[dense[r]]) {
+                pairs.push_back((uint32_t)r);
+                pairs.push_back((uint32_t)dense[r]);
+            }
+        n_nn = dense.size();
+        rank_index_pairs = pairs.data();
+        n_pairs = pairs.size() / 2;
+    }
+};
+
 /* Exchange over a shared directory, for the multi-process CPU test of the rank-sharded search (the product
  * exchange is RCCL through tm_comm_allgather_records): every all-gather writes <dir>/x<seq>_r<rank>.bin
  * (atomic rename) and waits for the files of the other ranks. */
@@ -231,6 +252,26 @@ int main(int argc, char** argv) {
     if (ro.empty()) {
         printf("FAIL no candidate found by the host logic over the oracle\n");
         ++failures;
+    }
+    if (std::string(argv[2]) == "oracle_sparse") { /* sparse neighbourhood views: the identical search */
+        oracle_backend_sparse sb;
+        static_cast<oracle_backend&>(sb) = ob;
+        search::stats_t st_sparse, st_dense;
+        search::params_t ps = p;
+        ps.stats = &st_sparse;
+        auto rs = search::find_all(sb, tmask, ps);
+        ps.stats = &st_dense;
+        auto rd = search::find_all(ob, tmask, ps);
+        bool same = rs.size() == ro.size() && rd.size() == ro.size();
+        for (size_t k = 0; k < rs.size() && same; ++k)
+            same = memcmp(rs[k].transform.m, ro[k].transform.m, 64) == 0 && rs[k].scene_corrs == ro[k].scene_corrs &&
+                   rs[k].model_corrs == ro[k].model_corrs;
+        same = same && st_sparse.draws == st_dense.draws && st_sparse.firsts_sampled == st_dense.firsts_sampled;
+        printf("%s sparse neighbourhood views == whole lists: %zu candidates, %llu draws over %llu first points, %llu entries "
+               "handed over instead of %llu\n", same ? "ok  " : "FAIL", rs.size(), (unsigned long long)st_sparse.draws,
+               (unsigned long long)st_sparse.firsts_sampled, (unsigned long long)st_sparse.neighbours,
+               (unsigned long long)st_dense.neighbours);
+        if (!same || st_sparse.draws == 0) ++failures;
     }
     for (const auto& c : ro) { /* each accepted candidate must sit on a planted pose */
         double best = 1e30;

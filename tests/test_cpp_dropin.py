@@ -76,6 +76,17 @@ def test_host_orchestration_over_oracle_backend(tmp_path):
     assert r.returncode == 0 and "PASSED" in r.stdout
 
 
+def test_sparse_neighbourhood_views_give_the_same_search(tmp_path):
+    """the sampling loop fed with (size, tangent members with their ranks) per neighbourhood instead of the whole index
+    list — what the HIP backend gets from tm_scene_radius_tangent_lists — draws the same positions, records the same
+    samples and ends with the same candidates (oracle backend, CPU)"""
+    exe = _compile("test_search", _oracle_link())
+    fx = _fixture(str(tmp_path / "case.bin"))
+    r = subprocess.run([exe, fx, "oracle_sparse"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ok   sparse neighbourhood views == whole lists" in r.stdout
+
+
 def _result_lines(text):
     return [ln for ln in text.splitlines() if ln.startswith("oracle backend") or ln.startswith("   corrs")
             or ln.startswith("   fingerprint")]

@@ -948,7 +948,8 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
     order = np.sort(c[sc > 0])
     for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
-                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}):
+                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1},
+                {"ed_wave_rows": 3, "search_segment": 300}):
         old_env = {k: gs.ctx.get_option(k) for k in env}
         for k, v in env.items():
             gs.ctx.set_option(k, v)
@@ -977,6 +978,21 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
                 if one[0] >= 0:
                     assert np.array_equal(got[5], one[5])
             assert many[1][0] == -1 and many[1][1] == 0
+            # the batches' segment steps merged into shared launches (default) == one batch after the other
+            with gs.ctx.option("search_per_range", 1):
+                seq = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
+            for got, want_ in zip(many, seq):
+                assert got[:5] == want_[:5] and (got[0] < 0 or np.array_equal(got[5], want_[5]))
+            with gs.ctx.option("search_segment", 300):  # several steps per batch, batches of unequal length
+                short = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
+                with gs.ctx.option("ed_wave_rows", 1):  # the continuation one pending hypothesis per batch first
+                    short1 = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient,
+                                               min_diameter_factor=0.2)
+            with gs.ctx.option("ed_wave_rows", 0):  # ... or all pending hypotheses at once
+                nowave = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
+            for other in (short, short1, nowave):
+                for got, want_ in zip(many, other):
+                    assert got[:5] == want_[:5] and (got[0] < 0 or np.array_equal(got[5], want_[5]))
     # degenerate batches
     assert gs.search_batch(gm, np.zeros((0, 2), np.uint32), diam, DT, 0.5, True, 0.0)[0] == -1
     with pytest.raises(capi.TmError):
@@ -992,6 +1008,16 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
         lists = gs.radius_lists(centers, r)
         for k, c in enumerate(centers):
             assert np.array_equal(lists[k], os_.radius_subset(int(c), r))
+        # the sampling loop's view of the same neighbourhoods: size + (rank, index) of the tangent members
+        counts, tangent = gs.radius_tangent_lists(centers, r)
+        tm = small_case["scene"]["tangent_mask"]
+        for k in range(len(centers)):
+            assert counts[k] == len(lists[k])
+            want = {int(rk): int(j) for rk, j in enumerate(lists[k]) if tm[j]}
+            assert tangent[k] == want, (r, k)
+    assert sum(len(t) for t in tangent) >= 0
+    counts, tangent = gs.radius_tangent_lists(centers, diam)
+    assert sum(len(t) for t in tangent) > 100
 
 
 def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case):

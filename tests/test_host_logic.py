@@ -152,6 +152,7 @@ def test_icp_refine_on_the_device_equals_the_host_loop(gpu_ctx, gpu_small, small
     rng = np.random.default_rng(19)
     dt2 = 6.0
     moved = 0
+    batch = {0: [], 1: [], 3: [], 10: []}  # (start, pose, count, iterations) per iteration limit
     for k, T in enumerate(small_case["scene"]["poses_scene_to_model"]):
         for trial, (angle, shift) in enumerate([(0.01, 0.5), (0.03, 1.5), (0.0, 0.0), (1.0, 50.0)]):
             dR = mod.rot(rng.normal(size=3), angle)
@@ -179,4 +180,11 @@ def test_icp_refine_on_the_device_equals_the_host_loop(gpu_ctx, gpu_small, small
                 assert cnt == best_n and iters == it, (k, trial, max_it)
                 assert np.array_equal(pose.view(np.uint32), np.asarray(best_t, np.float32).view(np.uint32)), (k, trial, max_it)
                 moved += int(it > 0)
+                batch[max_it].append((start, pose, cnt, iters))
     assert moved >= 6
+    # tm_icp_refine_batch: the same candidates side by side (loops of different lengths in one batch) = each alone
+    for max_it, rows in batch.items():
+        poses, cnts, its = gs.icp_refine_batch(gm, np.stack([r[0] for r in rows]), dt2, max_it)
+        for k, (_, pose, cnt, iters) in enumerate(rows):
+            assert cnts[k] == cnt and its[k] == iters, (max_it, k)
+            assert np.array_equal(poses[k].view(np.uint32), np.asarray(pose, np.float32).view(np.uint32)), (max_it, k)

@@ -69,6 +69,9 @@ int main(int argc, char** argv) {
         const auto& st = s.last_stats();
         printf("   phases [s]: radius %.3f sample %.3f generate+score %.3f extract %.3f icp %.3f arbitration %.3f mask %.3f | "
                "total %.3f\n", st.radius, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask, st.total);
+        printf("   sampling: %llu rounds, %llu first points sampled, %llu positions drawn, %llu neighbourhood entries handed over\n",
+               (unsigned long long)st.rounds, (unsigned long long)st.firsts_sampled, (unsigned long long)st.draws,
+               (unsigned long long)st.neighbours);
     }
     for (const auto& mt : matches) {
         double best = 1e30;

@@ -102,6 +102,7 @@ SIGNATURES = {
     "tm_scene_download": (C.c_int, [vp, f32p, i32p]),
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
+    "tm_scene_radius_tangent_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, u32p, u32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
@@ -126,6 +127,7 @@ SIGNATURES = {
                                              f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
     "tm_icp_refine": (C.c_int, [vp, vp, f32p, C.c_float, C.c_uint32, f32p, u32p, u32p]),
+    "tm_icp_refine_batch": (C.c_int, [vp, vp, f32p, C.c_uint32, C.c_float, C.c_uint32, f32p, u32p, u32p]),
     "tm_rigid_fit": (C.c_int, [C.POINTER(C.c_longlong), C.c_uint32, f32p]),
     "tm_best_of_batch": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.POINTER(BestRecord)]),
@@ -749,6 +751,20 @@ class Scene:
                                            counts.ctypes.data_as(u32p)))
         return [lists[k, :counts[k]].copy() for k in range(cn.size)]
 
+    def radius_tangent_lists(self, centers, radius):
+        """(sizes of the neighbourhoods, per centre a dict rank -> index of its tangent members)"""
+        c, pc = _u(centers)
+        counts = np.zeros(len(c), np.uint32)
+        n = C.c_uint32(0)
+        rc = lib().tm_scene_radius_tangent_lists(self.h, pc, len(c), radius, counts.ctypes.data_as(u32p), None, 0, C.byref(n))
+        if rc not in (OK, ERR_CAPACITY):
+            _check(rc)
+        tri = np.zeros((max(n.value, 1), 3), np.uint32)
+        _check(lib().tm_scene_radius_tangent_lists(self.h, pc, len(c), radius, counts.ctypes.data_as(u32p),
+                                                   tri.ctypes.data_as(u32p), n.value, C.byref(n)))
+        tri = tri[:n.value]
+        return counts, [dict(zip(tri[tri[:, 0] == k, 1].tolist(), tri[tri[:, 0] == k, 2].tolist())) for k in range(len(c))]
+
     def generate_hypotheses(self, model, ij_pairs, min_diameter_factor=0.2,
                             max_diameter_factor=1.0, force_up=False, query_limit=200, cap=None):
         ij, pij = _u(np.asarray(ij_pairs).reshape(-1, 2))
@@ -875,6 +891,16 @@ class Scene:
         _check(lib().tm_icp_refine(self.h, model.h, pT, dist_thres, max_iterations, out.ctypes.data_as(f32p),
                                    C.byref(cnt), C.byref(it)))
         return out, cnt.value, it.value
+
+    def icp_refine_batch(self, model, poses16, dist_thres, max_iterations):
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        n = P.shape[0]
+        out = np.zeros((n, 16), np.float32)
+        cnt = np.zeros(n, np.uint32)
+        it = np.zeros(n, np.uint32)
+        _check(lib().tm_icp_refine_batch(self.h, model.h, pP, n, dist_thres, max_iterations, out.ctypes.data_as(f32p),
+                                         cnt.ctypes.data_as(u32p), it.ctypes.data_as(u32p)))
+        return out, cnt, it
 
     def icp_accumulate(self, model, pose16, dist_thres):
         T, pT = _f(pose16)

@@ -20,6 +20,8 @@
 
 #include "tm_score.h"
 
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -57,7 +59,30 @@ struct ed_args {
     uint32_t prefix_words;   /* k_ed_fused<true>: 64-bit words of scan positions its LDS bit arrays hold */
     const uint32_t* stop;    /* tm_search_batch: index of the first sufficient hypothesis found so far, 0xFFFFFFFF =
                                 none yet; the kernels of later segments leave at once when it is set. null = unused */
+    /* One segment step of SEVERAL independent batches in one launch (tm_search_batches: the chunks of a round):
+     * the prefix kernel's workgroup (x, y) takes hypothesis rng_starts[y] + seg_step * seg_len + x of batch y and
+     * leaves at once when that is past the batch's end or the batch's stop word rng_stop[y] is set; h0 = 0 and the
+     * pending list holds global hypothesis indices. null = one batch per launch (h0, stop). */
+    const uint32_t* rng_starts;
+    const uint32_t* rng_stop;
+    uint32_t seg_len, seg_step;
+    /* The continuation in waves (k_pending_sort): the pending rows are in visit order, row_info[row] = position of
+     * the row among its batch's pending rows | batch << 20; a launch takes the rows with ord_lo <= position < ord_hi
+     * whose batch has no sufficient hypothesis yet. Only the FIRST sufficient hypothesis of a batch counts
+     * (reference include/impl/scene.hpp:330-338), and a segment with a true match holds dozens of pending
+     * hypotheses that all scan their whole neighbourhood: the first few in visit order settle it. null = all rows. */
+    const uint32_t* row_info;
+    uint32_t ord_lo, ord_hi;
 };
+
+/* does this launch take pending row `row` (see ed_args::row_info)? */
+__device__ __forceinline__ bool ed_row_selected(const ed_args& a, uint32_t row) {
+    if (!a.row_info) return true;
+    const uint32_t info = a.row_info[row], ord = info & 0xFFFFFu, b = info >> 20;
+    if (ord < a.ord_lo || ord >= a.ord_hi) return false;
+    if (a.rng_stop) return a.rng_stop[b] == 0xFFFFFFFFu;
+    return !(a.stop && *a.stop != 0xFFFFFFFFu);
+}
 
 __device__ __forceinline__ bool ed_stopped(const ed_args& a) { return a.stop && *a.stop != 0xFFFFFFFFu; }
 
@@ -126,6 +151,39 @@ __global__ __launch_bounds__(256) void k_ball_members(const float4* __restrict__
     if ((threadIdx.x & 63) == 0 && (i >> 6) < mwords) member[(size_t)c * mwords + (i >> 6)] = b;
     if (i == 0) centre_pos[c] = C;
 }
+
+/* The tangent members of several balls: for slot blockIdx.y and every scene point t with tangent_mask set that
+ * lies in the ball, one (slot, rank of t in the ball's ascending index order, t) triple is appended to `out`
+ * (wave-aggregated append; the order of the triples is not defined). */
+__global__ __launch_bounds__(256) void k_ball_tangent(const unsigned long long* __restrict__ member,
+                                                      const uint32_t* __restrict__ wprefix, uint32_t mwords,
+                                                      const uint32_t* __restrict__ tangent_idx, uint32_t n_tangent,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, lane = threadIdx.x & 63;
+    bool in = false;
+    uint32_t t = 0, rank = 0;
+    if (k < n_tangent) {
+        t = tangent_idx[k];
+        const unsigned long long mbits = member[(size_t)c * mwords + (t >> 6)];
+        in = ((mbits >> (t & 63u)) & 1ull) != 0ull;
+        rank = wprefix[(size_t)c * mwords + (t >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (t & 63u)) - 1ull));
+    }
+    const unsigned long long b = __ballot(in);
+    if (!b) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)b) - 1)) base = atomicAdd(cursor, (uint32_t)__popcll(b));
+    base = __shfl(base, __ffsll((long long)b) - 1);
+    if (in) {
+        const uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        out[3 * (size_t)e] = c;
+        out[3 * (size_t)e + 1] = rank;
+        out[3 * (size_t)e + 2] = t;
+    }
+}
+
+struct is_nonzero_i32 {
+    __host__ __device__ bool operator()(int32_t v) const { return v != 0; }
+};
 
 /* exclusive prefix of the word popcounts of one slot (one 1024-thread block per slot) and the total */
 __global__ __launch_bounds__(1024) void k_ball_prefix(const unsigned long long* __restrict__ member, uint32_t mwords,
@@ -271,6 +329,7 @@ __global__ __launch_bounds__(64) void k_ed_walk(ed_args a, ed_out o, float accep
     const uint32_t row = blockIdx.x, lane = threadIdx.x;
     if (ed_stopped(a)) return;
     if (pending && row0 + row >= *n_pending) return;
+    if (pending && !ed_row_selected(a, row0 + row)) return;
     const uint32_t hl = pending ? pending[row0 + row] : row;
     const bool ball = a.ball.slot_of_hyp != nullptr;
     const uint32_t slot = ball ? a.ball.slot_of_hyp[a.h0 + hl] : 0u;
@@ -405,6 +464,7 @@ __global__ __launch_bounds__(256) void k_ed_bits_wide(ed_args a, ed_cull ca, con
     const float4 tbs = have_tile ? ca.tiles[t] : make_float4(0.f, 0.f, 0.f, -1.f);
     const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
     for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        if (!ed_row_selected(a, row0 + row)) continue;
         const uint32_t hl = pending[row0 + row];
         const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
         const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
@@ -469,6 +529,7 @@ __global__ __launch_bounds__(256) void k_ed_score_rows(ed_args a, const uint32_t
     const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
     const bool ball = a.ball.slot_of_hyp != nullptr;
     for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        if (!ed_row_selected(a, row0 + row)) continue; /* uniform over the workgroup */
         const uint32_t hl = pending[row0 + row];
         const uint32_t lim = limit[a.h0 + hl];
         long long fx = 0;
@@ -541,7 +602,12 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     const uint32_t n_items = from_list ? *n_pending : gridDim.x;
     const uint32_t* const tests_in = tests;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t hl = from_list ? pending[item] : item;
+    uint32_t hl = from_list ? pending[item] : item;
+    if (PREFIX && a.rng_starts) { /* merged step: (local index, batch) -> global hypothesis, or nothing to do */
+        const uint32_t b = blockIdx.y;
+        hl = a.rng_starts[b] + a.seg_step * a.seg_len + blockIdx.x;
+        if (blockIdx.x >= a.seg_len || hl >= a.rng_starts[b + 1] || a.rng_stop[b] != 0xFFFFFFFFu) return;
+    }
     tests = tests_in;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bit_words = PREFIX ? a.prefix_words : a.words;
@@ -778,39 +844,159 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     } /* item */
 }
 
+/* The pending list of one step in visit order: ascending hypothesis index (the prefix kernel appends in no order),
+ * and per row its position among the pending rows of its batch | batch << 20 (ed_args::row_info). One workgroup,
+ * rank sort in LDS for up to kPendingSortMax rows; a longer list is left as it is with position 0 everywhere, which
+ * makes every row part of the first wave (= no waves). */
+constexpr uint32_t kPendingSortMax = 4096;
+__global__ __launch_bounds__(1024) void k_pending_sort(uint32_t* __restrict__ pending,
+                                                       const uint32_t* __restrict__ n_pending,
+                                                       const uint32_t* __restrict__ rng_starts, uint32_t n_ranges,
+                                                       uint32_t cap, uint32_t* __restrict__ row_info) {
+    __shared__ uint32_t s_h[kPendingSortMax];
+    const uint32_t n = min(*n_pending, cap);
+    if (n > kPendingSortMax) {
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) row_info[i] = 0u;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) s_h[i] = pending[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint32_t v = s_h[i];
+        uint32_t b = 0, lo = 0;
+        if (rng_starts) {
+            while (b + 1 < n_ranges && rng_starts[b + 1] <= v) ++b;
+            lo = rng_starts[b];
+        }
+        uint32_t rank = 0, before_batch = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t w = s_h[j];
+            rank += w < v ? 1u : 0u;
+            before_batch += w < lo ? 1u : 0u;
+        }
+        pending[rank] = v;
+        row_info[rank] = min(rank - before_batch, 0xFFFFFu) | (b << 20);
+    }
+}
+
+/* what decides, after a wave of the continuation, whether a batch has its sufficient hypothesis */
+struct ed_seg_check {
+    const uint32_t* counts = nullptr;
+    const unsigned long long* fx = nullptr;
+    float sufficient = 0.f;
+    uint32_t* found = nullptr;      /* one word per batch (merged step) or the batch's word */
+    const uint32_t* starts = nullptr; /* merged step: device hypothesis offsets of the batches */
+    uint32_t n_ranges = 0, seg_len = 0, step = 0;
+    uint32_t h0 = 0, h1 = 0;        /* single batch: the segment's hypotheses */
+};
+
+/* first hypothesis of [n0, n1) with a positive score and (float)count > sufficient -> *found, unless an earlier
+ * segment already has one; one workgroup */
+__global__ __launch_bounds__(1024) void k_segment_first(const uint32_t* __restrict__ counts,
+                                                        const unsigned long long* __restrict__ fx, uint32_t n0,
+                                                        uint32_t n1, float sufficient, uint32_t* found) {
+    __shared__ uint32_t s_first;
+    if (*found != 0xFFFFFFFFu) return;
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t h = n0 + threadIdx.x; h < n1; h += blockDim.x)
+        if (fx[h] != 0ull && (float)counts[h] > sufficient) {
+            atomicMin(&s_first, h);
+            break;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_first != 0xFFFFFFFFu) *found = s_first;
+}
+/* the same for one segment step of several batches: workgroup b looks at hypotheses
+ * [starts[b] + step * seg_len, min(+ seg_len, starts[b + 1])) unless found[b] is already set */
+__global__ __launch_bounds__(1024) void k_segment_first_ranges(const uint32_t* __restrict__ counts,
+                                                               const unsigned long long* __restrict__ fx,
+                                                               const uint32_t* __restrict__ starts, uint32_t seg_len,
+                                                               uint32_t step, float sufficient, uint32_t* found) {
+    __shared__ uint32_t s_first;
+    const uint32_t b = blockIdx.x;
+    if (found[b] != 0xFFFFFFFFu) return;
+    const uint32_t n0 = starts[b] + step * seg_len, n1 = min(n0 + seg_len, starts[b + 1]);
+    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t h = n0 + threadIdx.x; h < n1; h += blockDim.x)
+        if (fx[h] != 0ull && (float)counts[h] > sufficient) {
+            atomicMin(&s_first, h);
+            break;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_first != 0xFFFFFFFFu) found[b] = s_first;
+}
+
 /* the fused rule in two launches: the prefix kernel (small LDS, high occupancy) decides the hypotheses that
  * drop at the first checkpoint, the full kernel continues with the rest (TM_ED_ONE_KERNEL=1: full kernel only) */
 static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t fused_lds, const ed_args& a,
                                   const ed_cull& cu, const ed_out& o, float accept_thresh, const uint32_t* d_tests,
-                                  uint32_t rows_cap = 0) {
+                                  uint32_t rows_cap = 0, uint32_t n_ranges = 0, uint32_t* d_n_step = nullptr,
+                                  const ed_seg_check* check = nullptr) {
+    /* n_ranges > 0: one segment step of n_ranges batches (a.rng_*): n_hyp = n_ranges * a.seg_len workgroups, the
+     * pending counter d_n_step was zeroed by the caller for all steps at once */
+    auto run_check = [&]() {
+        if (check && check->starts)
+            hipLaunchKernelGGL(k_segment_first_ranges, dim3(check->n_ranges), dim3(1024), 0, c->stream, check->counts,
+                               check->fx, check->starts, check->seg_len, check->step, check->sufficient, check->found);
+        else if (check)
+            hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, check->counts, check->fx, check->h0,
+                               check->h1, check->sufficient, check->found);
+    };
     if (c->opt.ed_one_kernel) {
         hipLaunchKernelGGL(k_ed_fused<false>, dim3(n_hyp), dim3(256), fused_lds, c->stream, a, cu, o, accept_thresh,
                            d_tests, s->oref.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        run_check();
         return hipGetLastError();
     }
-    if (s->ed_pending.ensure((size_t)n_hyp + 1) != TM_OK) return hipErrorOutOfMemory;
-    uint32_t* d_n = s->ed_pending.p + n_hyp;
-    hipError_t e = hipMemsetAsync(d_n, 0, 4, c->stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ed_fused<true>, dim3(n_hyp), dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
+    uint32_t* d_n = d_n_step;
+    if (!d_n) {
+        if (s->ed_pending.ensure((size_t)n_hyp + 1) != TM_OK) return hipErrorOutOfMemory;
+        d_n = s->ed_pending.p + n_hyp;
+        hipError_t e = hipMemsetAsync(d_n, 0, 4, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 pgrid = n_ranges ? dim3(a.seg_len, n_ranges) : dim3(n_hyp);
+    hipLaunchKernelGGL(k_ed_fused<true>, pgrid, dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
                        accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
     if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !c->opt.ed_narrow) {
         /* wide continuation (ball mode: the scan order is the neighbourhood list): bits of all positions of the
          * pending hypotheses, then the rule and the score terms on those rows; rows_cap rows of bit arrays */
-        ed_args as = a; /* k_ed_score addresses scene points by original index */
-        as.sc.sref = s->oref.p;
+        ed_args aw = a;
         const uint32_t gw = (a.words + 255u) / 256u, gs = (cu.n_tiles + 63u) / 64u, gb = (a.words * 8u + 255u) / 256u;
+        /* Only the first sufficient hypothesis of a batch counts (check != null: a search step). The rows go through
+         * in two waves in visit order — the first `ed_wave_rows` pending hypotheses of every batch, then the rest of
+         * the batches that still have none: a segment that contains a true match holds dozens of pending hypotheses
+         * which each scan their whole neighbourhood, and the first few settle it. Whole-batch scoring (check == null)
+         * reports every hypothesis: one wave. */
+        const uint32_t wave_rows = check && rows_cap >= n_hyp ? (uint32_t)c->opt.ed_wave_rows : 0u;
+        if (wave_rows) {
+            if (s->ed_row_info.ensure(n_hyp) != TM_OK) return hipErrorOutOfMemory;
+            hipLaunchKernelGGL(k_pending_sort, dim3(1), dim3(1024), 0, c->stream, s->ed_pending.p, d_n, a.rng_starts, n_ranges,
+                               n_hyp, s->ed_row_info.p);
+            aw.row_info = s->ed_row_info.p;
+        }
+        ed_args as = aw; /* k_ed_score addresses scene points by original index */
+        as.sc.sref = s->oref.p;
         for (uint32_t row0 = 0; row0 < n_hyp; row0 += rows_cap) {
             const uint32_t rows = std::min(rows_cap, n_hyp - row0);
             const uint32_t gy = std::min(rows, 128u);
             hipLaunchKernelGGL(k_ed_zero_rows, dim3(gw, gy), dim3(256), 0, c->stream, a.tail_bits, a.corr_bits, a.words,
                                d_n, row0, rows);
-            hipLaunchKernelGGL(k_ed_bits_wide, dim3(gs, gy), dim3(256), 0, c->stream, a, cu, s->ed_pending.p, d_n, row0,
-                               rows);
-            hipLaunchKernelGGL(k_ed_walk, dim3(rows), dim3(64), 0, c->stream, a, o, accept_thresh, d_tests,
-                               s->ed_pending.p, d_n, row0);
-            hipLaunchKernelGGL(k_ed_score_rows, dim3(gb, gy), dim3(256), 0, c->stream, as, o.limit, s->ed_pending.p, d_n,
-                               row0, rows);
+            for (uint32_t wave = 0; wave < (wave_rows ? 2u : 1u); ++wave) {
+                if (wave_rows) {
+                    aw.ord_lo = as.ord_lo = wave == 0 ? 0u : wave_rows;
+                    aw.ord_hi = as.ord_hi = wave == 0 ? wave_rows : 0xFFFFFFFFu;
+                }
+                hipLaunchKernelGGL(k_ed_bits_wide, dim3(gs, gy), dim3(256), 0, c->stream, aw, cu, s->ed_pending.p, d_n, row0,
+                                   rows);
+                hipLaunchKernelGGL(k_ed_walk, dim3(rows), dim3(64), 0, c->stream, aw, o, accept_thresh, d_tests,
+                                   s->ed_pending.p, d_n, row0);
+                hipLaunchKernelGGL(k_ed_score_rows, dim3(gb, gy), dim3(256), 0, c->stream, as, o.limit, s->ed_pending.p, d_n,
+                                   row0, rows);
+                run_check();
+            }
         }
         return hipGetLastError();
     }
@@ -818,6 +1004,7 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
     hipLaunchKernelGGL(k_ed_fused<false>, dim3(std::min<uint32_t>(n_hyp, (uint32_t)cus * 2u)), dim3(256), fused_lds,
                        c->stream, a, cu, o, accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
+    run_check();
     return hipGetLastError();
 }
 
@@ -939,6 +1126,12 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
     a.stop = nullptr;
+    a.rng_starts = nullptr;
+    a.rng_stop = nullptr;
+    a.seg_len = a.seg_step = 0;
+    a.row_info = nullptr;
+    a.ord_lo = 0;
+    a.ord_hi = 0xFFFFFFFFu;
     a.prefix_words = ed_prefix_words(a.S);
     ed_out o;
     o.counts = d_counts.p;
@@ -1019,23 +1212,6 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
 }
 
 namespace tmx {
-/* first hypothesis of [n0, n1) with a positive score and (float)count > sufficient -> *found, unless an earlier
- * segment already has one; one workgroup */
-__global__ __launch_bounds__(1024) void k_segment_first(const uint32_t* __restrict__ counts,
-                                                        const unsigned long long* __restrict__ fx, uint32_t n0,
-                                                        uint32_t n1, float sufficient, uint32_t* found) {
-    __shared__ uint32_t s_first;
-    if (*found != 0xFFFFFFFFu) return;
-    if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t h = n0 + threadIdx.x; h < n1; h += blockDim.x)
-        if (fx[h] != 0ull && (float)counts[h] > sufficient) {
-            atomicMin(&s_first, h);
-            break;
-        }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_first != 0xFFFFFFFFu) *found = s_first;
-}
 }  // namespace tmx
 
 /* The ball mode with everything already on the device: poses at d_poses, the slot (index into uniq) of every
@@ -1044,7 +1220,7 @@ __global__ __launch_bounds__(1024) void k_segment_first(const uint32_t* __restri
 static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t n_hyp, const uint32_t* uniq,
                         uint32_t n_slots, float radius, float dist_thres, float accept_prob, uint32_t segment = 0,
                         float sufficient = 0.f, uint32_t* d_found = nullptr, const uint32_t* range_starts = nullptr,
-                        uint32_t n_ranges = 0) {
+                        uint32_t n_ranges = 0, const uint32_t* d_starts_dev = nullptr) {
     /* range_starts (n_ranges + 1 hypothesis offsets, host): independent batches, each with its own word of
      * d_found and its own segments; null = one batch, all hypotheses */
     const uint32_t one_range[2] = {0u, n_hyp};
@@ -1138,6 +1314,12 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.tail_bits = d_tail.p;
     a.corr_bits = d_corr.p;
     a.stop = nullptr;
+    a.rng_starts = nullptr;
+    a.rng_stop = nullptr;
+    a.seg_len = a.seg_step = 0;
+    a.row_info = nullptr;
+    a.ord_lo = 0;
+    a.ord_hi = 0xFFFFFFFFu;
     a.prefix_words = ed_prefix_words(a.S);
     ed_brick_filter(m, dist_thres * m->resolution, a.sc);
     ed_args as = a; /* k_ed_score addresses scene points by original index */
@@ -1167,15 +1349,56 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         /* tm_search_batch: only the first sufficient hypothesis in visit order is wanted (reference :330-338: later
          * ones are scored without effect). The hypotheses go through in segments; after each, *d_found takes the
          * first sufficient index of the segment, and the kernels of all later segments leave at once. */
+        if (n_ranges > 1 && d_starts_dev && !c->opt.ed_one_kernel && !c->opt.ed_narrow && !c->opt.search_per_range) {
+            /* The batches are independent (the chunks of one find_parallel round): segment step k of ALL of them
+             * goes through in one set of launches — workgroup (x, b) of the prefix kernel takes the x-th hypothesis of
+             * batch b's k-th segment, the pending hypotheses of all batches share the wide continuation, and one
+             * workgroup per batch writes its stop word. A round of seven chunks costs max(segments) steps of six
+             * launches instead of sum(segments) x 7, and the latency-bound continuation kernels (a chain of
+             * dependent gathers per pending row) run once per step instead of once per batch. */
+            uint32_t steps = 0;
+            for (uint32_t b = 0; b < n_ranges; ++b)
+                steps = std::max(steps, (range_starts[b + 1] - range_starts[b] + segment - 1) / segment);
+            const size_t pend_cap = (size_t)n_ranges * segment;
+            TM_FORWARD(s->ed_pending.ensure(pend_cap + steps + 1));
+            uint32_t* d_n_steps = s->ed_pending.p + pend_cap;
+            TM_HIP_CHECK(hipMemsetAsync(d_n_steps, 0, (size_t)steps * 4, c->stream));
+            a.h0 = 0;
+            a.stop = nullptr;
+            a.rng_starts = d_starts_dev;
+            a.rng_stop = d_found;
+            a.seg_len = segment;
+            const uint32_t rows_cap = (uint32_t)std::min<size_t>(chunk, pend_cap);
+            for (uint32_t k = 0; k < steps; ++k) {
+                a.seg_step = k;
+                ed_seg_check chk;
+                chk.counts = d_counts.p;
+                chk.fx = d_fx.p;
+                chk.sufficient = sufficient;
+                chk.found = d_found;
+                chk.starts = d_starts_dev;
+                chk.n_ranges = n_ranges;
+                chk.seg_len = segment;
+                chk.step = k;
+                TM_HIP_CHECK(launch_ed_fused(s, c, (uint32_t)pend_cap, fused_lds, a, cu, o, accept_thresh, d_tests.p, rows_cap,
+                                             n_ranges, d_n_steps + k, &chk));
+            }
+            a.rng_starts = nullptr;
+        } else
         for (uint32_t b = 0; b < n_ranges; ++b) {
             a.stop = d_found + b;
             for (uint32_t h0 = range_starts[b]; h0 < range_starts[b + 1]; h0 += segment) {
                 const uint32_t nh = std::min(segment, range_starts[b + 1] - h0);
                 a.h0 = h0;
-                TM_HIP_CHECK(launch_ed_fused(s, c, nh, fused_lds, a, cu, o, accept_thresh, d_tests.p, std::min(chunk, nh)));
-                hipLaunchKernelGGL(k_segment_first, dim3(1), dim3(1024), 0, c->stream, d_counts.p, d_fx.p, h0, h0 + nh,
-                                   sufficient, d_found + b);
-                TM_HIP_CHECK(hipGetLastError());
+                ed_seg_check chk;
+                chk.counts = d_counts.p;
+                chk.fx = d_fx.p;
+                chk.sufficient = sufficient;
+                chk.found = d_found + b;
+                chk.h0 = h0;
+                chk.h1 = h0 + nh;
+                TM_HIP_CHECK(launch_ed_fused(s, c, nh, fused_lds, a, cu, o, accept_thresh, d_tests.p, std::min(chunk, nh), 0,
+                                             nullptr, &chk));
             }
         }
     } else if (fused) {
@@ -1398,7 +1621,7 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
         /* segments of 2048 hypotheses (one resident round of the prefix kernel); TM_SEARCH_SEGMENT=0: all at once */
         const uint32_t segment = s->ctx->opt.search_segment >= 0 ? (uint32_t)s->ctx->opt.search_segment : 2048u;
         TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
-                                accept_prob, segment, sufficient, d_found, starts.data(), n_batches));
+                                accept_prob, segment, sufficient, d_found, starts.data(), n_batches, d_starts));
         for (uint32_t b = 0; b < n_batches; ++b)
             hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
                                (const double*)nullptr, s->ed_dropped.p, starts[b + 1] - starts[b], sufficient, (double)m->n,
@@ -1540,6 +1763,88 @@ extern "C" int tm_score_hypotheses_on_points(tm_scene* s, tm_model* m, const flo
 /* radius_search_inclusive for several centres with the index lists built on the device: membership bits,
  * per-word prefix counts and an ordered scatter (the kernels of the ball mode above); only counts[k] indices
  * per centre travel back. */
+/* What the sampling loop of find_in_subset needs of nn = radius_search_inclusive(radius, centre) (reference
+ * include/impl/scene.hpp:273-302): its size (inner_bound :276-281, and the range of the shuffle's draws :285) and its
+ * members with tangent_mask_ set — every other member fails the first filter of :290 whatever its index is. So only
+ * those travel: counts[k] = size of nn_k, and one (k, rank, index) triple per tangent member of nn_k, rank = its
+ * position in nn_k's ascending order (the order tm_scene_radius_lists hands out). A neighbourhood of 60,000 points
+ * with 4 % tangent points is 29 KB instead of 240 KB. *n_triples = total written (triples = 3 x uint32 each, order not
+ * defined); TM_ERR_CAPACITY (with counts and *n_triples valid) when cap_triples is too small. */
+extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
+                                             uint32_t* counts, uint32_t* triples, uint32_t cap_triples,
+                                             uint32_t* n_triples) {
+    TM_REQUIRE(s && counts && n_triples && (centers || n_centers == 0), TM_ERR_INVALID,
+               "tm_scene_radius_tangent_lists: null argument");
+    *n_triples = 0;
+    if (n_centers == 0) return TM_OK;
+    for (uint32_t k = 0; k < n_centers; ++k)
+        TM_REQUIRE(centers[k] < s->n, TM_ERR_INVALID, "tm_scene_radius_tangent_lists: centre index out of range");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    if (!s->tangent_idx_ready) { /* ascending indices of the points with tangent_mask set: once per scene */
+        TM_FORWARD(s->d_tangent_idx.ensure((size_t)s->n + 1));
+        size_t tmp = 0;
+        rocprim::counting_iterator<uint32_t> idx(0u);
+        auto flags = rocprim::make_transform_iterator(s->d_tmask.p, is_nonzero_i32());
+        TM_HIP_CHECK(rocprim::select(nullptr, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n, (size_t)s->n,
+                                     c->stream));
+        TM_FORWARD(scratch_ensure(c, tmp));
+        TM_HIP_CHECK(rocprim::select(c->scratch.p, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n,
+                                     (size_t)s->n, c->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(&s->n_tangent, s->d_tangent_idx.p + s->n, 4, hipMemcpyDeviceToHost, c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        s->tangent_idx_ready = true;
+    }
+    const uint32_t mwords = (s->n + 63) / 64;
+    TM_FORWARD(s->ed_centres.ensure(n_centers));
+    TM_FORWARD(s->ed_member.ensure((size_t)n_centers * mwords));
+    TM_FORWARD(s->ed_wprefix.ensure((size_t)n_centers * mwords));
+    TM_FORWARD(s->ed_S.ensure((size_t)n_centers + 1)); /* + the append cursor */
+    TM_FORWARD(s->ed_cpos.ensure(n_centers));
+    const size_t worst = (size_t)n_centers * s->n_tangent;
+    TM_FORWARD(s->ed_tlist.ensure(3 * std::max<size_t>(worst, 1)));
+    TM_HIP_CHECK(hipMemcpyAsync(s->ed_centres.p, centers, (size_t)n_centers * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->ed_S.p + n_centers, 0, 4, c->stream));
+    const dim3 grid_n((s->n + 255) / 256, n_centers);
+    hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, s->ed_centres.p,
+                       radius * radius, mwords, s->ed_member.p, s->ed_cpos.p);
+    hipLaunchKernelGGL(k_ball_prefix, dim3(n_centers), dim3(1024), 0, c->stream, s->ed_member.p, mwords,
+                       s->ed_wprefix.p, s->ed_S.p);
+    if (s->n_tangent)
+        hipLaunchKernelGGL(k_ball_tangent, dim3((s->n_tangent + 255) / 256, n_centers), dim3(256), 0, c->stream,
+                           s->ed_member.p, s->ed_wprefix.p, mwords, s->d_tangent_idx.p, s->n_tangent,
+                           s->ed_S.p + n_centers, s->ed_tlist.p);
+    TM_HIP_CHECK(hipGetLastError());
+    /* sizes and the append cursor in one read-back, then exactly the triples that were written */
+    const size_t head = ((size_t)n_centers + 1) * 4;
+    if (s->h_pinned_bytes < head + 64) {
+        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+        s->h_pinned = nullptr;
+        s->h_pinned_bytes = 0;
+        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, 1 << 20, hipHostMallocDefault));
+        s->h_pinned_bytes = 1 << 20;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_S.p, head, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(counts, s->h_pinned, (size_t)n_centers * 4);
+    const uint32_t total = ((const uint32_t*)s->h_pinned)[n_centers];
+    *n_triples = total;
+    if (total == 0) return TM_OK;
+    TM_REQUIRE(triples && cap_triples >= total, TM_ERR_CAPACITY, "tm_scene_radius_tangent_lists: room for fewer triples than found");
+    const size_t need = (size_t)total * 12;
+    if (s->h_pinned_bytes < need) {
+        (void)hipHostFree(s->h_pinned);
+        s->h_pinned = nullptr;
+        s->h_pinned_bytes = 0;
+        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
+        s->h_pinned_bytes = need + need / 4;
+    }
+    TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_tlist.p, need, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(triples, s->h_pinned, need);
+    return TM_OK;
+}
+
 extern "C" int tm_scene_radius_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
                                      int32_t* lists, uint32_t stride, uint32_t* counts) {
     TM_REQUIRE(s && counts && (centers || n_centers == 0), TM_ERR_INVALID, "tm_scene_radius_lists: null argument");

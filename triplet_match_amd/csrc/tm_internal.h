@@ -102,6 +102,9 @@ struct options {
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
     int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
     int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
+    int ed_wave_rows = 8;     /* pending hypotheses per batch the continuation of a search step takes first (in visit
+                                 order); the rest follows only for batches still without a sufficient one. 0 = all at once */
+    int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
 };
 
 /* One tm_best_reduce in flight (tm_best_reduce_begin .. _end): the winners land in pinned host memory behind an
@@ -242,6 +245,11 @@ struct tm_scene {
     tmx::dbuf<uint32_t> ed_tests, ed_saved, ed_limit, ed_pos;
     tmx::dbuf<unsigned long long> ed_tail, ed_corr, ed_tilebits, ed_member;
     tmx::dbuf<uint32_t> ed_slot, ed_centres, ed_wprefix, ed_S;
+    tmx::dbuf<uint32_t> d_tangent_idx; /* ascending indices of the points with tangent_mask set, + their number */
+    uint32_t n_tangent = 0;
+    bool tangent_idx_ready = false;
+    tmx::dbuf<uint32_t> ed_tlist;      /* (slot, rank, index) triples of tm_scene_radius_tangent_lists */
+    tmx::dbuf<uint32_t> ed_row_info;   /* per pending row: position among its batch's pending rows | batch << 20 */
     tmx::dbuf<uint32_t> ed_pending; /* hypotheses the prefix kernel of the early-drop rule hands to the full kernel, + count */
     tmx::dbuf<float4> ed_cpos;
     /* tm_search_batch: pairs, provenance, slot of a pair's first point, centre per hypothesis, result record */

@@ -862,11 +862,19 @@ __global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
  * adds the blocks (no atomics: sixteen same-line atomics per wave serialise in one L2 channel). */
 constexpr int kIcpBlocks = 512;
 
+struct icp_state;
+__device__ __forceinline__ const uint32_t* icp_done_word(const icp_state* st, uint32_t cand);
+
+/* blockIdx.y = candidate (tm_icp_refine_batch: the candidates of one find_parallel round are refined side by side):
+ * pose a.poses + 16 y, partials [y][gridDim.x][16], loop state st[y] (null on the first pass) */
 __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n_pad,
-                                                        unsigned long long* __restrict__ partials /* [grid][16] */,
-                                                        const uint32_t* __restrict__ done = nullptr) {
+                                                        unsigned long long* __restrict__ partials /* [cand][grid][16] */,
+                                                        const icp_state* __restrict__ st = nullptr) {
     __shared__ long long s_acc[4][16];
-    if (done && *done) return; /* tm_icp_refine: the loop has ended */
+    const uint32_t cand = blockIdx.y;
+    if (st && *icp_done_word(st, cand)) return; /* tm_icp_refine: this candidate's loop has ended */
+    a.poses += (size_t)cand * 16;
+    partials += (size_t)cand * gridDim.x * 16;
     long long acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0;
@@ -913,6 +921,7 @@ struct icp_state {
     float best_t[16];
     uint32_t iter, done;
 };
+__device__ __forceinline__ const uint32_t* icp_done_word(const icp_state* st, uint32_t cand) { return &st[cand].done; }
 __device__ void icp_step(const unsigned long long* sums, float* pose, icp_state* st, uint32_t max_iterations, bool first) {
     if (first) {
         st->iter = 0;
@@ -941,14 +950,20 @@ __device__ void icp_step(const unsigned long long* sums, float* pose, icp_state*
     for (int k = 0; k < 16; ++k) pose[k] = T[k];
 }
 
-/* st != null (tm_icp_refine): thread 0 goes on with the turn of the loop these sums belong to */
+/* st != null (tm_icp_refine): thread 0 goes on with the turn of the loop these sums belong to. One workgroup per
+ * candidate (blockIdx.x): partials [cand][n_blocks][16], sums [cand][16], pose [cand][16], st[cand]. */
 __global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
-                                                      unsigned long long* __restrict__ sums /* 16 */,
-                                                      const uint32_t* __restrict__ done = nullptr,
+                                                      unsigned long long* __restrict__ sums /* [cand][16] */,
+                                                      int check_done = 0,
                                                       float* pose = nullptr, icp_state* st = nullptr,
                                                       uint32_t max_iterations = 0, int first = 0) {
     __shared__ unsigned long long s_part[16][16];
-    if (done && *done) return;
+    const uint32_t cand = blockIdx.x;
+    partials += (size_t)cand * n_blocks * 16;
+    sums += (size_t)cand * 16;
+    if (pose) pose += (size_t)cand * 16;
+    if (st) st += cand;
+    if (check_done && st && st->done) return;
     const uint32_t k = threadIdx.x & 15, slice = threadIdx.x >> 4; /* 16 slices of the block list */
     unsigned long long t = 0;
     for (uint32_t b = slice; b < n_blocks; b += 16) t += partials[(size_t)b * 16 + k];
@@ -1573,6 +1588,9 @@ int tm_scene_destroy(tm_scene* s) {
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     s->d_cloud.release();
     s->d_tmask.release();
+    s->d_tangent_idx.release();
+    s->ed_tlist.release();
+    s->ed_row_info.release();
     s->d_mask.release();
     s->d_order.release();
     s->d_bounds.release();
@@ -1953,7 +1971,7 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_scores_fx.p + 16);
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
-                       s->w_scores_fx.p);
+                       s->w_scores_fx.p, 0);
     TM_HIP_CHECK(hipGetLastError());
     unsigned long long h_sums[16];
     TM_HIP_CHECK(hipMemcpyAsync(h_sums, s->w_scores_fx.p, 16 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1965,39 +1983,54 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
 
 /* icp_ as one call (reference include/impl/scene.hpp:369-400 without the final finish_find): the passes, the
  * rigid fits and the "stop when the correspondences get fewer" test all run on the device, queued up front; one
- * 80-byte read-back at the end. Same poses as the host loop over tm_icp_accumulate + search::detail::rigid_fit. */
-int tm_icp_refine(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t max_iterations,
-                  float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations) {
+ * read-back at the end. Same poses as the host loop over tm_icp_accumulate + search::detail::rigid_fit.
+ * The batch form refines n independent candidates side by side (the reference refines the candidates of a round
+ * one after the other, :169-171; they do not depend on one another): every pass is ONE accumulate launch over
+ * (scene blocks, candidates) and ONE finalize launch with a workgroup per candidate, so a round's chain of
+ * launches is max_iterations + 1 passes long instead of candidates x (max_iterations + 1). */
+int tm_icp_refine_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
+                        uint32_t max_iterations, float* out_poses16, uint32_t* out_counts, uint32_t* out_iterations) {
     TM_FORWARD(check_pair(s, m));
-    TM_REQUIRE(pose16 && out_pose16 && out_count, TM_ERR_INVALID, "tm_icp_refine: null argument");
+    if (n == 0) return TM_OK;
+    TM_REQUIRE(poses16 && out_poses16 && out_counts, TM_ERR_INVALID, "tm_icp_refine_batch: null argument");
+    TM_REQUIRE(n <= 65535u, TM_ERR_INVALID, "tm_icp_refine_batch: more than 65,535 candidates");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
-    TM_FORWARD(s->w_poses.ensure(16));
+    TM_FORWARD(s->w_poses.ensure((size_t)n * 16));
     TM_FORWARD(s->w_counts.ensure(1));
     const uint32_t icp_blocks = std::min<uint32_t>((uint32_t)kIcpBlocks, s->n_sorted / 256);
     const size_t state_words = (sizeof(icp_state) + 7) / 8;
-    TM_FORWARD(s->w_scores_fx.ensure(16 + (size_t)kIcpBlocks * 16 + state_words));
-    icp_state* st = reinterpret_cast<icp_state*>(s->w_scores_fx.p + 16 + (size_t)kIcpBlocks * 16);
-    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
+    const size_t sums_words = (size_t)n * 16, part_words = (size_t)n * icp_blocks * 16;
+    TM_FORWARD(s->w_scores_fx.ensure(sums_words + part_words + state_words * n));
+    unsigned long long* sums = s->w_scores_fx.p;
+    unsigned long long* partials = s->w_scores_fx.p + sums_words;
+    icp_state* st = reinterpret_cast<icp_state*>(s->w_scores_fx.p + sums_words + part_words);
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
     score_args a;
     icp_score_args(s, m, dist_thres, a);
-    unsigned long long* sums = s->w_scores_fx.p;
-    unsigned long long* partials = s->w_scores_fx.p + 16;
     for (uint32_t pass = 0; pass <= max_iterations; ++pass) {
-        const uint32_t* done = pass ? &st->done : nullptr;
-        hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted, partials, done);
-        hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, partials, icp_blocks, sums, done,
+        hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks, n), dim3(256), 0, c->stream, a, s->n_sorted, partials,
+                           pass ? st : (const icp_state*)nullptr);
+        hipLaunchKernelGGL(k_icp_finalize, dim3(n), dim3(256), 0, c->stream, partials, icp_blocks, sums, pass ? 1 : 0,
                            s->w_poses.p, st, max_iterations, pass == 0 ? 1 : 0);
     }
     TM_HIP_CHECK(hipGetLastError());
-    icp_state h;
-    TM_HIP_CHECK(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    std::vector<icp_state> h(n);
+    TM_HIP_CHECK(hipMemcpyAsync(h.data(), st, sizeof(icp_state) * n, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 16; ++k) out_pose16[k] = h.best_t[k];
-    *out_count = (uint32_t)h.best_sums[15];
-    if (out_iterations) *out_iterations = h.iter;
+    for (uint32_t k = 0; k < n; ++k) {
+        for (int e = 0; e < 16; ++e) out_poses16[(size_t)k * 16 + e] = h[k].best_t[e];
+        out_counts[k] = (uint32_t)h[k].best_sums[15];
+        if (out_iterations) out_iterations[k] = h[k].iter;
+    }
     return TM_OK;
+}
+
+int tm_icp_refine(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t max_iterations,
+                  float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations) {
+    TM_REQUIRE(pose16 && out_pose16 && out_count, TM_ERR_INVALID, "tm_icp_refine: null argument");
+    return tm_icp_refine_batch(s, m, pose16, 1, dist_thres, max_iterations, out_pose16, out_count, out_iterations);
 }
 
 /* the rigid fit of the ICP loop on the host (the same function the device loop runs) */
