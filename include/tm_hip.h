@@ -345,6 +345,15 @@ int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pos
                                float dist_thres, uint32_t* scene_corrs, uint32_t* model_corrs,
                                uint32_t cap, uint32_t* count, double* score);
 
+/* finish_find for n poses in one call (the reference calls it once per candidate, include/impl/scene.hpp:361-364, and
+ * at the end of icp_, :401): the passes are queued back to back, ONE read-back of the counts and one of the lists
+ * (through pinned memory). scene_corrs / model_corrs = n rows of `stride` entries, counts[k] of row k valid, each
+ * row what tm_extract_correspondences returns for that pose alone. TM_ERR_CAPACITY (counts valid) when stride is
+ * smaller than a list. */
+int tm_extract_correspondences_batch(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n,
+                                     float dist_thres, uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride,
+                                     uint32_t* counts, double* scores);
+
 /* One ICP accumulation pass (reference icp_, include/impl/scene.hpp:385-393 + icp_correlation,
  * opencl/icp.cl:55-86): finds the correspondences of `pose16` exactly like finish_find (all points) and
  * returns their number and 15 sums over them — sum s (3), sum m (3), sum s_a*m_b (9, index 3*a+b) with s

@@ -318,6 +318,37 @@ struct hip_backend {
         out.scene_corrs.assign(sc_scratch.begin(), sc_scratch.begin() + count);
         out.model_corrs.assign(mc_scratch.begin(), mc_scratch.begin() + count);
     }
+    /* finish_find of several poses in one call (tm_extract_correspondences_batch): one read-back of the counts, one
+     * of the lists */
+    void extract_batch(const std::vector<search::pose_t>& Ts, float dist_thres, std::vector<search::candidate_t>& out) {
+        const uint32_t n = (uint32_t)Ts.size();
+        out.resize(n);
+        if (n == 0) return;
+        std::vector<uint32_t> counts(n);
+        std::vector<double> scores(n);
+        size_t stride = std::max<size_t>(batch_stride, 1024);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (sc_scratch.size() < stride * n) sc_scratch.resize(stride * n);
+            if (mc_scratch.size() < stride * n) mc_scratch.resize(stride * n);
+            const int rc = tm_extract_correspondences_batch(s, m, &Ts[0].m[0], n, dist_thres, sc_scratch.data(),
+                                                            mc_scratch.data(), (uint32_t)stride, counts.data(), scores.data());
+            if (rc == TM_ERR_CAPACITY && attempt == 0) {
+                size_t mx = 1;
+                for (uint32_t cnt : counts) mx = std::max<size_t>(mx, cnt);
+                stride = batch_stride = mx + mx / 8;
+                continue;
+            }
+            check(rc, "tm_extract_correspondences_batch");
+            break;
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            out[k].transform = Ts[k];
+            out[k].signed_score = scores[k];
+            out[k].scene_corrs.assign(sc_scratch.begin() + k * stride, sc_scratch.begin() + k * stride + counts[k]);
+            out[k].model_corrs.assign(mc_scratch.begin() + k * stride, mc_scratch.begin() + k * stride + counts[k]);
+        }
+    }
+    size_t batch_stride = 0;
     /* the whole ICP loop on the device (tm_icp_refine); TM_ICP_HOST_LOOP=1: one call per pass, fits on the host */
     bool supports_icp_refine() const { return !env_once().icp_host_loop; }
     search::pose_t icp_refine(const search::pose_t& T, float dist_thres, uint32_t max_iterations) {

@@ -317,6 +317,23 @@ inline void announce_round(B& be, const std::vector<uint32_t>& firsts, std::true
 template <class B>
 inline void announce_round(B&, const std::vector<uint32_t>&, std::false_type) {}
 
+/* does the backend run finish_find for several poses in one call? (hip_backend: tm_extract_correspondences_batch) */
+template <class B, class = void>
+struct has_extract_batch : std::false_type {};
+template <class B>
+struct has_extract_batch<B, decltype(void(std::declval<B&>().extract_batch(std::declval<const std::vector<pose_t>&>(), 0.f,
+                                                                             std::declval<std::vector<candidate_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline void extract_all(B& be, const std::vector<pose_t>& Ts, float dist_thres, std::vector<candidate_t>& out, std::true_type) {
+    be.extract_batch(Ts, dist_thres, out);
+}
+template <class B>
+inline void extract_all(B& be, const std::vector<pose_t>& Ts, float dist_thres, std::vector<candidate_t>& out, std::false_type) {
+    out.resize(Ts.size());
+    for (size_t k = 0; k < Ts.size(); ++k) be.extract(Ts[k], dist_thres, out[k]);
+}
+
 /* The shuffled copy of a neighbourhood list, kept sparse: position -> scene index for the positions that hold a
  * point with tangent_mask set; every other position holds a point the sampling loop skips whatever its index is
  * (first filter of include/impl/scene.hpp:290) and is simply absent (get() = -1). A swap of the lazy Fisher-Yates
@@ -325,9 +342,11 @@ inline void announce_round(B&, const std::vector<uint32_t>&, std::false_type) {}
 struct sparse_list {
     std::vector<uint32_t> key;
     std::vector<int32_t> val;
+    std::vector<uint64_t> present; /* one bit per position: is it in the table? 24 of 25 lookups end here */
     uint32_t shift = 32, used = 0;
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    void reset(size_t expect) {
+    void reset(size_t expect, size_t positions) {
+        present.assign((positions + 63) / 64 + 1, 0ull);
         uint32_t bits = 10;
         while (((size_t)1 << bits) < 4 * expect + 64) ++bits;
         key.assign((size_t)1 << bits, kEmpty);
@@ -337,6 +356,7 @@ struct sparse_list {
     }
     uint32_t slot_of(uint32_t pos) const { return (pos * 0x9E3779B1u) >> shift; }
     int32_t get(uint32_t pos) const {
+        if (!((present[pos >> 6] >> (pos & 63u)) & 1ull)) return -1;
         const uint32_t mask = (uint32_t)key.size() - 1;
         for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
             if (key[h] == pos) return val[h];
@@ -344,6 +364,12 @@ struct sparse_list {
         }
     }
     void put(uint32_t pos, int32_t v) {
+        if (v < 0) {
+            if (!((present[pos >> 6] >> (pos & 63u)) & 1ull)) return; /* absent stays absent */
+            present[pos >> 6] &= ~(1ull << (pos & 63u));
+        } else {
+            present[pos >> 6] |= 1ull << (pos & 63u);
+        }
         const uint32_t mask = (uint32_t)key.size() - 1;
         for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
             if (key[h] == pos) {
@@ -545,7 +571,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         if (sparse) {
             /* the same shuffle on the sparse copy: the draws depend on the list's LENGTH only (rng() % (n - k)), and
              * a position's content matters only if it is a tangent point; same r, same j at every step as below */
-            shuffled.reset(n_t_pairs);
+            shuffled.reset(n_t_pairs, n_nn);
             for (size_t e = 0; e < n_t_pairs; ++e) shuffled.put(t_pairs[2 * e], (int32_t)t_pairs[2 * e + 1]);
             for (size_t k = 0; k < n_nn; ++k) {
                 if (p.stats) ++p.stats->draws;
@@ -817,14 +843,14 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             batched = detail::device_icp_batch(be, starts, 2.f * p.dist_thres, p.max_icp_iterations, refined,
                                                detail::has_icp_refine_batch<Backend>{});
         }
-        for (size_t k = 0; k < starts.size(); ++k) {
+        if (batched) {
+            TM_TIMED(extract);
+            std::vector<candidate_t> got;
+            detail::extract_all(be, refined, 2.f * p.dist_thres, got, detail::has_extract_batch<Backend>{});
+            for (auto& c : got) cands.push_back(std::move(c));
+        }
+        for (size_t k = 0; k < starts.size() && !batched; ++k) {
             candidate_t c;
-            if (batched) {
-                TM_TIMED(extract);
-                be.extract(refined[k], 2.f * p.dist_thres, c);
-                cands.push_back(std::move(c));
-                continue;
-            }
             {
                 TM_TIMED(extract);
                 be.extract(starts[k], p.dist_thres, c); /* :361-364 */

@@ -999,6 +999,19 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
         gs.search_batch(gm, np.array([[0, gs.n]], np.uint32), diam, DT, 0.5, True, 0.0)
 
 
+def test_extract_batch_equals_single_calls(gpu_small, small_case):
+    """tm_extract_correspondences_batch (finish_find for several poses, one read-back) == one call per pose"""
+    gm, gs = gpu_small["model"], gpu_small["scene"]
+    poses = random_poses_near_truth(small_case, 7, seed=3)
+    got = gs.extract_correspondences_batch(gm, poses, DT)
+    hits = 0
+    for k in range(len(poses)):
+        sc, mc, score = gs.extract_correspondences(gm, poses[k], DT)
+        assert np.array_equal(got[k][0], sc) and np.array_equal(got[k][1], mc) and got[k][2] == score
+        hits += int(len(sc) > 100)
+    assert hits >= 2
+
+
 def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
     gs, os_ = gpu_small["scene"], oracle_small["scene"]
     diam = oracle_small["model"].diameter

@@ -125,6 +125,8 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(BatchResult)]),
     "tm_extract_correspondences": (C.c_int, [vp, vp, f32p, C.c_float, u32p, u32p, C.c_uint32, u32p,
                                              f64p]),
+    "tm_extract_correspondences_batch": (C.c_int, [vp, vp, f32p, C.c_uint32, C.c_float, u32p, u32p, C.c_uint32, u32p,
+                                                   f64p]),
     "tm_icp_accumulate": (C.c_int, [vp, vp, f32p, C.c_float, u32p, C.POINTER(C.c_longlong)]),
     "tm_icp_refine": (C.c_int, [vp, vp, f32p, C.c_float, C.c_uint32, f32p, u32p, u32p]),
     "tm_icp_refine_batch": (C.c_int, [vp, vp, f32p, C.c_uint32, C.c_float, C.c_uint32, f32p, u32p, u32p]),
@@ -909,6 +911,23 @@ class Scene:
         _check(lib().tm_icp_accumulate(self.h, model.h, pT, dist_thres, C.byref(cnt),
                                        sums.ctypes.data_as(C.POINTER(C.c_longlong))))
         return cnt.value, sums
+
+    def extract_correspondences_batch(self, model, poses16, dist_thres):
+        """[(scene_corrs, model_corrs, score)] per pose, one call"""
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        rc = lib().tm_extract_correspondences_batch(self.h, model.h, pP, n, dist_thres, None, None, 0,
+                                                    counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p))
+        _check(rc)
+        stride = max(int(counts.max()), 1)
+        sc = np.zeros((n, stride), np.uint32)
+        mc = np.zeros((n, stride), np.uint32)
+        _check(lib().tm_extract_correspondences_batch(self.h, model.h, pP, n, dist_thres, sc.ctypes.data_as(u32p),
+                                                      mc.ctypes.data_as(u32p), stride, counts.ctypes.data_as(u32p),
+                                                      scores.ctypes.data_as(f64p)))
+        return [(sc[k, :counts[k]].copy(), mc[k, :counts[k]].copy(), float(scores[k])) for k in range(n)]
 
     def extract_correspondences(self, model, pose16, dist_thres):
         T, pT = _f(pose16)

@@ -168,12 +168,20 @@ __global__ __launch_bounds__(256) void k_ball_tangent(const unsigned long long* 
         in = ((mbits >> (t & 63u)) & 1ull) != 0ull;
         rank = wprefix[(size_t)c * mwords + (t >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (t & 63u)) - 1ull));
     }
+    /* one append per workgroup: same-address atomics from every wave serialise (153 us per call with one per wave) */
+    __shared__ uint32_t s_cnt[4], s_base;
     const unsigned long long b = __ballot(in);
-    if (!b) return;
-    uint32_t base = 0;
-    if (lane == (uint32_t)(__ffsll((long long)b) - 1)) base = atomicAdd(cursor, (uint32_t)__popcll(b));
-    base = __shfl(base, __ffsll((long long)b) - 1);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        s_base = total ? atomicAdd(cursor, total) : 0u;
+    }
+    __syncthreads();
     if (in) {
+        uint32_t base = s_base;
+        for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
         const uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         out[3 * (size_t)e] = c;
         out[3 * (size_t)e + 1] = rank;

@@ -1846,21 +1846,16 @@ int tm_score_hypotheses_ball(tm_scene* s, tm_model* m, const float* poses16, uin
     return TM_OK;
 }
 
-int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres,
-                               uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t cap, uint32_t* count,
-                               double* score) {
-    TM_FORWARD(check_pair(s, m));
-    TM_REQUIRE(pose16 && count, TM_ERR_INVALID, "tm_extract_correspondences: null argument");
-    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+/* finish_find for the pose at d_pose, everything left on the device: count -> d_count_fx[0] (as u64), fixed-point
+ * score sum -> d_count_fx[1], correspondences (ascending scene index) -> d_scene_corrs / d_model_corrs. Queued on
+ * the context's stream; no synchronisation. */
+static int extract_on_device(tm_scene* s, tm_model* m, const float* d_pose, float dist_thres,
+                             unsigned long long* d_count_fx, uint32_t* d_scene_corrs, uint32_t* d_model_corrs) {
     tm_ctx* c = s->ctx;
-    TM_HIP_CHECK(hipSetDevice(c->device));
-    TM_FORWARD(s->w_poses.ensure(16));
     TM_FORWARD(s->w_counts.ensure(1));
-    TM_FORWARD(s->w_scores_fx.ensure(1));
     TM_FORWARD(s->w_u32a.ensure(s->n));
-    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, pose16, 64, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, 4, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_scores_fx.p, 0, 8, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_count_fx, 0, 16, c->stream));
     TM_HIP_CHECK(hipMemsetAsync(s->w_u32a.p, 0xFF, (size_t)s->n * 4, c->stream));
     score_args a;
     a.spos = s->spos.p;
@@ -1871,9 +1866,9 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     a.mref = m->ref.p;
     a.vox = m->voxels.p;
     a.active = nullptr;
-    a.poses = s->w_poses.p;
+    a.poses = d_pose;
     a.counts = s->w_counts.p;
-    a.scores_fx = s->w_scores_fx.p;
+    a.scores_fx = d_count_fx + 1;
     a.g = m->grid;
     a.d2max = sq_threshold(dist_thres * m->resolution);
     a.n_hyp = 1;
@@ -1895,7 +1890,6 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     const uint32_t n_blocks = (s->n + 255) / 256, n_waves = n_blocks * 4;
     TM_FORWARD(s->w_u32b.ensure((size_t)n_waves + 1));
     TM_FORWARD(s->w_u32c.ensure((size_t)n_waves + 1));
-    TM_FORWARD(s->w_corr.ensure(2 * (size_t)s->n));
     TM_HIP_CHECK(hipMemsetAsync(s->w_u32b.p + n_waves, 0, 4, c->stream));
     hipLaunchKernelGGL(k_extract_count, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32b.p);
     size_t tmp = 0;
@@ -1905,25 +1899,80 @@ int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16],
     TM_HIP_CHECK(rocprim::exclusive_scan(c->scratch.p, tmp, s->w_u32b.p, s->w_u32c.p, 0u, (size_t)n_waves + 1,
                                          rocprim::plus<uint32_t>(), c->stream));
     hipLaunchKernelGGL(k_extract_scatter, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32c.p,
-                       m->new2orig.p, s->w_corr.p, s->w_corr.p + s->n);
+                       m->new2orig.p, d_scene_corrs, d_model_corrs);
+    /* the count rides with the score sum: one 16-byte read-back per pose */
+    TM_HIP_CHECK(hipMemcpyAsync(d_count_fx, s->w_u32c.p + n_waves, 4, hipMemcpyDeviceToDevice, c->stream));
     TM_HIP_CHECK(hipGetLastError());
-    unsigned long long fx = 0;
-    uint32_t n_corr = 0;
-    TM_HIP_CHECK(hipMemcpyAsync(&fx, s->w_scores_fx.p, 8, hipMemcpyDeviceToHost, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(&n_corr, s->w_counts.p, 4, hipMemcpyDeviceToHost, c->stream));
+    return TM_OK;
+}
+
+/* finish_find (include/impl/scene.hpp:100-106) for n poses in one call: the passes are queued one after the other,
+ * the counts come back in one read-back, the lists in a second one through pinned memory (the reference calls
+ * finish_find once per candidate, :361-364 and at the end of icp_, :401). scene_corrs / model_corrs = n rows of
+ * `stride` entries; counts[k] entries of row k are valid. TM_ERR_CAPACITY (counts valid) if stride is too small. */
+int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
+                                     uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride, uint32_t* counts,
+                                     double* scores) {
+    TM_FORWARD(check_pair(s, m));
+    if (n == 0) return TM_OK;
+    TM_REQUIRE(poses16 && counts, TM_ERR_INVALID, "tm_extract_correspondences_batch: null argument");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    TM_REQUIRE(n <= 4096u, TM_ERR_INVALID, "tm_extract_correspondences_batch: more than 4096 poses");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_FORWARD(s->w_poses.ensure((size_t)n * 16));
+    TM_FORWARD(s->w_scores_fx.ensure((size_t)n * 2));
+    TM_FORWARD(s->w_corr.ensure(2 * (size_t)s->n * n));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t k = 0; k < n; ++k)
+        TM_FORWARD(extract_on_device(s, m, s->w_poses.p + (size_t)k * 16, dist_thres, s->w_scores_fx.p + 2 * (size_t)k,
+                                     s->w_corr.p + 2 * (size_t)s->n * k, s->w_corr.p + 2 * (size_t)s->n * k + s->n));
+    std::vector<unsigned long long> h((size_t)n * 2);
+    TM_HIP_CHECK(hipMemcpyAsync(h.data(), s->w_scores_fx.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    *count = n_corr;
-    if (score) *score = ((double)fx * (1.0 / kFx)) / (double)m->n;
-    if ((scene_corrs || model_corrs) && n_corr) {
-        TM_REQUIRE(cap >= n_corr, TM_ERR_CAPACITY, "correspondence buffers too small");
-        if (scene_corrs)
-            TM_HIP_CHECK(hipMemcpyAsync(scene_corrs, s->w_corr.p, (size_t)n_corr * 4, hipMemcpyDeviceToHost, c->stream));
-        if (model_corrs)
-            TM_HIP_CHECK(hipMemcpyAsync(model_corrs, s->w_corr.p + s->n, (size_t)n_corr * 4, hipMemcpyDeviceToHost,
-                                        c->stream));
-        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    size_t total = 0;
+    uint32_t mx = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        counts[k] = (uint32_t)h[2 * (size_t)k];
+        if (scores) scores[k] = ((double)h[2 * (size_t)k + 1] * (1.0 / kFx)) / (double)m->n;
+        total += counts[k];
+        mx = std::max(mx, counts[k]);
+    }
+    if (!(scene_corrs || model_corrs) || total == 0) return TM_OK;
+    TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
+    const size_t need = total * 8;
+    if (s->h_pinned_bytes < need) {
+        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+        s->h_pinned = nullptr;
+        s->h_pinned_bytes = 0;
+        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
+        s->h_pinned_bytes = need + need / 4;
+    }
+    uint32_t* stage = (uint32_t*)s->h_pinned;
+    size_t off = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (!counts[k]) continue;
+        TM_HIP_CHECK(hipMemcpyAsync(stage + off, s->w_corr.p + 2 * (size_t)s->n * k, (size_t)counts[k] * 4,
+                                    hipMemcpyDeviceToHost, c->stream));
+        TM_HIP_CHECK(hipMemcpyAsync(stage + off + counts[k], s->w_corr.p + 2 * (size_t)s->n * k + s->n, (size_t)counts[k] * 4,
+                                    hipMemcpyDeviceToHost, c->stream));
+        off += 2 * (size_t)counts[k];
+    }
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    off = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (scene_corrs) memcpy(scene_corrs + (size_t)k * stride, stage + off, (size_t)counts[k] * 4);
+        if (model_corrs) memcpy(model_corrs + (size_t)k * stride, stage + off + counts[k], (size_t)counts[k] * 4);
+        off += 2 * (size_t)counts[k];
     }
     return TM_OK;
+}
+
+int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres,
+                               uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t cap, uint32_t* count,
+                               double* score) {
+    TM_REQUIRE(pose16 && count, TM_ERR_INVALID, "tm_extract_correspondences: null argument");
+    return tm_extract_correspondences_batch(s, m, pose16, 1, dist_thres, scene_corrs, model_corrs, cap, count, score);
 }
 
 static void icp_score_args(const tm_scene* s, const tm_model* m, float dist_thres, score_args& a) {
