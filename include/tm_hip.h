@@ -221,6 +221,11 @@ uint32_t tm_scene_size(const tm_scene* scene);
 int tm_scene_radius_subset(tm_scene* scene, uint32_t center_idx, float radius, int32_t* out, uint32_t cap,
                            uint32_t* count);
 
+/* Entries ranks[0..n_ranks) of the list the LAST tm_scene_radius_subset call on this scene described (that call may
+ * have been made with out == NULL to count only): for a caller that needs a few random members of a large
+ * neighbourhood — the traits search's draw of its second and third sample point — and not 100,000 indices. */
+int tm_scene_radius_select(const tm_scene* scene, const uint32_t* ranks, uint32_t n_ranks, int32_t* out);
+
 /* The same for several centres in one call, with the index lists built on the device (membership bits ->
  * per-word prefix counts -> ordered scatter): counts[k] = size of the neighbourhood of centers[k],
  * lists[k * stride + j] its j-th index (ascending). lists may be NULL to get the counts only; stride must
@@ -465,6 +470,11 @@ int tm_scene_probe_projected(tm_scene* scene, int traits_kind, const float* stat
 uint64_t tm_scene_live_count(const tm_scene* scene);
 /* the surfels of a scene as the kernels see them (uvw surfels for a projected scene) and its tangent_mask */
 int tm_scene_download(const tm_scene* scene, float* surfels, int32_t* tangent_mask);
+/* The points of a scene with tangent_mask set — ascending indices and their surfels as the kernels see them (uvw
+ * surfels for a projected scene): all that the host side of a search ever reads of a scene's cloud (first and second
+ * sample points, include/impl/scene.hpp:266-302). A projected scene keeps exactly this on the host (its other points
+ * stay on the device; tm_scene_download fetches them when asked). indices / surfels may be null to get *count. */
+int tm_scene_tangent_points(const tm_scene* scene, uint32_t* indices, float* surfels, uint32_t cap, uint32_t* count);
 
 /* ---- HIP equivalents of the reference's orphaned OpenCL kernels (opencl/icp.cl, cylinder.cl) ----
  * icp_projection (opencl/icp.cl:1-53, with uv_project opencl/cylinder.cl:1-25 and mat44_multiply

@@ -39,8 +39,15 @@ struct projector_search {
     uint32_t max_draws = 20000;      /* sample sets drawn at most (most fall to the cheap rejections) */
     uint32_t max_searches = 32;      /* projectors that get a full search at most */
     uint32_t max_idle_searches = 8;  /* stop after this many searched projectors in a row without a match */
+    uint32_t max_idle_draws = 250;   /* ... or after this many sample sets in a row that led to no new search (rejected,
+                                        or on a surface that has had its search) */
     float radius_tolerance = 0.05f;  /* cylinder: |r_scene - r_model| <= tolerance * r_model */
     bool on_surface_samples = true;  /* sample points of the search: |w| <= the model projector's threshold */
+    bool skip_searched_surfaces = true; /* a sample set lying on a surface that already had its search is passed over:
+                                           that search ran its rounds until nothing more was found there (find_all,
+                                           include/impl/scene.hpp:70-79), and a coincident projector sees the same
+                                           points. "Coincident": all samples within the model projector's threshold of
+                                           the earlier surface and the surfaces' axes within ~3 degrees. */
     uint64_t seed = 13;
     bool verbose = false;
 };

@@ -504,6 +504,11 @@ public:
                                                              uint32_t max_icp_iterations,
                                                              const projector_search& ps = projector_search()) {
         std::vector<int32_t> base_tmask;
+        const auto t_call0 = std::chrono::steady_clock::now();
+        double ms_prepare = 0, ms_draw = 0, ms_probe = 0, ms_project = 0, ms_search = 0;
+        auto since = [](std::chrono::steady_clock::time_point t0) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        };
         ensure_scene(base_tmask);
         const uint32_t n = (uint32_t)cloud_->size();
         model<Point>& um = pm.uvw_model();
@@ -516,25 +521,45 @@ public:
                 free_pts.push_back(i);
         std::mt19937 rng((uint32_t)ps.seed);
         std::vector<int32_t> nb; /* neighbourhood of the first sample */
+        ms_prepare = since(t_call0);
         const uint32_t min_tangent = (uint32_t)(model_match_factor * (float)um.point_count()); /* = min_points, :114 */
         std::vector<projected_match_t<Traits>> results;
+        std::vector<typename Traits::const_handle_t> searched_; /* projectors that had a full search */
+        uint32_t skipped_surfaces_ = 0;
         uint32_t searches = 0, idle = 0;
+        bool mask_dirty = false; /* the device mask was set to the (empty) mask above */
         stats_ = search::stats_t();
-        for (uint32_t draw = 0; draw < ps.max_draws && searches < ps.max_searches && idle < ps.max_idle_searches; ++draw) {
+        uint32_t idle_draws = 0;
+        for (uint32_t draw = 0; draw < ps.max_draws && searches < ps.max_searches && idle < ps.max_idle_searches &&
+                                idle_draws < ps.max_idle_draws; ++draw, ++idle_draws) {
             if (free_pts.size() < (size_t)Traits::sample_count) break;
             /* the first sample anywhere among the unexplained points, the others in its neighbourhood
              * (radius = the model's diameter, the radius_search_inclusive of the search itself, :273): three
              * independent points of a room almost never share a wall, three neighbours often do */
             uint32_t idx[Traits::sample_count];
             bool ok = true;
+            const auto t_d0 = std::chrono::steady_clock::now();
+            struct add_on_exit { /* whatever way this draw ends, its time is booked */
+                double& acc;
+                std::chrono::steady_clock::time_point t0;
+                bool armed = true;
+                ~add_on_exit() {
+                    if (armed) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
+            } draw_timer{ms_draw, t_d0};
             idx[0] = free_pts[rng() % (uint32_t)free_pts.size()];
             if (Traits::sample_count > 1) {
+                /* only the size of the neighbourhood and the entries the draws pick are needed, not the list */
                 uint32_t cnt = 0;
-                nb.resize(n);
-                detail::check(tm_scene_radius_subset(h_, idx[0], um.diameter(), nb.data(), n, &cnt), "tm_scene_radius_subset");
+                detail::check(tm_scene_radius_subset(h_, idx[0], um.diameter(), nullptr, 0, &cnt), "tm_scene_radius_subset");
                 if (cnt < (uint32_t)Traits::sample_count) continue;
+                uint32_t ranks[Traits::sample_count];
+                int32_t picked[Traits::sample_count];
+                for (int k = 1; k < Traits::sample_count; ++k) ranks[k - 1] = rng() % cnt;
+                detail::check(tm_scene_radius_select(h_, ranks, (uint32_t)(Traits::sample_count - 1), picked),
+                              "tm_scene_radius_select");
                 for (int k = 1; k < Traits::sample_count; ++k) {
-                    idx[k] = (uint32_t)nb[rng() % cnt];
+                    idx[k] = (uint32_t)picked[k - 1];
                     for (int q = 0; q < k; ++q) ok = ok && idx[q] != idx[k];
                     ok = ok && !mask[idx[k]] && cloud_->points[idx[k]].getNormalVector3fMap().allFinite();
                 }
@@ -549,9 +574,39 @@ public:
             if (Traits::kind == TM_TRAITS_CYLINDER &&
                 !(std::fabs(handle->radius - pm.handle()->radius) <= ps.radius_tolerance * pm.handle()->radius))
                 continue;
+            if (ps.skip_searched_surfaces) { /* a surface that has had its search already? */
+                const bool use_band = pm.handle()->threshold > 0.f;
+                const float band = Traits::kind == TM_TRAITS_CYLINDER && pm.handle()->radius > 0.f
+                                       ? pm.handle()->threshold / pm.handle()->radius
+                                       : pm.handle()->threshold;
+                bool seen = false;
+                for (const auto& old : searched_) {
+                    float dotp = 0.f; /* third rows of g2l: the plane's normal / the cylinder's axis */
+                    for (int k = 0; k < 3; ++k) dotp += old->g2l(2, k) * handle->g2l(2, k);
+                    if (!(std::fabs(dotp) > 0.9986f)) continue;
+                    bool on = use_band;
+                    for (int k = 0; k < Traits::sample_count && on; ++k) {
+                        auto uvw = Traits::project(old, cloud_->points[idx[k]].getVector3fMap());
+                        on = uvw && std::fabs((*uvw)[2]) <= band;
+                    }
+                    if (on) {
+                        seen = true;
+                        break;
+                    }
+                }
+                if (seen) {
+                    ++skipped_surfaces_;
+                    continue;
+                }
+            }
             tm_scene* proj = nullptr;
+            ms_draw += since(t_d0);
+            draw_timer.armed = false;
             const auto t_p0 = std::chrono::steady_clock::now();
-            detail::check(tm_scene_set_mask(h_, mask.data()), "tm_scene_set_mask");
+            if (mask_dirty) { /* mask_ changes only when a match was accepted */
+                detail::check(tm_scene_set_mask(h_, mask.data()), "tm_scene_set_mask");
+                mask_dirty = false;
+            }
             {   /* the two rejections below, counted on the device before anything is built or downloaded */
                 const float band = !(ps.on_surface_samples && pm.handle()->threshold > 0.f) ? -1.f
                                    : Traits::kind == TM_TRAITS_CYLINDER && pm.handle()->radius > 0.f
@@ -560,37 +615,59 @@ public:
                 uint64_t live = 0;
                 uint32_t n_tan = 0;
                 detail::check(tm_scene_probe_projected(h_, Traits::kind, st, band, &live, &n_tan), "tm_scene_probe_projected");
+                ms_probe += since(t_p0);
                 if ((float)live < model_match_factor * (float)n_model || n_tan < min_tangent) continue;
             }
+            const auto t_c0 = std::chrono::steady_clock::now();
+            struct add_project {
+                double& acc;
+                std::chrono::steady_clock::time_point t0;
+                bool armed = true;
+                ~add_project() {
+                    if (armed) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
+            } project_timer{ms_project, t_c0};
             detail::check(tm_scene_create_projected(h_, Traits::kind, st, &proj), "tm_scene_create_projected");
             struct guard {
                 tm_scene* s;
                 ~guard() { tm_scene_destroy(s); }
             } g{proj};
             if ((float)tm_scene_live_count(proj) < model_match_factor * (float)n_model) continue;
-            /* the uvw scene as the kernels see it */
-            auto uvw = cloud_t::empty();
-            uvw->points.resize(n);
-            std::vector<int32_t> tmask(n);
-            detail::check(tm_scene_download(proj, uvw->points[0].raw(), tmask.data()), "tm_scene_download");
-            if (ps.on_surface_samples && pm.handle()->threshold > 0.f) {
+            /* What the host side of the search reads of the uvw scene: its tangent points (first and second samples,
+             * include/impl/scene.hpp:266-302) — the projected scene keeps the other points on the device. */
+            std::vector<int32_t> tmask(n, 0);
+            {
+                uint32_t cnt = 0;
+                detail::check(tm_scene_tangent_points(proj, nullptr, nullptr, 0, &cnt), "tm_scene_tangent_points");
+                tan_idx_.resize(cnt);
+                tan_rows_.resize(12 * (size_t)cnt);
+                if (cnt)
+                    detail::check(tm_scene_tangent_points(proj, tan_idx_.data(), tan_rows_.data(), cnt, &cnt),
+                                  "tm_scene_tangent_points");
+                const bool use_band = ps.on_surface_samples && pm.handle()->threshold > 0.f;
                 const float band = Traits::kind == TM_TRAITS_CYLINDER && pm.handle()->radius > 0.f
                                        ? pm.handle()->threshold / pm.handle()->radius /* w = height / radius */
                                        : pm.handle()->threshold;
-                for (uint32_t i = 0; i < n; ++i)
-                    if (tmask[i] && !(std::fabs(uvw->points[i].z) <= band)) tmask[i] = 0;
-            }
-            {   /* a surface with fewer tangent points than the arbitration demands as inliers cannot hold a match */
-                uint32_t n_tan = 0;
-                for (uint32_t i = 0; i < n; ++i) n_tan += (tmask[i] && !mask[i]) ? 1u : 0u;
+                uint32_t n_tan = 0; /* a surface with fewer tangent points than the arbitration demands as inliers
+                                       cannot hold a match */
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t i = tan_idx_[k];
+                    if (use_band && !(std::fabs(tan_rows_[12 * (size_t)k + 2]) <= band)) continue;
+                    tmask[i] = 1;
+                    n_tan += mask[i] ? 0u : 1u;
+                }
                 if (n_tan < min_tangent) continue;
             }
             ++searches;
+            idle_draws = 0;
+            searched_.push_back(handle);
+            ms_project += since(t_c0);
+            project_timer.armed = false;
             const auto t_p1 = std::chrono::steady_clock::now();
             detail::hip_backend<Point> be;
             be.s = proj;
             be.m = um.handle();
-            be.scloud = uvw.get();
+            be.scloud = cloud_.get(); /* the size is all the search takes from it; the uvw points stay on the device */
             be.mcloud = um.cloud().get();
             be.n_t = um.point_count();
             be.diam = um.diameter();
@@ -605,6 +682,7 @@ public:
                 search::single_rank one;
                 found = search::find_all(be, tmask, be.p, one, &mask);
             }
+            ms_search += since(t_p1);
             if (ps.verbose) {
                 const auto t_p2 = std::chrono::steady_clock::now();
                 fprintf(stderr, "[projected search] draw %u: projector searched (%llu points project), %zu match(es); "
@@ -627,6 +705,7 @@ public:
                 r.match.transform = r.match.transform.inverse(); /* uvw model -> uvw scene, as :92 */
                 r.match.signed_score = c.signed_score;
                 for (uint32_t i : c.scene_corrs) mask[i] = 1;
+                mask_dirty = true;
                 r.match.scene_corrs = std::move(c.scene_corrs);
                 r.match.model_corrs.reserve(c.model_corrs.size());
                 for (uint32_t k : c.model_corrs) r.match.model_corrs.push_back(pm.original_index(k));
@@ -639,6 +718,10 @@ public:
             free_pts.resize(w);
         }
         last_projector_searches_ = searches;
+        if (ps.verbose)
+            fprintf(stderr, "[projected search] %.1f ms in all: prepare the scene %.1f, draws + init_from_samples %.1f, probes %.1f, "
+                            "project + prepare %.1f, searches %.1f (%u searched, %u sample sets on surfaces already searched)\n",
+                    since(t_call0), ms_prepare, ms_draw, ms_probe, ms_project, ms_search, searches, skipped_surfaces_);
         return results;
     }
     /* projectors that got a full search in the last projected find_all_parallel */
@@ -716,6 +799,8 @@ protected:
     std::shared_ptr<detail::context_holder> ctx_;
     tm_scene* h_ = nullptr;
     uint32_t last_projector_searches_ = 0;
+    std::vector<uint32_t> tan_idx_; /* tangent points of the current projected scene */
+    std::vector<float> tan_rows_;
     std::vector<uint8_t> curvature_ok_;
     uint32_t workers_ = 7;
     uint32_t curvature_k_ = 30;

@@ -1031,6 +1031,13 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
     assert sum(len(t) for t in tangent) >= 0
     counts, tangent = gs.radius_tangent_lists(centers, diam)
     assert sum(len(t) for t in tangent) > 100
+    # a few entries of a neighbourhood without its list (the traits search's draws)
+    full = os_.radius_subset(int(centers[0]), diam)
+    ranks = np.array([0, 1, len(full) // 2, len(full) - 1, 7, 7], np.uint32)
+    n, picked = gs.radius_count_and_select(int(centers[0]), diam, ranks)
+    assert n == len(full) and np.array_equal(picked, full[ranks])
+    with pytest.raises(capi.TmError):
+        gs.radius_count_and_select(int(centers[0]), diam, np.array([len(full)], np.uint32))
 
 
 def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case):

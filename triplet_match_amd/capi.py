@@ -100,7 +100,9 @@ SIGNATURES = {
     "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
     "tm_scene_probe_projected": (C.c_int, [vp, C.c_int, f32p, C.c_float, u64p, u32p]),
     "tm_scene_download": (C.c_int, [vp, f32p, i32p]),
+    "tm_scene_tangent_points": (C.c_int, [vp, u32p, f32p, C.c_uint32, u32p]),
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
+    "tm_scene_radius_select": (C.c_int, [vp, u32p, C.c_uint32, i32p]),
     "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_scene_radius_tangent_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, u32p, u32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
@@ -728,6 +730,17 @@ class Scene:
         _check(lib().tm_scene_download(self.h, s.ctypes.data_as(f32p), tm.ctypes.data_as(i32p)))
         return s, tm
 
+    def tangent_points(self):
+        """(ascending indices, surfels) of the points with tangent_mask set, as the kernels see them"""
+        n = C.c_uint32(0)
+        _check(lib().tm_scene_tangent_points(self.h, None, None, 0, C.byref(n)))
+        idx = np.zeros(n.value, np.uint32)
+        rows = np.zeros((n.value, 12), np.float32)
+        if n.value:
+            _check(lib().tm_scene_tangent_points(self.h, idx.ctypes.data_as(u32p), rows.ctypes.data_as(f32p), n.value,
+                                                 C.byref(n)))
+        return idx, rows
+
     def set_mask(self, mask):
         if mask is None:
             _check(lib().tm_scene_set_mask(self.h, None))
@@ -742,6 +755,16 @@ class Scene:
         _check(lib().tm_scene_radius_subset(self.h, center_idx, radius, out.ctypes.data_as(i32p), out.size,
                                             C.byref(cnt)))
         return out
+
+    def radius_count_and_select(self, center_idx, radius, ranks):
+        """size of the neighbourhood (no list built) and its entries at the given ranks"""
+        n = C.c_uint32(0)
+        _check(lib().tm_scene_radius_subset(self.h, center_idx, radius, None, 0, C.byref(n)))
+        r, pr = _u(ranks)
+        out = np.zeros(len(r), np.int32)
+        if len(r):
+            _check(lib().tm_scene_radius_select(self.h, pr, len(r), out.ctypes.data_as(i32p)))
+        return n.value, out
 
     def radius_lists(self, centers, radius):
         cn, pc = _u(centers)

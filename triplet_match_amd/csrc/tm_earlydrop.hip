@@ -189,10 +189,6 @@ __global__ __launch_bounds__(256) void k_ball_tangent(const unsigned long long* 
     }
 }
 
-struct is_nonzero_i32 {
-    __host__ __device__ bool operator()(int32_t v) const { return v != 0; }
-};
-
 /* exclusive prefix of the word popcounts of one slot (one 1024-thread block per slot) and the total */
 __global__ __launch_bounds__(1024) void k_ball_prefix(const unsigned long long* __restrict__ member, uint32_t mwords,
                                                       uint32_t* __restrict__ wprefix, uint32_t* __restrict__ S_of_slot) {
@@ -1789,20 +1785,7 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
         TM_REQUIRE(centers[k] < s->n, TM_ERR_INVALID, "tm_scene_radius_tangent_lists: centre index out of range");
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
-    if (!s->tangent_idx_ready) { /* ascending indices of the points with tangent_mask set: once per scene */
-        TM_FORWARD(s->d_tangent_idx.ensure((size_t)s->n + 1));
-        size_t tmp = 0;
-        rocprim::counting_iterator<uint32_t> idx(0u);
-        auto flags = rocprim::make_transform_iterator(s->d_tmask.p, is_nonzero_i32());
-        TM_HIP_CHECK(rocprim::select(nullptr, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n, (size_t)s->n,
-                                     c->stream));
-        TM_FORWARD(scratch_ensure(c, tmp));
-        TM_HIP_CHECK(rocprim::select(c->scratch.p, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n,
-                                     (size_t)s->n, c->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(&s->n_tangent, s->d_tangent_idx.p + s->n, 4, hipMemcpyDeviceToHost, c->stream));
-        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-        s->tangent_idx_ready = true;
-    }
+    TM_FORWARD(scene_tangent_index(s));
     const uint32_t mwords = (s->n + 63) / 64;
     TM_FORWARD(s->ed_centres.ensure(n_centers));
     TM_FORWARD(s->ed_member.ensure((size_t)n_centers * mwords));

@@ -207,6 +207,13 @@ struct tm_scene {
     uint32_t n = 0;
     std::vector<float> h_cloud;
     std::vector<int32_t> h_tmask, h_mask;
+    /* A projected scene (tm_scene_create_projected) keeps its host mirror SPARSE: the host side of the search only
+     * ever reads the surfels of tangent points (sample filters), so only those come back from the device — 1.7 MB
+     * instead of 48 MB per projector at 1M points. h_tan_idx ascending, h_tan_rows 12 floats each; h_cloud stays
+     * empty. tm_scene_download fetches the full cloud from the device on demand. */
+    bool h_sparse = false;
+    std::vector<uint32_t> h_tan_idx;
+    std::vector<float> h_tan_rows;
     /* device copies of the inputs (original order) and the Morton order derived from them */
     tmx::dbuf<float> d_cloud;         /* n x 12 floats: the surfels as handed over */
     tmx::dbuf<int32_t> d_tmask, d_mask;
@@ -275,6 +282,10 @@ bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
 int scene_upload(tm_scene* s);
 int scene_build(tm_scene* s, bool resort);
+/* ascending indices of the points with tangent_mask set (s->d_tangent_idx, s->n_tangent), built once per scene */
+int scene_tangent_index(tm_scene* s);
+/* host mirror row of point i (12 floats), or null for a point a sparse mirror does not hold */
+const float* scene_row(const tm_scene* s, uint32_t i);
 }
 
 #endif /* TM_INTERNAL_H_ */

@@ -1663,8 +1663,40 @@ uint64_t tm_scene_live_count(const tm_scene* s) { return s ? s->n_live : 0; }
 
 int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) {
     TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
-    if (surfels) memcpy(surfels, s->h_cloud.data(), (size_t)s->n * 48);
+    if (s->h_sparse && surfels) { /* a projected scene keeps only its tangent points on the host: fetch the rest */
+        TM_HIP_CHECK(hipSetDevice(s->ctx->device));
+        TM_HIP_CHECK(hipMemcpyAsync(surfels, s->d_cloud.p, (size_t)s->n * 48, hipMemcpyDeviceToHost, s->ctx->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
+    } else if (surfels) {
+        memcpy(surfels, s->h_cloud.data(), (size_t)s->n * 48);
+    }
     if (tangent_mask) memcpy(tangent_mask, s->h_tmask.data(), (size_t)s->n * 4);
+    return TM_OK;
+}
+
+/* the points with tangent_mask set, ascending, with their surfels as the kernels see them (uvw surfels for a
+ * projected scene): all the host side of a search reads of a scene's cloud */
+int tm_scene_tangent_points(const tm_scene* s, uint32_t* indices, float* surfels, uint32_t cap, uint32_t* count) {
+    TM_REQUIRE(s && count, TM_ERR_INVALID, "tm_scene_tangent_points: null argument");
+    if (s->h_sparse) {
+        *count = (uint32_t)s->h_tan_idx.size();
+        if (!indices && !surfels) return TM_OK;
+        TM_REQUIRE(cap >= *count, TM_ERR_CAPACITY, "tm_scene_tangent_points: buffers too small");
+        if (indices) memcpy(indices, s->h_tan_idx.data(), (size_t)*count * 4);
+        if (surfels) memcpy(surfels, s->h_tan_rows.data(), (size_t)*count * 48);
+        return TM_OK;
+    }
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < s->n; ++i) {
+        if (!s->h_tmask[i]) continue;
+        if ((indices || surfels) && k < cap) {
+            if (indices) indices[k] = i;
+            if (surfels) memcpy(surfels + 12 * (size_t)k, s->h_cloud.data() + 12 * (size_t)i, 48);
+        }
+        ++k;
+    }
+    *count = k;
+    TM_REQUIRE(!(indices || surfels) || cap >= k, TM_ERR_CAPACITY, "tm_scene_tangent_points: buffers too small");
     return TM_OK;
 }
 
@@ -1672,8 +1704,9 @@ int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, ui
                             float maxf) {
     if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
     if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
-    const float* a = s->h_cloud.data() + (size_t)i * 12;
-    const float* b = s->h_cloud.data() + (size_t)j * 12;
+    const float* a = scene_row(s, i);
+    const float* b = scene_row(s, j);
+    if (!a || !b) return 0; /* a sparse mirror holds the tangent points: i is a first sample, hence one of them */
     f3 p1 = make3(a[0], a[1], a[2]), p2 = make3(b[0], b[1], b[2]);
     f3 t1 = make3(a[9], a[10], a[11]), t2 = make3(b[9], b[10], b[11]);
     float lower = m->diameter * minf, upper = m->diameter * maxf;
@@ -1775,7 +1808,8 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
             const uint32_t i = (uint32_t)subset[k];
             if (act[i]) continue;
             act[i] = 1;
-            if (!s->h_mask[i] && fin3(s->h_cloud.data() + (size_t)i * 12)) ++n_active;
+            const float* row = scene_row(s, i); /* (a statistics figure; a sparse mirror counts unknown points as live) */
+            if (!s->h_mask[i] && (!row || fin3(row))) ++n_active;
         }
         int rc0 = s->w_active.ensure(s->n);
         hipError_t e = rc0 ? hipErrorOutOfMemory

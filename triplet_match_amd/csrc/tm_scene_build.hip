@@ -32,6 +32,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -453,6 +454,11 @@ extern "C" int tm_scene_radius_subset(tm_scene* s, uint32_t center_idx, float ra
                                 c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     uint32_t k = 0;
+    if (!out) { /* count only: the list stays described by the membership words (tm_scene_radius_select) */
+        for (uint32_t w = 0; w < n_words; ++w) k += (uint32_t)__builtin_popcountll(s->h_words[w]);
+        *count = k;
+        return TM_OK;
+    }
     for (uint32_t w = 0; w < n_words; ++w) {
         unsigned long long b = s->h_words[w];
         while (b) {
@@ -464,4 +470,59 @@ extern "C" int tm_scene_radius_subset(tm_scene* s, uint32_t center_idx, float ra
     }
     *count = k;
     return TM_OK;
+}
+
+/* entries ranks[0..n) (ascending order not required) of the list the LAST tm_scene_radius_subset call on this scene
+ * described — for a caller that needs a few members of a large neighbourhood and not the list */
+extern "C" int tm_scene_radius_select(const tm_scene* s, const uint32_t* ranks, uint32_t n_ranks, int32_t* out) {
+    TM_REQUIRE(s && (ranks || n_ranks == 0) && (out || n_ranks == 0), TM_ERR_INVALID, "tm_scene_radius_select: null argument");
+    TM_REQUIRE(!s->h_words.empty(), TM_ERR_NOT_INITIALIZED, "tm_scene_radius_select: no tm_scene_radius_subset call before");
+    for (uint32_t q = 0; q < n_ranks; ++q) {
+        uint32_t left = ranks[q];
+        out[q] = -1;
+        for (size_t w = 0; w < s->h_words.size(); ++w) {
+            unsigned long long b = s->h_words[w];
+            const uint32_t pc = (uint32_t)__builtin_popcountll(b);
+            if (left >= pc) {
+                left -= pc;
+                continue;
+            }
+            while (left--) b &= b - 1; /* drop the lower set bits */
+            out[q] = (int32_t)(w * 64u + (uint32_t)__builtin_ctzll(b));
+            break;
+        }
+        TM_REQUIRE(out[q] >= 0, TM_ERR_INVALID, "tm_scene_radius_select: rank beyond the neighbourhood");
+    }
+    return TM_OK;
+}
+
+namespace tmx {
+struct tmask_set {
+    __host__ __device__ bool operator()(int32_t v) const { return v != 0; }
+};
+}  // namespace tmx
+
+int tmx::scene_tangent_index(tm_scene* s) {
+    if (s->tangent_idx_ready) return TM_OK;
+    tm_ctx* c = s->ctx;
+    TM_FORWARD(s->d_tangent_idx.ensure((size_t)s->n + 1));
+    size_t tmp = 0;
+    rocprim::counting_iterator<uint32_t> idx(0u);
+    auto flags = rocprim::make_transform_iterator(s->d_tmask.p, tmask_set());
+    TM_HIP_CHECK(rocprim::select(nullptr, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n, (size_t)s->n,
+                                 c->stream));
+    TM_FORWARD(scratch_ensure(c, tmp));
+    TM_HIP_CHECK(rocprim::select(c->scratch.p, tmp, idx, flags, s->d_tangent_idx.p, s->d_tangent_idx.p + s->n, (size_t)s->n,
+                                 c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(&s->n_tangent, s->d_tangent_idx.p + s->n, 4, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    s->tangent_idx_ready = true;
+    return TM_OK;
+}
+
+const float* tmx::scene_row(const tm_scene* s, uint32_t i) {
+    if (!s->h_sparse) return s->h_cloud.data() + (size_t)i * 12;
+    auto it = std::lower_bound(s->h_tan_idx.begin(), s->h_tan_idx.end(), i);
+    if (it == s->h_tan_idx.end() || *it != i) return nullptr;
+    return s->h_tan_rows.data() + 12 * (size_t)(it - s->h_tan_idx.begin());
 }
