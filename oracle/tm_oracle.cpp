@@ -167,6 +167,84 @@ void tmo_feature(const float* s0, const float* s1, float f[4]) {
     f[3] = f[0];
 }
 
+/* The one place where the restatement (and the HIP kernels) knowingly compute something else than the reference's
+ * BINARY: the reference calls glibc's atan2f (include/impl/feature.hpp:7), we call tmo_atan2f (<= 1.1 ulp apart).
+ * This census says how often that changes a result: over the ordered pairs (i, j) of `subset` that pass the model's
+ * pair filters (include/impl/model.hpp:104-112; ij == NULL), or over an explicit pair list, the two descriptor angles
+ * are formed with both functions and binned with angle_step (src/discretize.cpp:26-30). Returns the number of pairs
+ * whose (k1, k2) bins differ; *n_pairs = pairs looked at, *n_bits = pairs whose angle bits differ at all, *max_abs =
+ * largest |difference| of an angle; up to cap differing pairs are written to differing_ij. Test infrastructure. */
+uint64_t tmo_atan2_census(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset, const uint32_t* ij,
+                          uint64_t n_ij, float lower_bound, float upper_bound, float angle_step, uint32_t* differing_ij,
+                          uint32_t cap, uint64_t* n_pairs, uint64_t* n_bits, float* max_abs) {
+    uint64_t looked = 0, bins = 0, bits = 0;
+    float worst = 0.f;
+    auto one = [&](uint32_t i, uint32_t j) {
+        const float* s0 = surfels + (size_t)i * 12;
+        const float* s1 = surfels + (size_t)j * 12;
+        v3 p0 = s_pos(s0), p1 = s_pos(s1), t0 = s_tgt(s0), t1 = s_tgt(s1);
+        v3 d0 = sub(p1, p0);
+        const float y1 = norm(cross(d0, t0)), x1 = fabsf(dot(d0, t0)), y2 = norm(cross(d0, t1)), x2 = fabsf(dot(d0, t1));
+        const float a1 = tmo_atan2f(y1, x1), a2 = tmo_atan2f(y2, x2);
+        const float b1 = atan2f(y1, x1), b2 = atan2f(y2, x2); /* glibc */
+        ++looked;
+        if (memcmp(&a1, &b1, 4) || memcmp(&a2, &b2, 4)) ++bits;
+        worst = std::max(worst, std::max(fabsf(a1 - b1), fabsf(a2 - b2)));
+        if (tmo_discretize_step(a1, angle_step) != tmo_discretize_step(b1, angle_step) ||
+            tmo_discretize_step(a2, angle_step) != tmo_discretize_step(b2, angle_step)) {
+            if (differing_ij && bins < cap) {
+                differing_ij[2 * bins] = i;
+                differing_ij[2 * bins + 1] = j;
+            }
+            ++bins;
+        }
+    };
+    if (ij) {
+        for (uint64_t k = 0; k < n_ij; ++k)
+            if (ij[2 * k] < n && ij[2 * k + 1] < n) one(ij[2 * k], ij[2 * k + 1]);
+    } else {
+        for (uint32_t a = 0; a < n_subset; ++a)
+            for (uint32_t b = 0; b < n_subset; ++b) {
+                const uint32_t i = subset[a], j = subset[b];
+                if (i == j) continue;
+                const float* si = surfels + (size_t)i * 12;
+                const float* sj = surfels + (size_t)j * 12;
+                v3 d1 = sub(s_pos(sj), s_pos(si));
+                const float dist1 = norm(d1);
+                d1 = divs(d1, dist1);
+                if (dist1 < lower_bound || dist1 > upper_bound) continue;
+                if (1.f - fabsf(dot(d1, s_tgt(si))) < 0.01f) continue;
+                one(i, j);
+            }
+    }
+    if (n_pairs) *n_pairs = looked;
+    if (n_bits) *n_bits = bits;
+    if (max_abs) *max_abs = worst;
+    return bins;
+}
+
+/* the early-drop bound (include/impl/scene.hpp:493-498) as restated against its literal transcription over a grid
+ * of (tried, |subset|, corrs): returns the number of points where the two differ (first few written to bad3) */
+uint64_t tmo_early_drop_compare(uint32_t subset_max, uint32_t step_subset, uint32_t step_tried, uint32_t step_corrs,
+                                uint64_t* n_points, uint32_t* bad3, uint32_t cap) {
+    uint64_t looked = 0, bad = 0;
+    for (uint32_t S = 1; S <= subset_max; S += step_subset)
+        for (uint32_t tried = 1; tried <= S; tried += step_tried)
+            for (uint32_t corrs = 0; corrs <= tried; corrs += step_corrs) {
+                ++looked;
+                if (tmo_early_drop_upper(tried, S, corrs) != tmo_early_drop_upper_literal(tried, S, corrs)) {
+                    if (bad3 && bad < cap) {
+                        bad3[3 * bad] = tried;
+                        bad3[3 * bad + 1] = S;
+                        bad3[3 * bad + 2] = corrs;
+                    }
+                    ++bad;
+                }
+            }
+    if (n_points) *n_points = looked;
+    return bad;
+}
+
 /* a3: ref: include/impl/feature.hpp:38-46. distance_step_count is a float passed to a uint32_t
  * parameter (implicit truncation); dim 3 is quantised with the dim-0 bounds (:44). */
 void tmo_discretize_feature(const float f[4], const float bmin[4], const float bmax[4],

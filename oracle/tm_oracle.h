@@ -50,6 +50,15 @@ uint32_t tmo_early_drop_upper(uint32_t tried, uint32_t subset_size, uint32_t cor
 uint32_t tmo_early_drop_upper_literal(uint32_t tried, uint32_t subset_size, uint32_t corrs);
 void     tmo_early_drop_checkpoints(uint32_t subset_size, uint32_t tests[18]);
 
+/* how many angle bins change when glibc's atan2f (the reference's call, feature.hpp:7) replaces tmo_atan2f: over the
+ * model's filtered subset pairs (ij == NULL) or an explicit pair list; see tm_oracle.cpp */
+uint64_t tmo_atan2_census(const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset, const uint32_t* ij,
+                          uint64_t n_ij, float lower_bound, float upper_bound, float angle_step, uint32_t* differing_ij,
+                          uint32_t cap, uint64_t* n_pairs, uint64_t* n_bits, float* max_abs);
+/* restated early-drop bound against the literal transcription over a grid; returns the number of differences */
+uint64_t tmo_early_drop_compare(uint32_t subset_max, uint32_t step_subset, uint32_t step_tried, uint32_t step_corrs,
+                                uint64_t* n_points, uint32_t* bad3, uint32_t cap);
+
 /* cloud->resolution() (pointcloud.hpp:66-82): exhaustive 2-NN + f32 running mean in point order */
 float    tmo_cloud_resolution(const float* surfels, uint32_t n, float* nn_dist, int threads);
 

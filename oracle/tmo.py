@@ -60,6 +60,12 @@ def lib():
         L.tmo_early_drop_upper_literal.restype = C.c_uint32
         L.tmo_early_drop_upper_literal.argtypes = [C.c_uint32] * 3
         L.tmo_early_drop_checkpoints.argtypes = [C.c_uint32, u32p]
+        L.tmo_atan2_census.restype = C.c_uint64
+        L.tmo_atan2_census.argtypes = [f32p, C.c_uint32, u32p, C.c_uint32, u32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                       u32p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]
+        L.tmo_early_drop_compare.restype = C.c_uint64
+        L.tmo_early_drop_compare.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), u32p,
+                                             C.c_uint32]
         L.tmo_cloud_resolution.restype = C.c_float
         L.tmo_cloud_resolution.argtypes = [f32p, C.c_uint32, f32p, C.c_int]
         L.tmo_cloud_curvature.argtypes = [f32p, C.c_uint32, C.c_uint32, f32p, C.c_int]
@@ -170,6 +176,36 @@ def cloud_curvature(surfels, k=30, threads=8):
     out = np.zeros((s.shape[0], 5), np.float32)
     lib().tmo_cloud_curvature(p, s.shape[0], k, out.ctypes.data_as(f32p), threads)
     return out
+
+
+def atan2_census(surfels, angle_step, subset=None, lower=0.0, upper=0.0, ij=None, cap=4096):
+    """bins that change with glibc's atan2f in place of the project's: dict(pairs, bins_differ, bits_differ,
+    max_abs_diff, differing_ij)"""
+    s, p = _f(np.asarray(surfels).reshape(-1, 12))
+    diff = np.zeros((cap, 2), np.uint32)
+    n_pairs, n_bits = C.c_uint64(0), C.c_uint64(0)
+    worst = np.zeros(1, np.float32)
+    if ij is None:
+        sub, sp = _u(subset)
+        nb = lib().tmo_atan2_census(p, s.shape[0], sp, len(sub), None, 0, lower, upper, angle_step,
+                                    diff.ctypes.data_as(u32p), cap, C.byref(n_pairs), C.byref(n_bits),
+                                    worst.ctypes.data_as(f32p))
+    else:
+        pairs, pp = _u(np.asarray(ij).reshape(-1, 2))
+        nb = lib().tmo_atan2_census(p, s.shape[0], None, 0, pp, pairs.shape[0], 0.0, 0.0, angle_step,
+                                    diff.ctypes.data_as(u32p), cap, C.byref(n_pairs), C.byref(n_bits),
+                                    worst.ctypes.data_as(f32p))
+    return dict(pairs=int(n_pairs.value), bins_differ=int(nb), bits_differ=int(n_bits.value),
+                max_abs_diff=float(worst[0]), differing_ij=diff[:min(nb, cap)].copy())
+
+
+def early_drop_compare(subset_max, step_subset, step_tried, step_corrs):
+    """(points compared, points where the restated bound differs from the literal transcription, first few)"""
+    n = C.c_uint64(0)
+    bad = np.zeros((16, 3), np.uint32)
+    k = lib().tmo_early_drop_compare(subset_max, step_subset, step_tried, step_corrs, C.byref(n),
+                                     bad.ctypes.data_as(u32p), 16)
+    return int(n.value), int(k), bad[:min(k, 16)]
 
 
 def cloud_knn(surfels, query, k, subset=None):

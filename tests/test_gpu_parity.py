@@ -1161,3 +1161,20 @@ def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case):
     tiny = capi.Cloud(gpu_ctx, cloud[:5])
     idx, d2, cnt = tiny.knn(cloud[:2, 0:3], 9)
     assert (cnt == 5).all() and (idx[:, 5:] == -1).all() and np.isinf(d2[:, 5:]).all()
+
+
+def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx):
+    """tm_cloud_curvature / tm_cloud_resolution (kd-tree kNN kernel, own Jacobi) against the float64 scipy cKDTree +
+    numpy.linalg.eigh vectors of tests/golden/curvature_20k.npz — an answer that passes through none of our code"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "curvature_20k.npz"))
+    cloud, _ = synth.synth_model(20000, seed=4)
+    c = gpu_ctx.cloud_curvature(cloud, int(g["k"]))
+    assert np.abs(c[:, 3] - g["pc_min"]).max() < 1e-6 and np.abs(c[:, 4] - g["pc_max"]).max() < 1e-6
+    res, nn1 = gpu_ctx.cloud_resolution(cloud)
+    assert (np.abs(nn1 - g["nn1"]) <= 1e-6 * g["nn1"]).all()
+    assert abs(res - float(np.mean(g["nn1"].astype(np.float64)))) < 1e-5 * res
+    # the neighbour accessor ends at the same 30th distance as scipy's tree
+    gc = capi.Cloud(gpu_ctx, cloud)
+    idx, d2, cnt = gc.knn(cloud[:2000, 0:3], int(g["k"]))
+    assert (np.abs(d2[:, -1] - g["kth_d2"][:2000]) <= 2e-6 * g["kth_d2"][:2000] + 1e-12).all()

@@ -244,3 +244,77 @@ def test_traits_roundtrip_and_kats():
     assert tmo.traits_project(tmo.PLANE, st, [0.3, 0.4, 0.1]) is not None
     assert tmo.traits_project(tmo.PLANE, st, [0.3, 0.4, 0.3]) is None
     assert abs(tmo.traits_intrinsic_distance(tmo.PLANE2, st, [0, 0, 0], [3, 4, 9]) - 5) < 1e-6
+
+
+# ---- independent pins (vectors / counts that do not come from our own arithmetic) ----
+def _golden(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+def test_curvature_and_resolution_against_scipy_and_numpy():
+    """cloud->curvature(30, i) and cloud->resolution() of the oracle (own exhaustive kNN, f32 running mean of the
+    projected normals, own Jacobi iteration) against tests/golden/curvature_20k.npz = scipy cKDTree + numpy.linalg.eigh
+    in float64 (make_curvature_golden.py): same neighbour sets up to ties (equal 30th-neighbour distances), principal
+    curvatures to 1e-6, nearest-neighbour distances to 1e-6 relative. The reference's mask `pc_min / pc_max < 0.2`
+    then differs only where the ratio sits on the threshold itself."""
+    import hashlib
+    from triplet_match_amd import synth
+    g = np.load(_golden("curvature_20k.npz"))
+    cloud, _ = synth.synth_model(20000, seed=4)
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(cloud).tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha, g["cloud_sha256"]), "the generator no longer makes the cloud the vectors were taken on"
+    c = tmo.cloud_curvature(cloud, int(g["k"]), threads=8)
+    assert np.abs(c[:, 3] - g["pc_min"]).max() < 1e-6 and np.abs(c[:, 4] - g["pc_max"]).max() < 1e-6
+    res, nn1 = tmo.cloud_resolution(cloud, threads=8)
+    assert (np.abs(nn1 - g["nn1"]) <= 1e-6 * g["nn1"]).all()
+    assert abs(res - float(np.mean(g["nn1"].astype(np.float64)))) < 1e-5 * res
+    mask_o = (c[:, 3] / c[:, 4]) < 0.2
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ratio_g = g["pc_min"].astype(np.float64) / g["pc_max"].astype(np.float64)
+    differ = np.nonzero(mask_o != (ratio_g < 0.2))[0]
+    assert len(differ) <= 5 and (np.abs(ratio_g[differ] - 0.2) < 1e-6).all()
+    rng = np.random.default_rng(2)
+    for i in rng.integers(0, len(cloud), 300):  # the oracle's kNN ends at the same distance as scipy's
+        _, d2 = tmo.cloud_knn(cloud, cloud[i, 0:3], int(g["k"]))
+        assert abs(d2[-1] - g["kth_d2"][i]) <= 2e-6 * g["kth_d2"][i] + 1e-12
+
+
+def test_atan2_census_is_what_was_committed():
+    """The reference's binary calls glibc atan2f, the project its own (include/impl/feature.hpp:7).
+    tests/golden/atan2_census.json says how many descriptor keys that changes at the configs[1] size: 4 of the
+    14,051,647 table entries, 0 of 869,958 scene pairs. Here: the file is consistent, and the small census in it is
+    reproduced from scratch (same glibc, same generator)."""
+    import json
+    import importlib.util
+    rec = json.load(open(_golden("atan2_census.json")))
+    full = rec["full_size"]
+    assert full["model_pairs"]["pairs"] == 14051647 and full["model_pairs"]["bins_differ"] == 4
+    assert len(full["model_pairs"]["differing_ij"]) == full["model_pairs"]["bins_differ"]
+    assert full["scene_pairs"]["bins_differ"] == 0 and full["scene_pairs"]["pairs"] > 800000
+    assert full["model_pairs"]["max_abs_diff"] <= 2.4e-7  # <= 1 ulp at pi / 2
+    spec = importlib.util.spec_from_file_location("make_atan2_census", _golden("make_atan2_census.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    small = mod.census(5_000, 50_000, 50_000)
+    for part in ("model_pairs", "scene_pairs"):
+        for key in ("pairs", "bins_differ", "bits_differ"):
+            assert small[part][key] == rec["small"][part][key], (part, key)
+
+
+def test_early_drop_bound_against_the_literal_expression_on_a_grid():
+    """the restated bound (positive operands) == the literal transcription of include/impl/scene.hpp:493-498
+    (negative operands, negative-double -> uint32 cast as x86-64 does it) on a grid of 3.3e8 (tried, subset size,
+    correspondences) triples up to subsets of a million points — not three known answers; the product's host function
+    agrees on a random sample of them"""
+    n, bad, first = tmo.early_drop_compare(1_000_000, 9973, 499, 101)
+    assert n > 300_000_000 and bad == 0, first
+    n, bad, first = tmo.early_drop_compare(1200, 1, 1, 1)  # every case up to subsets of 1,200 points
+    assert n > 200_000_000 and bad == 0, first
+    from triplet_match_amd import capi
+    rng = np.random.default_rng(7)
+    for _ in range(20000):
+        S = int(rng.integers(1, 1_000_001))
+        tried = int(rng.integers(1, S + 1))
+        corrs = int(rng.integers(0, tried + 1))
+        assert capi.early_drop_upper(tried, S, corrs) == tmo.early_drop_upper_literal(tried, S, corrs), (tried, S, corrs)
