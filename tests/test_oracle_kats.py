@@ -269,8 +269,8 @@ def test_curvature_and_resolution_against_scipy_and_numpy():
     res, nn1 = tmo.cloud_resolution(cloud, threads=8)
     assert (np.abs(nn1 - g["nn1"]) <= 1e-6 * g["nn1"]).all()
     assert abs(res - float(np.mean(g["nn1"].astype(np.float64)))) < 1e-5 * res
-    mask_o = (c[:, 3] / c[:, 4]) < 0.2
     with np.errstate(invalid="ignore", divide="ignore"):
+        mask_o = (c[:, 3] / c[:, 4]) < 0.2
         ratio_g = g["pc_min"].astype(np.float64) / g["pc_max"].astype(np.float64)
     differ = np.nonzero(mask_o != (ratio_g < 0.2))[0]
     assert len(differ) <= 5 and (np.abs(ratio_g[differ] - 0.2) < 1e-6).all()
