@@ -65,7 +65,7 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * read once from the environment variable TM_<NAME IN UPPER CASE> inside tm_ctx_create; afterwards only these
  * calls change it — no call of the path reads the environment. Names: debug_stats, debug_items, debug_times,
  * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
- * score_parts, score_slot_mib, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
+ * score_parts, score_slot_mib, item_sort, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
  * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of

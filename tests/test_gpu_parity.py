@@ -1055,6 +1055,11 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
                 cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
                 assert np.array_equal(cg, cb[:n]), (group, n)
                 assert np.array_equal(sg, sb[:n]), (group, n)  # fixed-point sums: identical, not merely close
+    # the items binned by the model region they land in (default for large batches only): same sums in any order
+    for shift in (0, 3, 4, 6):
+        with gpu_ctx.option("item_sort", shift):
+            cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
+        assert np.array_equal(cg, cb) and np.array_equal(sg, sb), shift
     # the per-hypothesis kernel of round 1 (still used for subset scoring) agrees as well
     with gpu_ctx.option("score_grouped", 0):
         cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)

@@ -93,6 +93,7 @@ static const opt_entry kOptions[] = {
     {"item_run", &options::item_run, -1, 30},
     {"score_item_wgs", &options::score_item_wgs, 0, 1 << 20},
     {"score_parts", &options::score_parts, 1, 64},
+    {"item_sort", &options::item_sort, -1, 6},
     {"score_slot_mib", &options::score_slot_mib, 1, 1 << 16},
     {"near_metric", &options::near_metric, 0, 2},
     {"model_morton", &options::model_morton, 0, 1},

@@ -95,6 +95,9 @@ struct options {
     int item_run = -1;        /* log2 of the run of items one XCD owns; -1 = from the item count */
     int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
     int score_parts = 3;      /* workgroups per hypothesis of k_score_culled */
+    int item_sort = -1;       /* the items of the grouped kernel binned by the model region they land in: cells of
+                                 2^item_sort voxels (3..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and
+                                 more (the three binning launches do not pay for a handful of items), 0 = never */
     int score_slot_mib = 256; /* byte budget of the grouped kernel's (group, chunk) slots per launch */
     int near_metric = 1;      /* brick filters under a plane2 / cylinder metric: 0 never, 1 when at least a tenth of
                                  the grid's bricks lies beyond the threshold (auto), 2 always */
@@ -246,6 +249,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> w_masks;       /* grouped scoring: hypothesis mask per (group, chunk) */
     tmx::dbuf<uint32_t> w_items;       /* grouped scoring: slots with a non-zero mask, + the count */
     tmx::dbuf<float2> w_aux;           /* grouped scoring: per hypothesis (rnorm, abs_eps) */
+    tmx::dbuf<uint32_t> w_item_bin, w_items_sorted, w_item_hist; /* grouped scoring: items binned by model region */
     tmx::dbuf<uint32_t> w_heads;       /* grouped scoring: per-XCD head words of the item hand-out */
     /* early-drop path (tm_earlydrop.hip) */
     tmx::dbuf<int32_t> ed_subset, ed_dropped;
