@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the 96-byte exchange goes "
                          "over gloo (RCCL refuses two ranks on one device); not a measurement")
+    ap.add_argument("--ed-profile", action="store_true",
+                    help="profiling aid: after the setup run only the device-resident early-drop scoring of the batch "
+                         "(three calls) and print its figure; tools/profile_r03.sh counts its fabric bytes")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="plumbing check without a GPU: the ranks come up over gloo, exchange one synthetic best "
                          "record each and rank 0 prints a line with \"selftest\": true and no value (tests/)")
@@ -140,6 +143,13 @@ def main():
     log("[rank %d] %d sample pairs -> %d hypotheses (%d before the batch cap)" % (rank, len(pairs), n_hyp, total))
     if n_hyp < H:
         log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (n_hyp, H))
+
+    if args.ed_profile:
+        out = early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, DIST_THRES, ACCEPT_PROB, reps=3, parity=False)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"ed_profile": True, "early_drop_ball_dev": out}), flush=True)
+        return
 
     cuda_dev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
 
@@ -482,6 +492,10 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
     except Exception as exc:  # sub-figures never fail the bench
         log("extras: early_drop_ball not measured: %s" % exc)
     try:
+        out["early_drop_ball_dev"] = early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres, accept_prob)
+    except Exception as exc:
+        log("extras: early_drop_ball_dev not measured: %s" % exc)
+    try:
         fx = "/tmp/tm_bench_c2_%d.bin" % os.getpid()
         with open(fx, "wb") as f:
             f.write(np.uint32(model.shape[0]).tobytes())
@@ -516,6 +530,62 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
     except Exception as exc:
         log("extras: e2e not measured: %s" % exc)
     return out or None
+
+
+def ed_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tm_earlydrop.hip", "tm_score.h", "tm_math.h"):
+        h.update(open(os.path.join(ROOT, "triplet_match_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres, accept_prob, reps=3, parity=True):
+    """The reference's default inner loop on the batch with everything resident (include/impl/scene.hpp:273,326,
+    492-506): every hypothesis scans nn(its first sample point, model diameter) under the early-drop rule,
+    tm_score_hypotheses_early_drop_ball_dev: poses in, results out on the device; only the centre indices (4 B per
+    hypothesis) go up. Time = HIP events on the library's stream around the call (its two internal read-backs of a
+    few words included). Bytes: L2->fabric requests of all its kernels from the committed PMC pass
+    (profiles/r03/early_drop_traffic.json, guarded by a hash of the kernel sources)."""
+    prov = np.zeros((n_hyp, 4), np.uint32)
+    ctx.d2h(prov, d_prov)
+    centers = np.ascontiguousarray(pairs[prov[:, 0], 0], dtype=np.uint32)
+    d_c, d_s, d_d, d_v = ctx.alloc(n_hyp * 4), ctx.alloc(n_hyp * 8), ctx.alloc(n_hyp * 4), ctx.alloc(n_hyp * 4)
+    ms = []
+    for _ in range(reps):
+        ctx.synchronize()
+        ctx.time_begin()
+        gs.score_hypotheses_early_drop_ball_dev(gm, d_poses, n_hyp, centers, gm.diameter, dist_thres, accept_prob,
+                                                d_c, d_s, d_d, d_v)
+        ms.append(ctx.time_end())
+    best = min(ms[1:]) if len(ms) > 1 else ms[0]
+    dropped = np.zeros(n_hyp, np.int32)
+    cnt = np.zeros(n_hyp, np.uint32)
+    ctx.d2h(dropped, d_d)
+    ctx.d2h(cnt, d_c)
+    out = {"value": round(n_hyp / (best * 1e-3), 1), "unit": "hypotheses/s", "ms": round(best, 3), "ms_all": [round(x, 3) for x in ms],
+           "hypotheses": int(n_hyp), "dropped_fraction": round(float((dropped >= 0).mean()), 4), "max_inliers": int(cnt.max()),
+           "timing": "HIP events on the library's stream around tm_score_hypotheses_early_drop_ball_dev",
+           "note": "project_ on nn(first point, model diameter) with early drop; poses and results device-resident"}
+    if parity:  # the device-resident call == the host-buffer call
+        poses = np.zeros((n_hyp, 16), np.float32)
+        ctx.d2h(poses, d_poses)
+        c2, _, d2, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, gm.diameter, dist_thres, accept_prob)
+        out["equals_host_buffer_call"] = bool(np.array_equal(c2, cnt) and np.array_equal(d2, dropped))
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03", "early_drop_traffic.json")))
+        if t.get("source_hash") == ed_source_hash() and t.get("hypotheses") == int(n_hyp):
+            gbs = t["fabric_bytes_per_call"] / (best * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "traffic": t["fabric_bytes_per_call"], "achieved": round(gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "frac_basis": "measured_l2_fabric_bytes: Infinity Cache + HBM, upper bound of HBM",
+                               "infinity_cache_frac": round(gbs / INFINITY_CACHE_RANDOM_GBS, 4),
+                               "kernel_busy_ms_under_profiler": t.get("kernel_busy_ms_per_call"),
+                               "note": "latency- and launch-bound (18 sequential checkpoints per hypothesis): the fraction is "
+                                       "small by construction; what the path is measured by is `value`"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp, dist_thres,

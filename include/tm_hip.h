@@ -66,12 +66,16 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * calls change it — no call of the path reads the environment. Names: debug_stats, debug_items, debug_times,
  * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
  * score_parts, score_slot_mib, item_sort, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
- * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows (DESIGN.md section 6 says what each selects).
+ * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows, ed_prefix_list (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */
 int tm_ctx_set_option(tm_ctx* ctx, const char* name, int value);
 int tm_ctx_get_option(const tm_ctx* ctx, const char* name, int* value);
+/* A stopwatch on the context's stream: HIP events around everything queued between the two calls (_end waits for
+ * it). For measuring device-resident calls such as tm_score_hypotheses_early_drop_ball_dev. */
+int tm_ctx_time_begin(tm_ctx* ctx);
+int tm_ctx_time_end(tm_ctx* ctx, float* ms);
 /* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline). While timing is
  * on, every scoring launch records an event pair and one row of device counters; nothing is copied to the
  * host and nothing synchronises until one of the two read-out calls below (they synchronise the stream).
@@ -314,6 +318,14 @@ int tm_score_hypotheses_early_drop_ball(tm_scene* scene, tm_model* model, const 
                                         uint32_t n_hyp, const uint32_t* centers, float radius,
                                         float dist_thres, float accept_prob, uint32_t* counts,
                                         double* scores, int32_t* dropped_at, uint32_t* saved);
+
+/* The same with the poses already on the device and the results left there: only the centre indices come from the
+ * host (4 bytes per hypothesis; their distinct values name the neighbourhoods to build). No synchronisation at the
+ * end: the results are complete when the context's stream has drained. */
+int tm_score_hypotheses_early_drop_ball_dev(tm_scene* scene, tm_model* model, const float* d_poses16, uint32_t n_hyp,
+                                            const uint32_t* centers, float radius, float dist_thres, float accept_prob,
+                                            uint32_t* d_counts, double* d_scores, int32_t* d_dropped_at,
+                                            uint32_t* d_saved);
 
 /* One batch of find_in_subset's inner loop in one call (include/impl/scene.hpp:284-350 for up to 16 first
  * points): the hypotheses of the valid sample pairs (i, j) are generated in visit order (pair after pair, the

@@ -897,6 +897,10 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
                     assert cb[h] == len(sc) and vb[h] == saved
                     assert abs(sb[h] - score) <= SCORE_RTOL * abs(score) + SCORE_ATOL_PER_TERM * max(1, len(sc))
             assert (db >= 0).any() and (db < 0).any()
+            # the first step from the neighbourhood list in scan order (instead of the same positions in curve order)
+            with gs.ctx.option("ed_prefix_list", 0):
+                alt = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
+            assert all(np.array_equal(x, y) for x, y in zip((cb, sb, db, vb), alt))
         finally:
             gs.set_mask(None)
             os_.set_mask(None)
@@ -948,7 +952,7 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
     order = np.sort(c[sc > 0])
     for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
-                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1},
+                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1}, {"ed_prefix_list": 0},
                 {"ed_wave_rows": 3, "search_segment": 300}):
         old_env = {k: gs.ctx.get_option(k) for k in env}
         for k, v in env.items():

@@ -20,6 +20,13 @@ else
   python3 tools/make_traffic_json.py $out/pmc k_score_items $out/traffic.json > /dev/null
 fi
 cp $out/traffic.json profiles/r03/traffic.json 2>/dev/null || true
+# the reference's default loop (neighbourhood + early-drop rule) on the same batch, device-resident: bytes and busy time
+echo "early drop" >> $out/progress.log
+python3 bench.py --ed-profile > $out/ed_plain.json 2> $out/ed_plain.log
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $out/ed_pmc -- python3 bench.py --ed-profile > $out/ed_pmc.json 2> $out/ed_pmc.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/ed_trace -- python3 bench.py --ed-profile > $out/ed_trace.json 2> $out/ed_trace.log
+python3 tools/make_ed_traffic_json.py $out/ed_pmc $out/ed_trace $out/ed_plain.json $out/early_drop_traffic.json > /dev/null
+cp $out/early_drop_traffic.json profiles/r03/early_drop_traffic.json 2>/dev/null || true
 # DRAM-share bracket: a 600k-point model (brick set of the near-surface shell >> 256 MB)
 echo "600k model" >> $out/progress.log
 PMC_PASSES="1 2 3" tools/pmc_rdreq.sh $out/pmc_600k --model-points 600000 > $out/pmc_600k.txt 2>&1

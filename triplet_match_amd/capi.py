@@ -53,6 +53,8 @@ SIGNATURES = {
     "tm_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "tm_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tm_ctx_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
+    "tm_ctx_time_begin": (C.c_int, [vp]),
+    "tm_ctx_time_end": (C.c_int, [vp, f32p]),
     "tm_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
     "tm_ctx_last_score_timing": (C.c_int, [vp, f32p, u64p, u64p, u64p]),
     "tm_ctx_score_timing_totals": (C.c_int, [vp, u32p, f32p, u64p]),
@@ -121,6 +123,8 @@ SIGNATURES = {
                                                  C.c_float, C.c_float, u32p, f64p, i32p, u32p]),
     "tm_score_hypotheses_early_drop_ball": (C.c_int, [vp, vp, f32p, C.c_uint32, u32p, C.c_float, C.c_float, C.c_float,
                                                      u32p, f64p, i32p, u32p]),
+    "tm_score_hypotheses_early_drop_ball_dev": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_float, C.c_float, C.c_float,
+                                                         vp, vp, vp, vp]),
     "tm_search_batch": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                   C.c_float, C.c_float, C.c_int, C.c_float, C.POINTER(BatchResult)]),
     "tm_search_batches": (C.c_int, [vp, vp, u32p, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
@@ -311,6 +315,15 @@ class Context:
             finally:
                 self.set_option(name, old)
         return _cm()
+
+    def time_begin(self):
+        _check(lib().tm_ctx_time_begin(self.h))
+
+    def time_end(self):
+        """milliseconds of GPU time since time_begin (HIP events on the context's stream)"""
+        ms = C.c_float(0)
+        _check(lib().tm_ctx_time_end(self.h, C.byref(ms)))
+        return ms.value
 
     def enable_timing(self, on=True):
         _check(lib().tm_ctx_enable_timing(self.h, int(on)))
@@ -884,6 +897,12 @@ class Scene:
                                                          counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p),
                                                          dropped.ctypes.data_as(i32p), saved.ctypes.data_as(u32p)))
         return counts, scores, dropped, saved
+
+    def score_hypotheses_early_drop_ball_dev(self, model, d_poses, n_hyp, centers, radius, dist_thres, accept_prob,
+                                             d_counts, d_scores, d_dropped, d_saved):
+        c, pc = _u(centers)
+        _check(lib().tm_score_hypotheses_early_drop_ball_dev(self.h, model.h, d_poses, n_hyp, pc, radius, dist_thres,
+                                                             accept_prob, d_counts, d_scores, d_dropped, d_saved))
 
     def search_batch(self, model, ij_pairs, radius, dist_thres, accept_prob, early_drop, sufficient,
                      min_diameter_factor=0.0, max_diameter_factor=1.0, force_up=False, query_limit=200):

@@ -107,6 +107,7 @@ static const opt_entry kOptions[] = {
     {"search_segment", &options::search_segment, -1, 1 << 24},
     {"search_per_range", &options::search_per_range, 0, 1},
     {"ed_wave_rows", &options::ed_wave_rows, 0, 1 << 19},
+    {"ed_prefix_list", &options::ed_prefix_list, 0, 1},
 };
 }  // namespace tmx
 
@@ -240,6 +241,21 @@ int tm_memcpy_d2h(tm_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
     TM_REQUIRE(c && dst && d_src, TM_ERR_INVALID, "tm_memcpy_d2h: null argument");
     TM_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return TM_OK;
+}
+
+/* a stopwatch on the context's stream (HIP events): everything queued between the two calls */
+int tm_ctx_time_begin(tm_ctx* c) {
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    return TM_OK;
+}
+int tm_ctx_time_end(tm_ctx* c, float* ms) {
+    TM_REQUIRE(c && ms, TM_ERR_INVALID, "tm_ctx_time_end: null argument");
+    TM_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    TM_HIP_CHECK(hipEventSynchronize(c->ev1));
+    TM_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return TM_OK;
 }
 

@@ -43,7 +43,48 @@ struct ed_ball {
     const float4* centre_pos;         /* [slots] xyz of the centre */
     uint32_t mwords, list_stride;
     float radius;
+    /* The scan positions the FIRST checkpoint needs (the first B positions of a slot's list), once more in the
+     * scene's curve order: entry = (sorted slot of the point, its scan position). The prefix kernel walks this
+     * list instead of the neighbourhood list — consecutive lanes then take neighbouring points: one coalesced
+     * load instead of a gather through the index list, and voxel / model gathers that share lines (the scan order,
+     * ascending scene index, is unrelated to space). [slots][plist_stride], plist_n[slot] entries; null = unused */
+    const uint2* plist;
+    const uint32_t* plist_n;
+    uint32_t plist_stride;
 };
+
+/* builds ed_ball::plist: one thread per (sorted scene slot, neighbourhood); wave-aggregated append, so that the 64
+ * consecutive points of a wave stay together in the list */
+__global__ __launch_bounds__(256) void k_ball_prefix_list(const float4* __restrict__ spos, uint32_t n_sorted,
+                                                          const unsigned long long* __restrict__ member,
+                                                          const uint32_t* __restrict__ wprefix, uint32_t mwords,
+                                                          const uint32_t* __restrict__ B_of_slot, uint32_t stride,
+                                                          uint32_t* __restrict__ plist_n, uint2* __restrict__ plist) {
+    const uint32_t sidx = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, lane = threadIdx.x & 63;
+    bool in = false;
+    uint32_t pos = 0;
+    if (sidx < n_sorted) {
+        const float4 P = spos[sidx];
+        if (P.x == P.x) { /* masked / non-finite / padding points carry NaN: they have no bits (reference :434) */
+            const uint32_t orig = __float_as_uint(P.w);
+            const unsigned long long mbits = member[(size_t)c * mwords + (orig >> 6)];
+            if ((mbits >> (orig & 63u)) & 1ull) {
+                pos = wprefix[(size_t)c * mwords + (orig >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (orig & 63u)) - 1ull));
+                in = pos < B_of_slot[c];
+            }
+        }
+    }
+    const unsigned long long b = __ballot(in);
+    if (!b) return;
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)b) - 1;
+    if ((int)lane == leader) base = atomicAdd(&plist_n[c], (uint32_t)__popcll(b));
+    base = __shfl(base, leader);
+    if (in) {
+        const uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (e < stride) plist[(size_t)c * stride + e] = make_uint2(sidx, pos);
+    }
+}
 
 struct ed_args {
     ed_ball ball;
@@ -663,6 +704,24 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
             score_args sc0 = a.sc;
             sc0.sref = oref; /* original order, as pass 3 */
             const uint32_t n_pos = min(pos_hi, S);
+            if (PREFIX && ball && a.ball.plist) {
+                /* the same positions in the scene's curve order (ed_ball::plist): same bits, coherent loads */
+                const uint2* pl = a.ball.plist + (size_t)slot * a.ball.plist_stride;
+                const uint32_t n_e = min(a.ball.plist_n[slot], a.ball.plist_stride);
+                for (uint32_t e = threadIdx.x; e < n_e; e += 256) {
+                    const uint2 en = pl[e];
+                    if (en.y >= n_pos) continue; /* the list was cut for this slot's B; a shorter prefix takes less */
+                    const float4 P = ca.spos[en.x];
+                    long long fx0 = 0;
+                    uint32_t pass0 = 0;
+                    bool tail = false;
+                    const uint32_t corr = eval_point(a.sc, T, make3(P.x, P.y, P.z), en.x, fx0, pass0, nullptr, &tail);
+                    if (!tail) continue;
+                    const unsigned long long bit = 1ull << (en.y & 63u);
+                    atomicOr(&tb[en.y >> 6], bit);
+                    if (corr) atomicOr(&cb[en.y >> 6], bit);
+                }
+            } else
             for (uint32_t pos = threadIdx.x; pos < n_pos; pos += 256) {
                 const uint32_t idx = ball ? (uint32_t)a.ball.list[(size_t)slot * a.ball.list_stride + pos]
                                           : (a.subset ? (uint32_t)a.subset[pos] : pos);
@@ -1269,6 +1328,28 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
                        d_list.p);
     TM_HIP_CHECK(hipGetLastError());
     const uint32_t words = std::max(1u, (S_max + 63) / 64);
+    /* the first checkpoint's positions of every neighbourhood in curve order (ed_ball::plist) */
+    const uint32_t prefix_words = ed_prefix_words(S_max);
+    uint32_t B_max = 0;
+    std::vector<uint32_t> h_B(n_slots);
+    for (uint32_t k = 0; k < n_slots; ++k) {
+        const uint32_t S_words = (h_S[k] + 63u) / 64u;
+        uint32_t Bw = (h_tests[(size_t)k * 18] + 1024u + 63u) / 64u;
+        Bw = std::min(std::min(Bw, S_words), prefix_words);
+        h_B[k] = Bw * 64u;
+        B_max = std::max(B_max, h_B[k]);
+    }
+    const bool use_plist = c->opt.ed_prefix_list && B_max > 0;
+    if (use_plist) {
+        TM_FORWARD(s->ed_plist.ensure((size_t)n_slots * B_max));
+        TM_FORWARD(s->ed_plist_n.ensure(2 * (size_t)n_slots));
+        TM_HIP_CHECK(hipMemcpyAsync(s->ed_plist_n.p + n_slots, h_B.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
+        TM_HIP_CHECK(hipMemsetAsync(s->ed_plist_n.p, 0, (size_t)n_slots * 4, c->stream));
+        hipLaunchKernelGGL(k_ball_prefix_list, dim3((s->n_sorted + 255) / 256, n_slots), dim3(256), 0, c->stream, s->spos.p,
+                           s->n_sorted, d_member.p, d_wprefix.p, mwords, s->ed_plist_n.p + n_slots, B_max, s->ed_plist_n.p,
+                           s->ed_plist.p);
+        TM_HIP_CHECK(hipGetLastError());
+    }
     const uint64_t budget = 256ull << 20; /* bytes per bit array */
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_hyp, budget / ((uint64_t)words * 8)));
     chunk = std::min(chunk, 65535u);
@@ -1285,6 +1366,9 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.ball.mwords = mwords;
     a.ball.list_stride = list_stride;
     a.ball.radius = radius;
+    a.ball.plist = use_plist ? s->ed_plist.p : nullptr;
+    a.ball.plist_n = s->ed_plist_n.p;
+    a.ball.plist_stride = B_max;
     a.sc.spos = nullptr;
     a.sc.spos3 = nullptr;
     a.sc.sref = s->sref.p; /* the culled kernel addresses scene points by their sorted slot */
@@ -1485,6 +1569,57 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
         double raw = (double)fx[h] * (1.0 / kFx);
         scores[h] = dropped_at[h] >= 0 ? raw : raw / (double)m->n; /* :502 / :509 */
     }
+    return TM_OK;
+}
+
+namespace tmx {
+/* scores as project_ returns them: the raw partial sum for a dropped hypothesis (:502), sum / |model| otherwise (:509) */
+__global__ void k_ed_scores(const unsigned long long* __restrict__ fx, const int32_t* __restrict__ dropped, uint32_t n,
+                            double inv_scale, double n_model, double* __restrict__ out) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    const double raw = (double)fx[h] * inv_scale;
+    out[h] = dropped[h] >= 0 ? raw : raw / n_model;
+}
+}  // namespace tmx
+
+/* The same with the poses already on the device and the results left there (pipelines, bench): only the centre
+ * indices (4 bytes per hypothesis) come from the host — their distinct values name the neighbourhoods to build. */
+extern "C" int tm_score_hypotheses_early_drop_ball_dev(tm_scene* s, tm_model* m, const float* d_poses16, uint32_t n_hyp,
+                                                       const uint32_t* centers, float radius, float dist_thres,
+                                                       float accept_prob, uint32_t* d_counts, double* d_scores,
+                                                       int32_t* d_dropped_at, uint32_t* d_saved) {
+    TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
+    TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
+    TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
+    if (n_hyp == 0) return TM_OK;
+    TM_REQUIRE(d_poses16 && centers && d_counts && d_scores && d_dropped_at && d_saved, TM_ERR_INVALID,
+               "tm_score_hypotheses_early_drop_ball_dev: null argument");
+    TM_REQUIRE(radius >= 0.f, TM_ERR_INVALID, "negative radius");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
+        for (uint32_t h = 0; h < n_hyp; ++h) {
+            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
+            order[h] = {centers[h], h};
+        }
+        std::sort(order.begin(), order.end());
+        for (uint32_t k = 0; k < n_hyp; ++k) {
+            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
+            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
+        }
+    }
+    TM_FORWARD(s->ed_slot.ensure(n_hyp));
+    TM_HIP_CHECK(hipMemcpyAsync(s->ed_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
+    TM_FORWARD(ed_ball_core(s, m, d_poses16, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres, accept_prob));
+    TM_HIP_CHECK(hipMemcpyAsync(d_counts, s->w_counts.p, (size_t)n_hyp * 4, hipMemcpyDeviceToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(d_saved, s->ed_saved.p, (size_t)n_hyp * 4, hipMemcpyDeviceToDevice, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(d_dropped_at, s->ed_dropped.p, (size_t)n_hyp * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_ed_scores, dim3((n_hyp + 255) / 256), dim3(256), 0, c->stream, s->w_scores_fx.p, s->ed_dropped.p,
+                       n_hyp, 1.0 / kFx, (double)m->n, d_scores);
+    TM_HIP_CHECK(hipGetLastError());
     return TM_OK;
 }
 

@@ -105,6 +105,8 @@ struct options {
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
     int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
     int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
+    int ed_prefix_list = 1;   /* 0: the first step of the early-drop rule walks the neighbourhood list (scan order)
+                                 instead of the same positions in the scene's curve order */
     int ed_wave_rows = 8;     /* pending hypotheses per batch the continuation of a search step takes first (in visit
                                  order); the rest follows only for batches still without a sufficient one. 0 = all at once */
     int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
@@ -260,6 +262,8 @@ struct tm_scene {
     uint32_t n_tangent = 0;
     bool tangent_idx_ready = false;
     tmx::dbuf<uint32_t> ed_tlist;      /* (slot, rank, index) triples of tm_scene_radius_tangent_lists */
+    tmx::dbuf<uint2> ed_plist;         /* first-checkpoint positions of every neighbourhood in curve order */
+    tmx::dbuf<uint32_t> ed_plist_n;    /* their counts, then the cut-off B per slot */
     tmx::dbuf<uint32_t> ed_row_info;   /* per pending row: position among its batch's pending rows | batch << 20 */
     tmx::dbuf<uint32_t> ed_pending; /* hypotheses the prefix kernel of the early-drop rule hands to the full kernel, + count */
     tmx::dbuf<float4> ed_cpos;

@@ -1665,6 +1665,8 @@ int tm_scene_destroy(tm_scene* s) {
     s->d_tangent_idx.release();
     s->ed_tlist.release();
     s->ed_row_info.release();
+    s->ed_plist.release();
+    s->ed_plist_n.release();
     s->w_item_bin.release();
     s->w_items_sorted.release();
     s->w_item_hist.release();
