@@ -96,8 +96,8 @@ struct options {
     int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
     int score_parts = 3;      /* workgroups per hypothesis of k_score_culled */
     int item_sort = -1;       /* the items of the grouped kernel binned by the model region they land in: cells of
-                                 2^item_sort voxels (3..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and
-                                 more (the three binning launches do not pay for a handful of items), 0 = never */
+                                 2^item_sort voxels (2..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and
+                                 more against a voxel table of 256 MB and more (see score_device), 0 = never */
     int score_slot_mib = 256; /* byte budget of the grouped kernel's (group, chunk) slots per launch */
     int near_metric = 1;      /* brick filters under a plane2 / cylinder metric: 0 never, 1 when at least a tenth of
                                  the grid's bricks lies beyond the threshold (auto), 2 always */

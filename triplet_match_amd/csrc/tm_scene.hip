@@ -1396,7 +1396,14 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             TM_FORWARD(scratch_ensure(c, tmp));
             TM_HIP_CHECK(rocprim::select(c->scratch.p, tmp, slots, flags, s->w_items.p, s->w_items.p + n_slots_g,
                                          n_slots_g, c->stream));
-            const int item_sort = c->opt.item_sort < 0 ? (n_hyp >= 8192u ? 4 : 0) : c->opt.item_sort;
+            /* auto: on for large batches against a voxel table of 256 MB and more (the configs[1] model: 702 MB,
+             * +5 %; the 100k-point model of config 5: +3 %). The unsorted order (group-major, chunks along the scene's
+             * curve) already has model-space locality — consecutive items share a pose and cover neighbouring scene
+             * chunks — and the unordered scatter gives that up inside a cell: with a table that fits the Infinity
+             * Cache anyway the binning only costs (plane2 uvw model, 21 MB: 7.4 -> 8.0 ms; 23k-point model, 79 MB:
+             * 4.4 -> 5.0 ms; the cylinder's 36 MB sheet is the exception, 12.4 -> 11.4 ms with item_sort = 4) */
+            int item_sort = c->opt.item_sort;
+            if (item_sort < 0) item_sort = (n_hyp >= 8192u && m->voxel_slots * 4ull >= (256ull << 20)) ? 4 : 0;
             if (item_sort) { /* the items binned by the model region they land in (see k_item_bins) */
                 /* cells of 2^shift voxels, Morton-ordered */
                 const uint32_t cell_shift = (uint32_t)std::max(1, item_sort);
