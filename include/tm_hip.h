@@ -132,6 +132,11 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
  * pc_min = middle, pc_max = largest eigenvalue, both / k. The reference's tangent masks are
  * |tangent| > 0.7 && pc_min / pc_max < 0.2 (include/impl/scene.hpp:50, model.hpp:96-99). */
 int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5);
+/* The same for the listed points only (row q of curv5 = point indices[q]; the neighbours still come from the whole
+ * cloud). The reference computes the curvature of every point (include/impl/scene.hpp:48-49, model.hpp:68-71) but
+ * reads it only where the tangent test passes (:50, :96-99) — 4 % of the points at the configs[1] sizes. */
+int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
+                              uint32_t n_indices, float* curv5);
 
 /* ---- neighbour queries of pointcloud<Point> (include/pointcloud:38-63, include/impl/pointcloud.hpp:100-210) ----
  * tm_cloud = the cloud's search structure: kdtree() / build_tree_ (:100-136, :224-240), over all finite points or

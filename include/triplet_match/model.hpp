@@ -111,6 +111,16 @@ public:
             for (uint32_t i = 0; i < sub.size(); ++i) sub[i] = i;
         }
         subset_.clear();
+        if (curvature_k_) { /* the curvature of the points the filter below can reach, in one call */
+            std::vector<uint32_t> cand;
+            for (uint32_t idx : sub) {
+                const Point& p = cloud_->points[idx];
+                if (p.getVector3fMap().allFinite() && p.getNormalVector3fMap().allFinite() && tangent(p).allFinite() &&
+                    tangent(p).norm() > 0.7f && (!curvature_ok || (*curvature_ok)[idx]))
+                    cand.push_back(idx);
+            }
+            cloud_->prepare_curvature(curvature_k_, cand);
+        }
         for (uint32_t idx : sub) {
             const Point& p = cloud_->points[idx];
             bool finite = p.getVector3fMap().allFinite() && p.getNormalVector3fMap().allFinite() &&

@@ -161,8 +161,10 @@ public:
     /* curvature(k, idx), include/impl/pointcloud.hpp:200-204: kNN-k + principal curvatures of the projected
      * normals (tm_cloud_curvature, GPU); all points are computed on first use and cached per k */
     curvature_info_t curvature(uint32_t k, uint32_t idx) const {
-        if (curv_k_ != k || curv_.size() != 5 * points.size()) {
+        const bool have = curv_k_ == k && curv_.size() == 5 * points.size();
+        if (!have || (!curv_have_.empty() && !curv_have_[idx])) { /* nothing yet, or a partial cache without idx */
             curv_.assign(5 * points.size(), 0.f);
+            curv_have_.clear(); /* empty = every point */
             auto ctx = detail::default_context(0);
             if (!points.empty())
                 detail::check(tm_cloud_curvature(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, curv_.data()),
@@ -175,6 +177,33 @@ public:
         c.pc_min = curv_[5 * (size_t)idx + 3];
         c.pc_max = curv_[5 * (size_t)idx + 4];
         return c;
+    }
+    /* curvature(k, .) of the listed points in one go (tm_cloud_curvature_subset): what model::init and
+     * scene::find_all_parallel ask before their mask loops — they read the curvature of the points that pass the
+     * tangent test only (include/impl/model.hpp:96-99, scene.hpp:50), 4 % of a cloud, where the reference computes
+     * all of them (:68-71, :48-49). A later curvature(k, idx) of another point recomputes the whole cloud. */
+    void prepare_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
+        if (curv_k_ == k && curv_.size() == 5 * points.size()) {
+            bool all = true;
+            if (!curv_have_.empty())
+                for (uint32_t i : indices) all = all && curv_have_[i];
+            if (all) return;
+        }
+        curv_.assign(5 * points.size(), 0.f);
+        curv_have_.assign(points.size(), 0);
+        if (!indices.empty()) {
+            auto ctx = detail::default_context(0);
+            std::vector<float> rows(5 * indices.size());
+            detail::check(tm_cloud_curvature_subset(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, indices.data(),
+                                                    (uint32_t)indices.size(), rows.data()),
+                          "tm_cloud_curvature_subset");
+            for (size_t q = 0; q < indices.size(); ++q) {
+                std::memcpy(&curv_[5 * (size_t)indices[q]], &rows[5 * q], 20);
+                curv_have_[indices[q]] = 1;
+            }
+        }
+        curv_k_ = k;
+        curv_hash_ = content_hash();
     }
 
     /* ---- neighbour accessors (include/pointcloud:38-63) ---- */
@@ -306,6 +335,7 @@ private:
     bool resolution_fixed_ = false;
     mutable float diameter_ = -1.f;
     mutable std::vector<float> curv_;
+    mutable std::vector<uint8_t> curv_have_; /* which rows of curv_ are filled; empty = all */
     mutable uint32_t curv_k_ = 0;
     mutable uint64_t curv_hash_ = 0;
 };

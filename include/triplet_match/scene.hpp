@@ -760,6 +760,12 @@ protected:
             return;
         }
         tangent_mask.assign(n, 0);
+        if (curvature_k_) { /* the curvature of the points the test below can reach, in one call */
+            std::vector<uint32_t> cand;
+            for (uint32_t i = 0; i < n; ++i)
+                if (tangent(cloud_->points[i]).norm() > 0.7f && (curvature_ok_.empty() || curvature_ok_[i])) cand.push_back(i);
+            cloud_->prepare_curvature(curvature_k_, cand);
+        }
         for (uint32_t i = 0; i < n; ++i) {
             bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
             if (t && !curvature_ok_.empty() && !curvature_ok_[i]) t = false;

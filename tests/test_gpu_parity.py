@@ -1187,3 +1187,15 @@ def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx):
     gc = capi.Cloud(gpu_ctx, cloud)
     idx, d2, cnt = gc.knn(cloud[:2000, 0:3], int(g["k"]))
     assert (np.abs(d2[:, -1] - g["kth_d2"][:2000]) <= 2e-6 * g["kth_d2"][:2000] + 1e-12).all()
+
+
+def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case):
+    """tm_cloud_curvature_subset (the points that pass the tangent test only) == those rows of tm_cloud_curvature,
+    bit for bit; non-finite listed points keep zero rows"""
+    cloud = small_case["scene"]["surfels"][:8000].copy()
+    cloud[77, 1] = np.inf
+    full = gpu_ctx.cloud_curvature(cloud, 30)
+    idx = np.concatenate([[77, 0, 7999], np.nonzero(np.linalg.norm(cloud[:, 9:12], axis=1) > 0.7)[0]]).astype(np.uint32)
+    sub = gpu_ctx.cloud_curvature_subset(cloud, idx, 30)
+    assert np.array_equal(sub.view(np.uint32), full[idx].view(np.uint32)) and (sub[0] == 0).all()
+    assert len(idx) > 100

@@ -73,6 +73,7 @@ SIGNATURES = {
                                     C.c_float, f32p, u32p, u32p]),
     "tm_cloud_resolution": (C.c_int, [vp, f32p, C.c_uint32, f32p, f32p]),
     "tm_cloud_curvature": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, f32p]),
+    "tm_cloud_curvature_subset": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p]),
     "tm_cloud_create": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, C.POINTER(vp)]),
     "tm_cloud_destroy": (C.c_int, [vp]),
     "tm_cloud_tree_size": (C.c_uint32, [vp]),
@@ -392,6 +393,13 @@ class Context:
         s, ps = _f(np.asarray(surfels).reshape(-1, 12))
         out = np.zeros((s.shape[0], 5), np.float32)
         _check(lib().tm_cloud_curvature(self.h, ps, s.shape[0], k, out.ctypes.data_as(f32p)))
+        return out
+
+    def cloud_curvature_subset(self, surfels, indices, k=30):
+        s, ps = _f(np.asarray(surfels).reshape(-1, 12))
+        idx, pi = _u(indices)
+        out = np.zeros((len(idx), 5), np.float32)
+        _check(lib().tm_cloud_curvature_subset(self.h, ps, s.shape[0], k, pi, len(idx), out.ctypes.data_as(f32p)))
         return out
 
     def best_of_batch(self, d_counts, d_scores, d_poses, n_hyp, id_offset=0, id_stride=1):

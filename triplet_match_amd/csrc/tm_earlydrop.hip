@@ -1305,7 +1305,13 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         (rc = d_fx.ensure(n_hyp)) || (rc = d_tests.ensure((size_t)n_slots * 18 + 2)))
         return rc;
     TM_HIP_CHECK(hipMemcpyAsync(d_cent.p, uniq, (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
+    /* hypotheses a search step never reaches (later segments after the stop, pending rows after the first waves)
+     * keep these: no score, no correspondences, "dropped at once" — never a sufficient hypothesis, never stale
+     * values of an earlier call */
     TM_HIP_CHECK(hipMemsetAsync(d_fx.p, 0, (size_t)n_hyp * 8, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_counts.p, 0, (size_t)n_hyp * 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_saved.p, 0, (size_t)n_hyp * 4, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(d_dropped.p, 0, (size_t)n_hyp * 4, c->stream));
     const dim3 grid_n((s->n + 255) / 256, n_slots);
     hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, d_cent.p, radius * radius,
                        mwords, d_member.p, s->ed_cpos.p);

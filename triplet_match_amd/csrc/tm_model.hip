@@ -259,20 +259,23 @@ __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __rest
                                                             const float4* __restrict__ pts /* xyz, orig idx */,
                                                             const float4* __restrict__ nrm /* orig order */,
                                                             uint32_t n /* finite points = entries of pts */,
-                                                            uint32_t k, float* __restrict__ curv5 /* zeroed */) {
+                                                            uint32_t k, float* __restrict__ curv5 /* zeroed */,
+                                                            const float4* __restrict__ queries = nullptr,
+                                                            uint32_t n_queries = 0) {
     __shared__ uint32_t st_node[kKdStack][kCurvThreads];
     __shared__ float st_bound[kKdStack][kCurvThreads];
     __shared__ float nb_d2[kCurvK][kCurvThreads];
     __shared__ uint32_t nb_idx[kCurvK][kCurvThreads];
     const uint32_t t = blockIdx.x * kCurvThreads + threadIdx.x;
-    if (t >= n) return;
+    if (t >= (queries ? n_queries : n)) return;
     const uint32_t tx = threadIdx.x;
     /* the queries run in kd-tree order: the threads of a wave ask for neighbouring points, walk nearly the same
      * nodes and read the same leaves (in the cloud's own order — arbitrary — every lane goes its own way: 57 ms
      * against 36 ms per 1M points) */
-    const float4 Q = pts[t];
+    /* with an explicit query list (tm_cloud_curvature_subset): query t = (xyz, original index), row t of curv5 */
+    const float4 Q = queries ? queries[t] : pts[t];
     const uint32_t self = __float_as_uint(Q.w);
-    float* out = curv5 + (size_t)self * 5;
+    float* out = curv5 + (size_t)(queries ? t : self) * 5;
     float q[3] = {Q.x, Q.y, Q.z};
     uint32_t have = 0;
     int sp = 1;
@@ -1017,9 +1020,20 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
 }
 
 int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5) {
+    return tm_cloud_curvature_subset(ctx, surfels, n, k, nullptr, n, curv5);
+}
+
+/* curvature(k, idx) for the listed points only (indices == NULL: all points, row i = point i). The reference computes
+ * it for every point (include/impl/scene.hpp:48-49, model.hpp:68-71) but reads it only where |tangent| > 0.7
+ * (:50, :96-99): 4 % of the points at the configs[1] sizes. The neighbours still come from the whole cloud. */
+int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
+                              uint32_t n_idx, float* curv5) {
     TM_REQUIRE(ctx && surfels && curv5, TM_ERR_INVALID, "tm_cloud_curvature: null argument");
     TM_REQUIRE(k >= 1 && k <= (uint32_t)kCurvK, TM_ERR_UNSUPPORTED, "tm_cloud_curvature: k must be in 1..32");
-    if (n == 0) return TM_OK;
+    if (n == 0 || (indices && n_idx == 0)) return TM_OK;
+    if (indices)
+        for (uint32_t q = 0; q < n_idx; ++q)
+            TM_REQUIRE(indices[q] < n, TM_ERR_INVALID, "tm_cloud_curvature_subset: index out of range");
     TM_HIP_CHECK(hipSetDevice(ctx->device));
     const bool dbg = ctx->opt.debug_times != 0; /* where the call's time goes, on stderr */
     auto t_last = std::chrono::steady_clock::now();
@@ -1041,7 +1055,8 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
     kb.pos = &pos;
     for (uint32_t i = 0; i < n; ++i)
         if (pos[i].x == pos[i].x) kb.order.push_back(i);
-    memset(curv5, 0, (size_t)n * 20);
+    const uint32_t n_rows = indices ? n_idx : n;
+    memset(curv5, 0, (size_t)n_rows * 20);
     if (kb.order.empty()) return TM_OK;
     lap("fill");
     kb.build(0, (int)kb.order.size(), 0);
@@ -1056,13 +1071,27 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
     }
     lap("kd points");
     const uint32_t kk = std::min<uint32_t>(k, (uint32_t)kb.order.size());
-    dbuf<float4> d_lo, d_hi, d_pts, d_n;
+    dbuf<float4> d_lo, d_hi, d_pts, d_n, d_q;
     dbuf<float> d_out;
-    auto cleanup = [&]() { d_lo.release(); d_hi.release(); d_pts.release(); d_n.release(); d_out.release(); };
+    auto cleanup = [&]() { d_lo.release(); d_hi.release(); d_pts.release(); d_n.release(); d_out.release(); d_q.release(); };
     int rc;
     const uint32_t n_kd = (uint32_t)kd_pts.size();
+    std::vector<float4> h_q; /* the listed points as queries: (xyz, original index); non-finite ones keep their zero row */
+    std::vector<uint32_t> q_row;
+    if (indices) {
+        for (uint32_t q = 0; q < n_idx; ++q) {
+            const float4& p = pos[indices[q]];
+            if (!(p.x == p.x)) continue;
+            float w;
+            memcpy(&w, &indices[q], 4);
+            h_q.push_back(make_float4(p.x, p.y, p.z, w));
+            q_row.push_back(q);
+        }
+        if (h_q.empty()) return TM_OK;
+    }
+    const uint32_t n_out = indices ? (uint32_t)h_q.size() : n;
     if ((rc = d_lo.alloc(kb.lo.size())) || (rc = d_hi.alloc(kb.hi.size())) || (rc = d_pts.alloc(kd_pts.size())) ||
-        (rc = d_n.alloc(n)) || (rc = d_out.alloc((size_t)n * 5))) {
+        (rc = d_n.alloc(n)) || (rc = d_out.alloc((size_t)n_out * 5)) || (indices && (rc = d_q.alloc(h_q.size())))) {
         cleanup();
         return rc;
     }
@@ -1070,16 +1099,24 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
     if (e == hipSuccess) e = hipMemcpyAsync(d_hi.p, kb.hi.data(), kb.hi.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_n.p, nrm.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, (size_t)n * 20, ctx->stream); /* non-finite points stay 0 */
+    if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, (size_t)n_out * 20, ctx->stream); /* non-finite points stay 0 */
+    if (e == hipSuccess && indices)
+        e = hipMemcpyAsync(d_q.p, h_q.data(), h_q.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     lap("alloc + upload");
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_curvature, dim3((n_kd + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0, ctx->stream,
-                           d_lo.p, d_hi.p, d_pts.p, d_n.p, n_kd, kk, d_out.p);
+        const uint32_t n_threads = indices ? n_out : n_kd;
+        hipLaunchKernelGGL(k_curvature, dim3((n_threads + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0, ctx->stream,
+                           d_lo.p, d_hi.p, d_pts.p, d_n.p, n_kd, kk, d_out.p, indices ? d_q.p : (const float4*)nullptr, n_out);
         e = hipGetLastError();
     }
     lap("kernel");
-    if (e == hipSuccess) e = hipMemcpyAsync(curv5, d_out.p, (size_t)n * 20, hipMemcpyDeviceToHost, ctx->stream);
+    std::vector<float> compact;
+    if (indices) compact.resize((size_t)n_out * 5);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(indices ? compact.data() : curv5, d_out.p, (size_t)n_out * 20, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && indices)
+        for (uint32_t q = 0; q < n_out; ++q) memcpy(curv5 + 5 * (size_t)q_row[q], compact.data() + 5 * (size_t)q, 20);
     lap("download");
     cleanup();
     if (e != hipSuccess) {
