@@ -245,13 +245,14 @@ int tm_scene_radius_lists(tm_scene* scene, const uint32_t* centers, uint32_t n_c
 /* What the sampling loop of find_in_subset (include/impl/scene.hpp:273-302) uses of those neighbourhoods: the size
  * of nn (inner_bound, :276-281; the range of the shuffle's draws, :285) and its members with tangent_mask_ set —
  * every other member fails the first filter of :290 whatever its index is. counts[k] = size of the neighbourhood
- * of centers[k]; triples = (k, rank, index) per tangent member, rank = its position in that neighbourhood's
- * ascending order (the order tm_scene_radius_lists hands out); 3 x uint32 each, in no defined order;
- * *n_triples = how many. TM_ERR_CAPACITY (counts and *n_triples valid) when cap_triples is too small; it never
- * exceeds n_centers x (tangent points of the scene). A 60,000-point neighbourhood with 4 % tangent points
- * travels as 29 KB instead of 240 KB. */
+ * of centers[k]; t_counts[k] = its tangent members; pairs = their (rank, index), 2 x uint32 each, slot after slot
+ * (slot k starts at the sum of the t_counts before it), each slot in ascending index order; rank = the member's
+ * position in that neighbourhood's ascending order (the order tm_scene_radius_lists hands out). *n_pairs = total.
+ * TM_ERR_CAPACITY (counts, t_counts and *n_pairs valid) when cap_pairs is too small. A 60,000-point neighbourhood
+ * with 4 % tangent points travels as 19 KB instead of 240 KB. */
 int tm_scene_radius_tangent_lists(tm_scene* scene, const uint32_t* centers, uint32_t n_centers, float radius,
-                                  uint32_t* counts, uint32_t* triples, uint32_t cap_triples, uint32_t* n_triples);
+                                  uint32_t* counts, uint32_t* t_counts, uint32_t* pairs, uint32_t cap_pairs,
+                                  uint32_t* n_pairs);
 
 /* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
  * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same

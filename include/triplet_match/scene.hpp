@@ -86,7 +86,7 @@ struct hip_backend {
     /* The sampling loop's view of nn = radius_search_inclusive(radius, i) (include/impl/scene.hpp:273-302): its
      * size and (rank, index) of its members with tangent_mask set (tm_scene_radius_tangent_lists) — every other
      * member fails the first filter of :290. Fetched for i and up to 63 announced first points after it. */
-    std::vector<uint32_t> t_counts, t_offsets, t_pairs, t_triples; /* per cached first point: |nn|, CSR of (rank, index) */
+    std::vector<uint32_t> t_counts, t_offsets, t_pairs; /* per cached first point: |nn|, CSR of (rank, index), ascending */
     size_t t_lo = 0, t_hi = 0;
     float t_radius = -1.f;
     bool supports_tangent_view() const { return !env_once().dense_neighbourhoods; }
@@ -106,29 +106,23 @@ struct hip_backend {
         t_hi = t_lo + batch.size();
         t_radius = radius;
         t_counts.assign(batch.size(), 0u);
-        uint32_t n_tri = 0;
-        if (t_triples.size() < 3 * 4096) t_triples.resize(3 * 4096);
+        std::vector<uint32_t> tc(batch.size(), 0u);
+        uint32_t n_pairs_total = 0;
+        if (t_pairs.size() < 2 * 8192) t_pairs.resize(2 * 8192);
         for (int attempt = 0; attempt < 2; ++attempt) {
             const int rc = tm_scene_radius_tangent_lists(s, batch.data(), (uint32_t)batch.size(), radius, t_counts.data(),
-                                                         t_triples.data(), (uint32_t)(t_triples.size() / 3), &n_tri);
+                                                         tc.data(), t_pairs.data(), (uint32_t)(t_pairs.size() / 2),
+                                                         &n_pairs_total);
             if (rc == TM_ERR_CAPACITY && attempt == 0) {
-                t_triples.resize(3 * ((size_t)n_tri + n_tri / 4 + 16));
+                t_pairs.resize(2 * ((size_t)n_pairs_total + n_pairs_total / 4 + 16));
                 continue;
             }
             check(rc, "tm_scene_radius_tangent_lists");
             break;
         }
-        /* bucket the triples by slot (counting sort): t_pairs[2 * (t_offsets[k] + e)] = rank, [+ 1] = index */
+        /* the pairs arrive slot after slot, each slot in ascending index (= ascending rank) order */
         t_offsets.assign(batch.size() + 1, 0u);
-        for (uint32_t e = 0; e < n_tri; ++e) ++t_offsets[t_triples[3 * (size_t)e] + 1];
-        for (size_t k = 0; k < batch.size(); ++k) t_offsets[k + 1] += t_offsets[k];
-        t_pairs.resize(2 * (size_t)n_tri + 2);
-        std::vector<uint32_t> cur(t_offsets.begin(), t_offsets.end() - 1);
-        for (uint32_t e = 0; e < n_tri; ++e) {
-            const uint32_t k = t_triples[3 * (size_t)e], d = cur[k]++;
-            t_pairs[2 * (size_t)d] = t_triples[3 * (size_t)e + 1];
-            t_pairs[2 * (size_t)d + 1] = t_triples[3 * (size_t)e + 2];
-        }
+        for (size_t k = 0; k < batch.size(); ++k) t_offsets[k + 1] = t_offsets[k] + tc[k];
     }
     void tangent_view(uint32_t i, float radius, size_t& n_nn, const uint32_t*& rank_index_pairs, size_t& n_pairs) {
         size_t k = t_lo;

@@ -334,29 +334,50 @@ inline void extract_all(B& be, const std::vector<pose_t>& Ts, float dist_thres, 
     for (size_t k = 0; k < Ts.size(); ++k) be.extract(Ts[k], dist_thres, out[k]);
 }
 
-/* The shuffled copy of a neighbourhood list, kept sparse: position -> scene index for the positions that hold a
- * point with tangent_mask set; every other position holds a point the sampling loop skips whatever its index is
- * (first filter of include/impl/scene.hpp:290) and is simply absent (get() = -1). A swap of the lazy Fisher-Yates
- * shuffle moves the (at most two) entries involved; swapping two absent positions is nothing. Open addressing,
- * cleared per first point. */
+/* The shuffled copy of a neighbourhood list, kept sparse. Of the list only the entries with tangent_mask set matter
+ * (every other one fails the first filter of include/impl/scene.hpp:290 whatever its index is); they arrive as
+ * (rank, index) pairs in ascending rank order. Before any swap, position p holds pairs[ordinal(p)] if bit p of
+ * `tangent` is set (ordinal = number of set bits below p: a per-word prefix count + a popcount), else "nothing" (-1).
+ * A swap of the lazy Fisher-Yates shuffle that involves a tangent entry records the two positions' new contents in a
+ * small open-addressing table (`moved` marks them); swapping two positions that hold nothing is nothing. Per first
+ * point: clearing two bitmaps of |nn| bits, setting the tangent bits, one prefix pass — no per-entry inserts. */
 struct sparse_list {
-    std::vector<uint32_t> key;
+    const uint32_t* pairs = nullptr; /* (rank, index), ascending rank */
+    std::vector<uint64_t> tangent, moved;
+    std::vector<uint32_t> word_prefix; /* tangent bits set before each word */
+    std::vector<uint32_t> key;         /* displaced positions */
     std::vector<int32_t> val;
-    std::vector<uint64_t> present; /* one bit per position: is it in the table? 24 of 25 lookups end here */
     uint32_t shift = 32, used = 0;
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    void reset(size_t expect, size_t positions) {
-        present.assign((positions + 63) / 64 + 1, 0ull);
-        uint32_t bits = 10;
-        while (((size_t)1 << bits) < 4 * expect + 64) ++bits;
-        key.assign((size_t)1 << bits, kEmpty);
-        val.resize((size_t)1 << bits);
-        shift = 32 - bits;
+    void reset(const uint32_t* rank_index_pairs, size_t n_pairs, size_t positions) {
+        pairs = rank_index_pairs;
+        const size_t words = (positions + 63) / 64 + 1;
+        tangent.assign(words, 0ull);
+        moved.assign(words, 0ull);
+        for (size_t e = 0; e < n_pairs; ++e) tangent[pairs[2 * e] >> 6] |= 1ull << (pairs[2 * e] & 63u);
+        word_prefix.resize(words);
+        uint32_t run = 0;
+        for (size_t w = 0; w < words; ++w) {
+            word_prefix[w] = run;
+            run += (uint32_t)__builtin_popcountll(tangent[w]);
+        }
+        if (key.size() != 2048) {
+            key.assign(2048, kEmpty);
+            val.resize(2048);
+            shift = 32 - 11;
+        } else if (used) {
+            std::fill(key.begin(), key.end(), kEmpty);
+        }
         used = 0;
     }
     uint32_t slot_of(uint32_t pos) const { return (pos * 0x9E3779B1u) >> shift; }
     int32_t get(uint32_t pos) const {
-        if (!((present[pos >> 6] >> (pos & 63u)) & 1ull)) return -1;
+        const uint64_t bit = 1ull << (pos & 63u);
+        if (!(moved[pos >> 6] & bit)) { /* untouched by the shuffle so far */
+            const uint64_t tw = tangent[pos >> 6];
+            if (!(tw & bit)) return -1;
+            return (int32_t)pairs[2 * (size_t)(word_prefix[pos >> 6] + (uint32_t)__builtin_popcountll(tw & (bit - 1))) + 1];
+        }
         const uint32_t mask = (uint32_t)key.size() - 1;
         for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
             if (key[h] == pos) return val[h];
@@ -364,12 +385,7 @@ struct sparse_list {
         }
     }
     void put(uint32_t pos, int32_t v) {
-        if (v < 0) {
-            if (!((present[pos >> 6] >> (pos & 63u)) & 1ull)) return; /* absent stays absent */
-            present[pos >> 6] &= ~(1ull << (pos & 63u));
-        } else {
-            present[pos >> 6] |= 1ull << (pos & 63u);
-        }
+        moved[pos >> 6] |= 1ull << (pos & 63u);
         const uint32_t mask = (uint32_t)key.size() - 1;
         for (uint32_t h = slot_of(pos);; h = (h + 1) & mask) {
             if (key[h] == pos) {
@@ -377,7 +393,6 @@ struct sparse_list {
                 return;
             }
             if (key[h] == kEmpty) {
-                if (v < 0) return; /* absent already means "not a tangent point" */
                 key[h] = pos;
                 val[h] = v;
                 if (++used * 2 > key.size()) grow();
@@ -394,8 +409,15 @@ struct sparse_list {
         val.resize(k2.size() * 2);
         --shift;
         used = 0;
-        for (size_t h = 0; h < k2.size(); ++h)
-            if (k2[h] != kEmpty && v2[h] >= 0) put(k2[h], v2[h]);
+        const uint32_t mask = (uint32_t)key.size() - 1;
+        for (size_t q = 0; q < k2.size(); ++q) {
+            if (k2[q] == kEmpty) continue;
+            uint32_t h = slot_of(k2[q]);
+            while (key[h] != kEmpty) h = (h + 1) & mask;
+            key[h] = k2[q];
+            val[h] = v2[q];
+            ++used;
+        }
     }
 };
 
@@ -571,8 +593,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         if (sparse) {
             /* the same shuffle on the sparse copy: the draws depend on the list's LENGTH only (rng() % (n - k)), and
              * a position's content matters only if it is a tangent point; same r, same j at every step as below */
-            shuffled.reset(n_t_pairs, n_nn);
-            for (size_t e = 0; e < n_t_pairs; ++e) shuffled.put(t_pairs[2 * e], (int32_t)t_pairs[2 * e + 1]);
+            shuffled.reset(t_pairs, n_t_pairs, n_nn);
             for (size_t k = 0; k < n_nn; ++k) {
                 if (p.stats) ++p.stats->draws;
                 if (k + 1 < n_nn) {

@@ -1030,8 +1030,8 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
         tm = small_case["scene"]["tangent_mask"]
         for k in range(len(centers)):
             assert counts[k] == len(lists[k])
-            want = {int(rk): int(j) for rk, j in enumerate(lists[k]) if tm[j]}
-            assert tangent[k] == want, (r, k)
+            want = np.array([(rk, j) for rk, j in enumerate(lists[k]) if tm[j]], np.uint32).reshape(-1, 2)
+            assert np.array_equal(tangent[k], want), (r, k)  # ascending index order, ranks in the full list
     assert sum(len(t) for t in tangent) >= 0
     counts, tangent = gs.radius_tangent_lists(centers, diam)
     assert sum(len(t) for t in tangent) > 100

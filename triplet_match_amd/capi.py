@@ -107,7 +107,7 @@ SIGNATURES = {
     "tm_scene_radius_subset": (C.c_int, [vp, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_scene_radius_select": (C.c_int, [vp, u32p, C.c_uint32, i32p]),
     "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
-    "tm_scene_radius_tangent_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, u32p, u32p, C.c_uint32, u32p]),
+    "tm_scene_radius_tangent_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, u32p, u32p, u32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
@@ -798,18 +798,20 @@ class Scene:
         return [lists[k, :counts[k]].copy() for k in range(cn.size)]
 
     def radius_tangent_lists(self, centers, radius):
-        """(sizes of the neighbourhoods, per centre a dict rank -> index of its tangent members)"""
+        """(sizes of the neighbourhoods, per centre the (rank, index) pairs of its tangent members, ascending)"""
         c, pc = _u(centers)
         counts = np.zeros(len(c), np.uint32)
+        tc = np.zeros(len(c), np.uint32)
         n = C.c_uint32(0)
-        rc = lib().tm_scene_radius_tangent_lists(self.h, pc, len(c), radius, counts.ctypes.data_as(u32p), None, 0, C.byref(n))
+        rc = lib().tm_scene_radius_tangent_lists(self.h, pc, len(c), radius, counts.ctypes.data_as(u32p),
+                                                 tc.ctypes.data_as(u32p), None, 0, C.byref(n))
         if rc not in (OK, ERR_CAPACITY):
             _check(rc)
-        tri = np.zeros((max(n.value, 1), 3), np.uint32)
+        pairs = np.zeros((max(n.value, 1), 2), np.uint32)
         _check(lib().tm_scene_radius_tangent_lists(self.h, pc, len(c), radius, counts.ctypes.data_as(u32p),
-                                                   tri.ctypes.data_as(u32p), n.value, C.byref(n)))
-        tri = tri[:n.value]
-        return counts, [dict(zip(tri[tri[:, 0] == k, 1].tolist(), tri[tri[:, 0] == k, 2].tolist())) for k in range(len(c))]
+                                                   tc.ctypes.data_as(u32p), pairs.ctypes.data_as(u32p), n.value, C.byref(n)))
+        offs = np.concatenate([[0], np.cumsum(tc)]).astype(np.int64)
+        return counts, [pairs[offs[k]:offs[k + 1]].copy() for k in range(len(c))]
 
     def generate_hypotheses(self, model, ij_pairs, min_diameter_factor=0.2,
                             max_diameter_factor=1.0, force_up=False, query_limit=200, cap=None):

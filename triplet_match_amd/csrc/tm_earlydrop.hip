@@ -193,41 +193,52 @@ __global__ __launch_bounds__(256) void k_ball_members(const float4* __restrict__
     if (i == 0) centre_pos[c] = C;
 }
 
-/* The tangent members of several balls: for slot blockIdx.y and every scene point t with tangent_mask set that
- * lies in the ball, one (slot, rank of t in the ball's ascending index order, t) triple is appended to `out`
- * (wave-aggregated append; the order of the triples is not defined). */
-__global__ __launch_bounds__(256) void k_ball_tangent(const unsigned long long* __restrict__ member,
-                                                      const uint32_t* __restrict__ wprefix, uint32_t mwords,
-                                                      const uint32_t* __restrict__ tangent_idx, uint32_t n_tangent,
-                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ out) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, lane = threadIdx.x & 63;
-    bool in = false;
-    uint32_t t = 0, rank = 0;
-    if (k < n_tangent) {
-        t = tangent_idx[k];
-        const unsigned long long mbits = member[(size_t)c * mwords + (t >> 6)];
-        in = ((mbits >> (t & 63u)) & 1ull) != 0ull;
-        rank = wprefix[(size_t)c * mwords + (t >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (t & 63u)) - 1ull));
+/* The tangent members of several balls, in ascending index order: one 1024-thread workgroup per slot walks the scene's
+ * tangent points (ascending), keeps those inside the ball, and writes (rank of the point in the ball's ascending index
+ * order, index) at the position a block scan gives it — staging[slot][e], t_counts[slot] entries. */
+__global__ __launch_bounds__(1024) void k_ball_tangent(const unsigned long long* __restrict__ member,
+                                                       const uint32_t* __restrict__ wprefix, uint32_t mwords,
+                                                       const uint32_t* __restrict__ tangent_idx, uint32_t n_tangent,
+                                                       uint32_t stride, uint2* __restrict__ staging,
+                                                       uint32_t* __restrict__ t_counts) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const unsigned long long* mb = member + (size_t)c * mwords;
+    const uint32_t per = (n_tangent + 1023u) / 1024u, k0 = min(t * per, n_tangent), k1 = min(k0 + per, n_tangent);
+    uint32_t local = 0;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t p = tangent_idx[k];
+        local += (uint32_t)((mb[p >> 6] >> (p & 63u)) & 1ull);
     }
-    /* one append per workgroup: same-address atomics from every wave serialise (153 us per call with one per wave) */
-    __shared__ uint32_t s_cnt[4], s_base;
-    const unsigned long long b = __ballot(in);
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(b);
+    s_sum[t] = local;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t total = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-        s_base = total ? atomicAdd(cursor, total) : 0u;
+    for (uint32_t off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
+        const uint32_t v = t >= off ? s_sum[t - off] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
     }
-    __syncthreads();
-    if (in) {
-        uint32_t base = s_base;
-        for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
-        const uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        out[3 * (size_t)e] = c;
-        out[3 * (size_t)e + 1] = rank;
-        out[3 * (size_t)e + 2] = t;
+    uint32_t e = s_sum[t] - local;
+    for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t p = tangent_idx[k];
+        const unsigned long long mbits = mb[p >> 6];
+        if (!((mbits >> (p & 63u)) & 1ull)) continue;
+        const uint32_t rank = wprefix[(size_t)c * mwords + (p >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (p & 63u)) - 1ull));
+        if (e < stride) staging[(size_t)c * stride + e] = make_uint2(rank, p);
+        ++e;
     }
+    if (t == 1023) t_counts[c] = s_sum[1023];
+}
+
+/* the slots' lists one behind the other (CSR: slot c starts at the sum of the counts before it) */
+__global__ __launch_bounds__(256) void k_ball_tangent_compact(const uint2* __restrict__ staging, uint32_t stride,
+                                                              const uint32_t* __restrict__ t_counts,
+                                                              uint2* __restrict__ out) {
+    const uint32_t c = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= t_counts[c]) return;
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < c; ++q) base += t_counts[q];
+    out[base + e] = staging[(size_t)c * stride + e];
 }
 
 /* exclusive prefix of the word popcounts of one slot (one 1024-thread block per slot) and the total */
@@ -1911,16 +1922,16 @@ extern "C" int tm_score_hypotheses_on_points(tm_scene* s, tm_model* m, const flo
 /* What the sampling loop of find_in_subset needs of nn = radius_search_inclusive(radius, centre) (reference
  * include/impl/scene.hpp:273-302): its size (inner_bound :276-281, and the range of the shuffle's draws :285) and its
  * members with tangent_mask_ set — every other member fails the first filter of :290 whatever its index is. So only
- * those travel: counts[k] = size of nn_k, and one (k, rank, index) triple per tangent member of nn_k, rank = its
- * position in nn_k's ascending order (the order tm_scene_radius_lists hands out). A neighbourhood of 60,000 points
- * with 4 % tangent points is 29 KB instead of 240 KB. *n_triples = total written (triples = 3 x uint32 each, order not
- * defined); TM_ERR_CAPACITY (with counts and *n_triples valid) when cap_triples is too small. */
+ * those travel: counts[k] = size of nn_k, t_counts[k] = its tangent members, and their (rank, index) pairs, slot after
+ * slot, each slot in ascending index order; rank = position in nn_k's ascending order (the order
+ * tm_scene_radius_lists hands out). A neighbourhood of 60,000 points with 4 % tangent points is 19 KB instead of
+ * 240 KB. *n_pairs = total; TM_ERR_CAPACITY (counts, t_counts and *n_pairs valid) when cap_pairs is too small. */
 extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
-                                             uint32_t* counts, uint32_t* triples, uint32_t cap_triples,
-                                             uint32_t* n_triples) {
-    TM_REQUIRE(s && counts && n_triples && (centers || n_centers == 0), TM_ERR_INVALID,
+                                             uint32_t* counts, uint32_t* t_counts, uint32_t* pairs, uint32_t cap_pairs,
+                                             uint32_t* n_pairs) {
+    TM_REQUIRE(s && counts && t_counts && n_pairs && (centers || n_centers == 0), TM_ERR_INVALID,
                "tm_scene_radius_tangent_lists: null argument");
-    *n_triples = 0;
+    *n_pairs = 0;
     if (n_centers == 0) return TM_OK;
     for (uint32_t k = 0; k < n_centers; ++k)
         TM_REQUIRE(centers[k] < s->n, TM_ERR_INVALID, "tm_scene_radius_tangent_lists: centre index out of range");
@@ -1931,24 +1942,25 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
     TM_FORWARD(s->ed_centres.ensure(n_centers));
     TM_FORWARD(s->ed_member.ensure((size_t)n_centers * mwords));
     TM_FORWARD(s->ed_wprefix.ensure((size_t)n_centers * mwords));
-    TM_FORWARD(s->ed_S.ensure((size_t)n_centers + 1)); /* + the append cursor */
+    TM_FORWARD(s->ed_S.ensure(2 * (size_t)n_centers)); /* sizes, then tangent counts */
     TM_FORWARD(s->ed_cpos.ensure(n_centers));
-    const size_t worst = (size_t)n_centers * s->n_tangent;
-    TM_FORWARD(s->ed_tlist.ensure(3 * std::max<size_t>(worst, 1)));
+    const uint32_t stride = std::max(1u, s->n_tangent);
+    TM_FORWARD(s->ed_tlist.ensure(4 * (size_t)n_centers * stride)); /* staging + CSR, 2 words per entry each */
+    uint2* d_staging = reinterpret_cast<uint2*>(s->ed_tlist.p);
+    uint2* d_csr = d_staging + (size_t)n_centers * stride;
     TM_HIP_CHECK(hipMemcpyAsync(s->ed_centres.p, centers, (size_t)n_centers * 4, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(s->ed_S.p + n_centers, 0, 4, c->stream));
     const dim3 grid_n((s->n + 255) / 256, n_centers);
     hipLaunchKernelGGL(k_ball_members, grid_n, dim3(256), 0, c->stream, s->opos.p, s->n, s->ed_centres.p,
                        radius * radius, mwords, s->ed_member.p, s->ed_cpos.p);
     hipLaunchKernelGGL(k_ball_prefix, dim3(n_centers), dim3(1024), 0, c->stream, s->ed_member.p, mwords,
                        s->ed_wprefix.p, s->ed_S.p);
-    if (s->n_tangent)
-        hipLaunchKernelGGL(k_ball_tangent, dim3((s->n_tangent + 255) / 256, n_centers), dim3(256), 0, c->stream,
-                           s->ed_member.p, s->ed_wprefix.p, mwords, s->d_tangent_idx.p, s->n_tangent,
-                           s->ed_S.p + n_centers, s->ed_tlist.p);
+    hipLaunchKernelGGL(k_ball_tangent, dim3(n_centers), dim3(1024), 0, c->stream, s->ed_member.p, s->ed_wprefix.p, mwords,
+                       s->d_tangent_idx.p, s->n_tangent, stride, d_staging, s->ed_S.p + n_centers);
+    hipLaunchKernelGGL(k_ball_tangent_compact, dim3((stride + 255) / 256, n_centers), dim3(256), 0, c->stream, d_staging,
+                       stride, s->ed_S.p + n_centers, d_csr);
     TM_HIP_CHECK(hipGetLastError());
-    /* sizes and the append cursor in one read-back, then exactly the triples that were written */
-    const size_t head = ((size_t)n_centers + 1) * 4;
+    /* sizes and tangent counts in one read-back, then exactly the pairs that were written */
+    const size_t head = 2 * (size_t)n_centers * 4;
     if (s->h_pinned_bytes < head + 64) {
         if (s->h_pinned) (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
@@ -1959,11 +1971,14 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
     TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_S.p, head, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     memcpy(counts, s->h_pinned, (size_t)n_centers * 4);
-    const uint32_t total = ((const uint32_t*)s->h_pinned)[n_centers];
-    *n_triples = total;
+    memcpy(t_counts, (const uint32_t*)s->h_pinned + n_centers, (size_t)n_centers * 4);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_centers; ++k) total += t_counts[k];
+    TM_REQUIRE(total <= 0xFFFFFFFFull, TM_ERR_UNSUPPORTED, "tm_scene_radius_tangent_lists: more than 2^32 pairs");
+    *n_pairs = (uint32_t)total;
     if (total == 0) return TM_OK;
-    TM_REQUIRE(triples && cap_triples >= total, TM_ERR_CAPACITY, "tm_scene_radius_tangent_lists: room for fewer triples than found");
-    const size_t need = (size_t)total * 12;
+    TM_REQUIRE(pairs && cap_pairs >= total, TM_ERR_CAPACITY, "tm_scene_radius_tangent_lists: room for fewer pairs than found");
+    const size_t need = (size_t)total * 8;
     if (s->h_pinned_bytes < need) {
         (void)hipHostFree(s->h_pinned);
         s->h_pinned = nullptr;
@@ -1971,9 +1986,9 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
         TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
         s->h_pinned_bytes = need + need / 4;
     }
-    TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_tlist.p, need, hipMemcpyDeviceToHost, c->stream));
+    TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, d_csr, need, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    memcpy(triples, s->h_pinned, need);
+    memcpy(pairs, s->h_pinned, need);
     return TM_OK;
 }
 
