@@ -261,7 +261,7 @@ struct tm_scene {
     tmx::dbuf<uint32_t> d_tangent_idx; /* ascending indices of the points with tangent_mask set, + their number */
     uint32_t n_tangent = 0;
     bool tangent_idx_ready = false;
-    tmx::dbuf<uint32_t> ed_tlist;      /* (slot, rank, index) triples of tm_scene_radius_tangent_lists */
+    tmx::dbuf<uint32_t> ed_tlist;      /* staging + CSR (rank, index) pairs of tm_scene_radius_tangent_lists */
     tmx::dbuf<uint2> ed_plist;         /* first-checkpoint positions of every neighbourhood in curve order */
     tmx::dbuf<uint32_t> ed_plist_n;    /* their counts, then the cut-off B per slot */
     tmx::dbuf<uint32_t> ed_row_info;   /* per pending row: position among its batch's pending rows | batch << 20 */
