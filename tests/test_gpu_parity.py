@@ -901,9 +901,66 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
             with gs.ctx.option("ed_prefix_list", 0):
                 alt = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
             assert all(np.array_equal(x, y) for x, y in zip((cb, sb, db, vb), alt))
+            # the continuation on bit rows instead of the interval reductions; the first step one workgroup per
+            # hypothesis instead of sixteen hypotheses of a neighbourhood per workgroup
+            for opts in ({"ed_hist": 0}, {"ed_prefix_group": 0}, {"ed_hist": 0, "ed_prefix_group": 0}, {"ed_ball_list": 0},
+                         {"ed_prefix_group": 16}):
+                old_opts = {k: gs.ctx.get_option(k) for k in opts}
+                for k, v in opts.items():
+                    gs.ctx.set_option(k, v)
+                try:
+                    alt = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
+                finally:
+                    for k, v in old_opts.items():
+                        gs.ctx.set_option(k, v)
+                assert all(np.array_equal(x, y) for x, y in zip((cb, sb, db, vb), alt)), opts
         finally:
             gs.set_mask(None)
             os_.set_mask(None)
+
+
+def test_early_drop_interval_reductions_and_their_fallback(gpu_small, oracle_small, small_case, capfd):
+    """The continuation of the rule on interval reductions (k_ed_hist_wide) == the bit-array kernels == the oracle,
+    also where the reductions cannot decide and hand the row over: nothing is ever dropped (accept_prob 0) so every
+    checkpoint is visited, poses with a handful of in-grid points leave intervals without a test position, and
+    neighbourhoods of fewer than 20 points have coinciding checkpoints."""
+    gs, gm = gpu_small["scene"], gpu_small["model"]
+    os_, om = oracle_small["scene"], oracle_small["model"]
+    rng = np.random.default_rng(77)
+    near = random_poses_near_truth(small_case, 40, seed=5)
+    far = near.copy()
+    far[:, 12:15] += rng.normal(0, 0.45 * om.diameter, (len(far), 3)).astype(np.float32)  # mostly outside the grid
+    poses = np.concatenate([near, far])
+    tidx = np.nonzero(small_case["scene"]["tangent_mask"])[0]
+    cset = rng.choice(tidx, size=4, replace=False).astype(np.uint32)
+    centers = cset[rng.integers(0, 4, len(poses))]
+    res = small_case["resolution"]
+    fallbacks = 0
+    for radius, accept in ((om.diameter, 0.0), (om.diameter, 0.02), (om.diameter, 0.5), (2.5 * res, 0.0), (0.0, 0.0)):
+        gs.ctx.set_option("debug_ed", 1)
+        try:
+            got = gs.score_hypotheses_early_drop_ball(gm, poses, centers, radius, DT, accept)
+        finally:
+            gs.ctx.set_option("debug_ed", 0)
+        err = capfd.readouterr().err
+        for line in err.splitlines():
+            if "rows to the bit-array kernel" in line:
+                fallbacks += int(line.split("pending,")[1].split()[0])
+        with gs.ctx.option("ed_hist", 0):
+            want = gs.score_hypotheses_early_drop_ball(gm, poses, centers, radius, DT, accept)
+            with gs.ctx.option("ed_prefix_group", 0):
+                want2 = gs.score_hypotheses_early_drop_ball(gm, poses, centers, radius, DT, accept)
+        with gs.ctx.option("ed_ball_list", 0):
+            want3 = gs.score_hypotheses_early_drop_ball(gm, poses, centers, radius, DT, accept)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want3)), (radius, accept)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)), (radius, accept)
+        assert all(np.array_equal(x, y) for x, y in zip(got, want2)), (radius, accept)
+        for h in list(range(0, len(poses), 7)):
+            nn = os_.radius_subset(int(centers[h]), radius)
+            sc, mc, score, saved = os_.project(om, poses[h], accept, DT, subset=nn, early_out=True)
+            assert got[0][h] == len(sc) and got[3][h] == saved, (radius, accept, h)
+            assert abs(got[1][h] - score) <= SCORE_RTOL * abs(score) + SCORE_ATOL_PER_TERM * max(1, len(sc))
+    assert fallbacks > 0
 
 
 def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_case):
@@ -953,7 +1010,8 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     order = np.sort(c[sc > 0])
     for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
                 {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1}, {"ed_prefix_list": 0},
-                {"ed_wave_rows": 3, "search_segment": 300}):
+                {"ed_wave_rows": 3, "search_segment": 300}, {"ed_hist": 0}, {"ed_hist": 0, "ed_wave_rows": 0}, {"ed_prefix_group": 0}, {"ed_prefix_group": 0, "ed_hist": 0}, {"ed_ball_list": 0}, {"ed_prefix_group": 5},
+                {"ed_hist": 0, "search_segment": 300}):
         old_env = {k: gs.ctx.get_option(k) for k in env}
         for k, v in env.items():
             gs.ctx.set_option(k, v)

@@ -108,6 +108,9 @@ static const opt_entry kOptions[] = {
     {"search_per_range", &options::search_per_range, 0, 1},
     {"ed_wave_rows", &options::ed_wave_rows, 0, 1 << 19},
     {"ed_prefix_list", &options::ed_prefix_list, 0, 1},
+    {"ed_hist", &options::ed_hist, 0, 1},
+    {"ed_ball_list", &options::ed_ball_list, 0, 1},
+    {"ed_prefix_group", &options::ed_prefix_group, 0, 16},
 };
 }  // namespace tmx
 

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <unordered_map>
 #include <vector>
 
 namespace tmx {
@@ -49,6 +50,14 @@ struct ed_ball {
      * load instead of a gather through the index list, and voxel / model gathers that share lines (the scan order,
      * ascending scene index, is unrelated to space). [slots][plist_stride], plist_n[slot] entries; null = unused */
     const uint2* plist;
+    const float4* plist_p; /* (x, y, z, sorted slot) of the same entries */
+    /* every member of the neighbourhood the same way (entry = sorted slot, scan position; unmasked points only, a wave's
+     * 64 consecutive scene points together): what the continuation streams instead of looking up the rank of every
+     * scene point of a tile in the membership words (two gathers over addresses unrelated to space).
+     * [slots][blist_stride], blist_n[slot] entries; null = unused */
+    const uint2* blist;
+    const uint32_t* blist_n;
+    uint32_t blist_stride;
     const uint32_t* plist_n;
     uint32_t plist_stride;
 };
@@ -59,18 +68,35 @@ __global__ __launch_bounds__(256) void k_ball_prefix_list(const float4* __restri
                                                           const unsigned long long* __restrict__ member,
                                                           const uint32_t* __restrict__ wprefix, uint32_t mwords,
                                                           const uint32_t* __restrict__ B_of_slot, uint32_t stride,
-                                                          uint32_t* __restrict__ plist_n, uint2* __restrict__ plist) {
+                                                          uint32_t* __restrict__ plist_n, uint2* __restrict__ plist,
+                                                          float4* __restrict__ plist_p, uint32_t* __restrict__ blist_n,
+                                                          uint2* __restrict__ blist, uint32_t blist_stride) {
     const uint32_t sidx = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, lane = threadIdx.x & 63;
-    bool in = false;
+    bool in = false, member_pt = false;
     uint32_t pos = 0;
+    float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sidx < n_sorted) {
-        const float4 P = spos[sidx];
+        P = spos[sidx];
         if (P.x == P.x) { /* masked / non-finite / padding points carry NaN: they have no bits (reference :434) */
             const uint32_t orig = __float_as_uint(P.w);
             const unsigned long long mbits = member[(size_t)c * mwords + (orig >> 6)];
             if ((mbits >> (orig & 63u)) & 1ull) {
                 pos = wprefix[(size_t)c * mwords + (orig >> 6)] + (uint32_t)__popcll(mbits & ((1ull << (orig & 63u)) - 1ull));
+                member_pt = true;
                 in = pos < B_of_slot[c];
+            }
+        }
+    }
+    if (blist) { /* ed_ball::blist: every member, same order */
+        const unsigned long long ba = __ballot(member_pt);
+        if (ba) {
+            uint32_t base_a = 0;
+            const int leader_a = __ffsll((long long)ba) - 1;
+            if ((int)lane == leader_a) base_a = atomicAdd(&blist_n[c], (uint32_t)__popcll(ba));
+            base_a = __shfl(base_a, leader_a);
+            if (member_pt) {
+                const uint32_t e = base_a + (uint32_t)__popcll(ba & ((1ull << lane) - 1ull));
+                if (e < blist_stride) blist[(size_t)c * blist_stride + e] = make_uint2(sidx, pos);
             }
         }
     }
@@ -82,7 +108,10 @@ __global__ __launch_bounds__(256) void k_ball_prefix_list(const float4* __restri
     base = __shfl(base, leader);
     if (in) {
         const uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (e < stride) plist[(size_t)c * stride + e] = make_uint2(sidx, pos);
+        if (e < stride) {
+            plist[(size_t)c * stride + e] = make_uint2(sidx, pos);
+            plist_p[(size_t)c * stride + e] = make_float4(P.x, P.y, P.z, __uint_as_float(sidx));
+        }
     }
 }
 
@@ -618,6 +647,298 @@ __global__ __launch_bounds__(256) void k_ed_score_rows(ed_args a, const uint32_t
     }
 }
 
+/* Wide continuation without bit rows. The rule needs, per checkpoint k, (1) the first evaluated ("tail") scan
+ * position at or after x_k = max(tests[k], 1) - 1 and (2) the correspondences up to and including it. As long as
+ * every interval [x_k, x_k+1) holds a tail position — any hypothesis that is still alive after the first
+ * checkpoint has thousands — test k runs at m_k = min{tail pos >= x_k}, which lies inside that interval, and the
+ * positions between x_k and m_k have no bits at all, so
+ *     corrs_k = #{correspondences at pos < x_k} + [m_k is a correspondence].
+ * Both are order-free reductions over the neighbourhood: per row 19 interval counts, 19 interval sums of the
+ * fixed-point score terms, and 18 packed minima (position << 42 | not-a-correspondence << 41 | score term), kept in
+ * LDS per (row, super-tile) workgroup and merged with one global atomic per non-empty entry. k_ed_hist_walk then
+ * applies the rule to the 18 minima; a row with an empty interval before a later tail position (the next test
+ * position then depends on bit order), or with a score term that does not fit 41 bits, goes to the bit-array
+ * kernel through a fallback list — same outcome either way (tests: every option combination against the oracle).
+ * Layout of a row (kEdHistWords 64-bit words): [0, 10) 20 x u32 counts (19 intervals + overflow flag),
+ * [10, 29) sums, [29, 47) minima. */
+constexpr uint32_t kEdHistWords = 48, kEdHistFx = 10, kEdHistMin = 29;
+constexpr uint32_t kEdHistPosBits = 22; /* scan positions below 4,194,304 */
+constexpr int kEdNT = 4;                /* evaluations a lane keeps in flight (eval_points_staged) */
+
+__global__ __launch_bounds__(256) void k_ed_hist_init(unsigned long long* __restrict__ hist,
+                                                      const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                      uint32_t rows_cap, uint32_t* __restrict__ fb_n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 2u) fb_n[i] = 0u;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    if (i < n_rows * kEdHistWords) hist[i] = (i % kEdHistWords) >= kEdHistMin ? ~0ull : 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_ed_hist_wide(ed_args a, ed_cull ca, const uint32_t* __restrict__ pending,
+                                                      const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                      uint32_t rows_cap, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned long long s_h[kEdHistWords];
+    __shared__ uint32_t s_x[18];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t u = blockIdx.x; /* super-tile of this workgroup; wave w takes its tiles 16 w .. 16 w + 15 */
+    if (u * 64u >= ca.n_tiles || ed_stopped(a)) return;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    const float4 sb = ca.supers[u];
+    const uint32_t t = u * 64u + wave * 16u + (lane & 15u);
+    const bool have_tile = lane < 16u && t < ca.n_tiles;
+    const float4 tbs = have_tile ? ca.tiles[t] : make_float4(0.f, 0.f, 0.f, -1.f);
+    const float ball_margin = 1e-5f * a.ball.radius + 4e-6f * ca.coord_max + 1e-12f;
+    uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_h);
+    for (uint32_t row = blockIdx.y; row < n_rows; row += gridDim.y) {
+        if (!ed_row_selected(a, row0 + row)) continue;
+        const uint32_t hl = pending[row0 + row];
+        const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+        const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                                  ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                                  T.r22 * T.r22);
+        const float abs_eps = 1e-6f * (3.f * rnorm * ca.coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f);
+        const uint32_t slot = a.ball.slot_of_hyp[a.h0 + hl];
+        const float4 C = a.ball.centre_pos[slot];
+        const f3 bc = make3(C.x, C.y, C.z);
+        /* the super-tile as a whole (the same test in every lane), then one tile per lane */
+        bool shit = sphere_hits_box(a.sc, T, rnorm, abs_eps, sb);
+        shit = shit && !(len(make3(sb.x, sb.y, sb.z) - bc) > a.ball.radius + sb.w * 1.00001f + ball_margin);
+        if (!shit) continue;
+        bool hit = have_tile && sphere_hits_box(a.sc, T, rnorm, abs_eps, tbs);
+        hit = hit && !(len(make3(tbs.x, tbs.y, tbs.z) - bc) > a.ball.radius + tbs.w * 1.00001f + ball_margin);
+        unsigned long long tmask = __ballot(hit);
+        const uint32_t S = a.ball.S_of_slot[slot];
+        const uint32_t* tests = a.ball.tests_of_slot + 18u * slot;
+        if (threadIdx.x < kEdHistWords) s_h[threadIdx.x] = threadIdx.x >= kEdHistMin ? ~0ull : 0ull;
+        if (threadIdx.x >= 64u && threadIdx.x < 82u) {
+            const uint32_t tk = tests[threadIdx.x - 64u];
+            s_x[threadIdx.x - 64u] = tk > 0u ? tk - 1u : 0u;
+        }
+        __syncthreads();
+        const float per_pos = S ? 20.f / (float)S : 0.f;
+        const unsigned long long* member = a.ball.member + (size_t)slot * a.ball.mwords;
+        const uint32_t* wprefix = a.ball.wprefix + (size_t)slot * a.ball.mwords;
+        while (tmask) { /* kEdNT tiles per turn, their evaluations level by level (eval_points_staged) */
+            uint32_t sidx[kEdNT], pos[kEdNT];
+            f3 pt[kEdNT];
+            bool live[kEdNT], tail[kEdNT], corr[kEdNT];
+            long long fx[kEdNT];
+            float4 P[kEdNT];
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                live[i] = tmask != 0ull;
+                const uint32_t tile = u * 64u + wave * 16u + (live[i] ? (uint32_t)__builtin_ctzll(tmask) : 0u);
+                tmask &= tmask - 1ull;
+                sidx[i] = tile * 64u + lane;
+                P[i] = live[i] ? ca.spos[sidx[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            unsigned long long mbits[kEdNT];
+            uint32_t wp[kEdNT];
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                live[i] = live[i] && (P[i].x == P[i].x); /* mask_ (:434), non-finite, padding */
+                const uint32_t orig = __float_as_uint(P[i].w);
+                mbits[i] = live[i] ? member[orig >> 6] : 0ull;
+                wp[i] = live[i] ? wprefix[orig >> 6] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                const uint32_t orig = __float_as_uint(P[i].w);
+                live[i] = live[i] && ((mbits[i] >> (orig & 63u)) & 1ull);
+                pos[i] = wp[i] + (uint32_t)__popcll(mbits[i] & ((1ull << (orig & 63u)) - 1ull));
+                pt[i] = make3(P[i].x, P[i].y, P[i].z);
+            }
+            eval_points_staged<kEdNT>(a.sc, [&](int) -> const pose12& { return T; }, pt, sidx, live, tail, corr, fx);
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                if (!tail[i]) continue;
+                /* interval of pos: j = #{k : x_k <= pos}; the guess is exact up to the rounding of tests[] */
+                uint32_t j = min(18u, (uint32_t)((float)(pos[i] + 1u) * per_pos));
+                while (j < 18u && s_x[j] <= pos[i]) ++j;
+                while (j > 0u && s_x[j - 1u] > pos[i]) --j;
+                if (corr[i]) {
+                    atomicAdd(&s_cnt[j], 1u);
+                    atomicAdd(&s_h[kEdHistFx + j], (unsigned long long)fx[i]);
+                    if ((unsigned long long)fx[i] >> 41) atomicAdd(&s_cnt[19], 1u);
+                }
+                if (j > 0u) {
+                    const unsigned long long key = ((unsigned long long)pos[i] << 42) | (corr[i] ? 0ull : 1ull << 41) |
+                                                   (corr[i] ? ((unsigned long long)fx[i] & ((1ull << 41) - 1ull)) : 0ull);
+                    if (key < s_h[kEdHistMin + j - 1u]) atomicMin(&s_h[kEdHistMin + j - 1u], key);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kEdHistWords - 1u) {
+            const unsigned long long v = s_h[threadIdx.x];
+            unsigned long long* g = hist + (size_t)row * kEdHistWords + threadIdx.x;
+            if (threadIdx.x < kEdHistMin) {
+                if (v) atomicAdd(g, v);
+            } else if (v != ~0ull)
+                atomicMin(g, v);
+        }
+        __syncthreads();
+    }
+}
+
+/* The same reductions from the neighbourhood's own list in curve order (ed_ball::blist) instead of the scene's
+ * tiles: workgroup (c, y) takes entries [2048 c, 2048 c + 2048) of the list of every row it visits. No sphere tests
+ * (the rows are hypotheses that passed the first checkpoint: most of their neighbourhood lands in the grid anyway)
+ * and no rank look-ups — the position rides in the entry. A point inside the grid whose super-brick has no brick in
+ * reach of the surface is a test position at most (score_args::super_near). */
+constexpr uint32_t kEdListChunk = 256u * 2u * (uint32_t)kEdNT;
+__global__ __launch_bounds__(256) void k_ed_hist_list(ed_args a, const float4* __restrict__ spos,
+                                                      const uint32_t* __restrict__ pending,
+                                                      const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                      uint32_t rows_cap, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned long long s_h[kEdHistWords];
+    __shared__ uint32_t s_x[18];
+    if (ed_stopped(a)) return;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_h);
+    const uint32_t e_base = blockIdx.x * kEdListChunk;
+    const uint32_t run = (n_rows + gridDim.y - 1u) / gridDim.y; /* consecutive rows per workgroup */
+    for (uint32_t row = blockIdx.y * run; row < min(n_rows, (blockIdx.y + 1u) * run); ++row) {
+        if (!ed_row_selected(a, row0 + row)) continue;
+        const uint32_t hl = pending[row0 + row];
+        const uint32_t slot = a.ball.slot_of_hyp[a.h0 + hl];
+        const uint32_t n_e = min(a.ball.blist_n[slot], a.ball.blist_stride);
+        if (e_base >= n_e) continue;
+        const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + hl) * 16);
+        const uint32_t S = a.ball.S_of_slot[slot];
+        const uint32_t* tests = a.ball.tests_of_slot + 18u * slot;
+        if (threadIdx.x < kEdHistWords) s_h[threadIdx.x] = threadIdx.x >= kEdHistMin ? ~0ull : 0ull;
+        if (threadIdx.x >= 64u && threadIdx.x < 82u) {
+            const uint32_t tk = tests[threadIdx.x - 64u];
+            s_x[threadIdx.x - 64u] = tk > 0u ? tk - 1u : 0u;
+        }
+        __syncthreads();
+        const float per_pos = S ? 20.f / (float)S : 0.f;
+        const uint2* bl = a.ball.blist + (size_t)slot * a.ball.blist_stride;
+        for (uint32_t r = 0; r < 2u; ++r) {
+            uint32_t sidx[kEdNT], pos[kEdNT];
+            f3 pt[kEdNT];
+            bool live[kEdNT], tail[kEdNT], corr[kEdNT];
+            long long fx[kEdNT];
+            uint2 en[kEdNT];
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                const uint32_t e = e_base + (r * (uint32_t)kEdNT + (uint32_t)i) * 256u + threadIdx.x;
+                live[i] = e < n_e;
+                en[i] = live[i] ? bl[e] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                const float4 P = live[i] ? spos[en[i].x] : make_float4(0.f, 0.f, 0.f, 0.f);
+                sidx[i] = en[i].x;
+                pos[i] = en[i].y;
+                pt[i] = make3(P.x, P.y, P.z);
+            }
+            eval_points_staged<kEdNT>(a.sc, [&](int) -> const pose12& { return T; }, pt, sidx, live, tail, corr, fx);
+#pragma unroll
+            for (int i = 0; i < kEdNT; ++i) {
+                if (!tail[i]) continue;
+                /* interval of pos: j = #{k : x_k <= pos}; the guess is exact up to the rounding of tests[] */
+                uint32_t j = min(18u, (uint32_t)((float)(pos[i] + 1u) * per_pos));
+                while (j < 18u && s_x[j] <= pos[i]) ++j;
+                while (j > 0u && s_x[j - 1u] > pos[i]) --j;
+                if (corr[i]) {
+                    atomicAdd(&s_cnt[j], 1u);
+                    atomicAdd(&s_h[kEdHistFx + j], (unsigned long long)fx[i]);
+                    if ((unsigned long long)fx[i] >> 41) atomicAdd(&s_cnt[19], 1u);
+                }
+                if (j > 0u) {
+                    const unsigned long long key = ((unsigned long long)pos[i] << 42) | (corr[i] ? 0ull : 1ull << 41) |
+                                                   (corr[i] ? ((unsigned long long)fx[i] & ((1ull << 41) - 1ull)) : 0ull);
+                    if (key < s_h[kEdHistMin + j - 1u]) atomicMin(&s_h[kEdHistMin + j - 1u], key);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kEdHistWords - 1u) {
+            const unsigned long long v = s_h[threadIdx.x];
+            unsigned long long* g = hist + (size_t)row * kEdHistWords + threadIdx.x;
+            if (threadIdx.x < kEdHistMin) {
+                if (v) atomicAdd(g, v);
+            } else if (v != ~0ull)
+                atomicMin(g, v);
+        }
+        __syncthreads();
+    }
+}
+
+/* the rule on the reductions of k_ed_hist_wide: one thread per pending row */
+__global__ __launch_bounds__(64) void k_ed_hist_walk(ed_args a, ed_out o, float accept_thresh,
+                                                     const uint32_t* __restrict__ pending,
+                                                     const uint32_t* __restrict__ n_pending, uint32_t row0,
+                                                     uint32_t rows_cap, const unsigned long long* __restrict__ hist,
+                                                     uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_n) {
+    if (ed_stopped(a)) return;
+    const uint32_t row = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n_all = *n_pending;
+    const uint32_t n_rows = min(n_all > row0 ? n_all - row0 : 0u, rows_cap);
+    if (row >= n_rows || !ed_row_selected(a, row0 + row)) return;
+    const uint32_t hl = pending[row0 + row];
+    const uint32_t slot = a.ball.slot_of_hyp[a.h0 + hl];
+    const uint32_t S = a.ball.S_of_slot[slot];
+    const unsigned long long* h = hist + (size_t)row * kEdHistWords;
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(h);
+    bool fallback = cnt[19] != 0u;
+    uint32_t c = cnt[0];
+    unsigned long long f = h[kEdHistFx];
+    int32_t dropped = -1;
+    uint32_t drop_count = 0, drop_pos = 0;
+    unsigned long long drop_fx = 0;
+    for (uint32_t k = 0; k < 18u && !fallback; ++k) {
+        const unsigned long long key = h[kEdHistMin + k];
+        if (key == ~0ull) { /* no tail position in [x_k, x_k+1): fine only if none follows either */
+            for (uint32_t j = k + 1u; j < 18u; ++j) fallback = fallback || h[kEdHistMin + j] != ~0ull;
+            break;
+        }
+        const uint32_t pos = (uint32_t)(key >> 42);
+        const bool is_corr = !((key >> 41) & 1ull);
+        const uint32_t corrs = c + (is_corr ? 1u : 0u);
+        const uint32_t upper = early_drop_upper(pos + 1u, S, corrs);
+        if ((float)upper < accept_thresh) { /* reference :500 */
+            dropped = (int32_t)k;
+            drop_count = corrs;
+            drop_pos = pos;
+            drop_fx = f + (is_corr ? (key & ((1ull << 41) - 1ull)) : 0ull);
+            break;
+        }
+        c += cnt[k + 1u];
+        f += h[kEdHistFx + k + 1u];
+    }
+    if (fallback) {
+        fb_list[atomicAdd(fb_n, 1u)] = hl;
+        return;
+    }
+    const uint32_t hyp = a.h0 + hl;
+    if (dropped >= 0) {
+        o.counts[hyp] = drop_count;
+        o.dropped_at[hyp] = dropped;
+        o.saved[hyp] = S - (drop_pos + 1u);
+        o.limit[hyp] = drop_pos;
+        a.sc.scores_fx[hyp] = drop_fx;
+    } else {
+        /* every interval after the last test is in c / f already, or empty */
+        uint32_t ct = 0;
+        unsigned long long ft = 0;
+        for (uint32_t j = 0; j < 19u; ++j) {
+            ct += cnt[j];
+            ft += h[kEdHistFx + j];
+        }
+        o.counts[hyp] = ct;
+        o.dropped_at[hyp] = -1;
+        o.saved[hyp] = 0u;
+        o.limit[hyp] = S ? S - 1u : 0xFFFFFFFFu;
+        a.sc.scores_fx[hyp] = ft;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Fused variant: one workgroup does all three passes for its hypothesis with the two bit arrays in LDS
  * (LDS atomics instead of global ones, no memsets, one launch). Used whenever 2 * words * 8 bytes fit
@@ -918,6 +1239,191 @@ __global__ __launch_bounds__(256) void k_ed_fused(ed_args a, ed_cull ca, ed_out 
     } /* item */
 }
 
+/* The first step of the rule for up to 16 consecutive hypotheses per workgroup. Hypotheses in visit order come in
+ * runs that share their first scene point, i.e. their neighbourhood and its first-checkpoint list
+ * (ed_ball::plist_p). Two things made one workgroup per hypothesis (k_ed_fused<true>) slow: every turn of its loop
+ * had a few lanes whose point lands inside the voxel grid, so the whole wave went down the chain of dependent
+ * gathers (brick code, voxel, model point, refs) with most lanes idle; and the bit arrays in LDS. Here
+ *   phase 1  a thread takes eight list entries into registers and runs transform + in-grid test under every pose
+ *            of the run (the pose is uniform over the workgroup: scalar registers; no memory access at all); the
+ *            (hypothesis, entry) pairs that land in the grid are appended to a queue in LDS (wave ballots);
+ *   phase 2  the queue is evaluated with all lanes busy (pose of the lane's hypothesis from LDS);
+ * and checkpoint 0 only needs #{correspondences at pos < x_0} and the first evaluated position at or after x_0
+ * (see k_ed_hist_wide) — two reductions per hypothesis, no bit arrays. A hypothesis the first checkpoint does not
+ * drop, or whose list ends before a test position, goes to the continuation, which evaluates the whole rule. */
+#ifndef TM_ED_PK
+#define TM_ED_PK 4
+#endif
+constexpr uint32_t kEdPG = 16, kEdPK = TM_ED_PK, kEdPQ = 4096;
+#ifndef TM_ED_NTQ
+#define TM_ED_NTQ 2
+#endif
+constexpr int kEdNTQ = TM_ED_NTQ; /* queue entries a lane evaluates together */
+__global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, float accept_thresh, uint32_t n_hyp,
+                                                         uint32_t G, uint32_t sb_lds_words,
+                                                         uint32_t* __restrict__ pending,
+                                                         uint32_t* __restrict__ n_pending) {
+    extern __shared__ uint32_t s_sb[]; /* score_args::super_near, when it fits */
+    __shared__ uint32_t s_cnt[kEdPG], s_slot[kEdPG], s_over[kEdPG];
+    __shared__ unsigned long long s_fx[kEdPG], s_min[kEdPG];
+    __shared__ float s_pose[kEdPG * 16];
+    __shared__ uint32_t s_q[kEdPQ];
+    __shared__ uint32_t s_qn;
+    if (ed_stopped(a)) return;
+    uint32_t h_first, h_end;
+    if (a.rng_starts) { /* merged step: batch blockIdx.y, the step's segment of it */
+        const uint32_t b = blockIdx.y;
+        const uint32_t lo = a.rng_starts[b] + a.seg_step * a.seg_len;
+        const uint32_t hi = min(lo + a.seg_len, a.rng_starts[b + 1]);
+        h_first = lo + blockIdx.x * G;
+        if (blockIdx.x * G >= a.seg_len || h_first >= hi || a.rng_stop[b] != 0xFFFFFFFFu) return;
+        h_end = min(h_first + G, hi);
+    } else {
+        h_first = blockIdx.x * G;
+        if (h_first >= n_hyp) return;
+        h_end = min(h_first + G, n_hyp);
+    }
+    const uint32_t n_g = h_end - h_first, lane = threadIdx.x & 63u;
+    if (threadIdx.x < kEdPG) {
+        s_cnt[threadIdx.x] = 0u;
+        s_over[threadIdx.x] = 0u;
+        s_fx[threadIdx.x] = 0ull;
+        s_min[threadIdx.x] = ~0ull;
+        s_slot[threadIdx.x] = threadIdx.x < n_g ? a.ball.slot_of_hyp[a.h0 + h_first + threadIdx.x] : 0xFFFFFFFFu;
+    }
+    if (threadIdx.x < n_g * 16u) s_pose[threadIdx.x] = a.sc.poses[(size_t)(a.h0 + h_first) * 16 + threadIdx.x];
+    if (threadIdx.x == 0) s_qn = 0u;
+    for (uint32_t w = threadIdx.x; w < sb_lds_words; w += 256u) s_sb[w] = a.sc.super_near[w];
+    const uint32_t* const sbits = !a.sc.super_near ? nullptr : sb_lds_words ? s_sb : a.sc.super_near;
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < n_g;) {
+        const uint32_t slot = s_slot[g0];
+        uint32_t g1 = g0 + 1u;
+        while (g1 < n_g && s_slot[g1] == slot) ++g1;
+        const uint32_t S = a.ball.S_of_slot[slot];
+        const uint32_t t0 = a.ball.tests_of_slot[18u * slot];
+        const uint32_t x0 = t0 > 0u ? t0 - 1u : 0u;
+        const uint32_t S_words = (S + 63u) / 64u;
+        uint32_t B_words = (t0 + 1024u + 63u) / 64u;
+        if (B_words > S_words) B_words = S_words;
+        if (B_words > a.prefix_words) B_words = a.prefix_words;
+        const uint32_t n_pos = min(B_words * 64u, S);
+        const uint32_t n_e = min(min(a.ball.plist_n[slot], a.ball.plist_stride), 1u << 20);
+        const uint2* pl = a.ball.plist + (size_t)slot * a.ball.plist_stride;
+        const float4* pp = a.ball.plist_p + (size_t)slot * a.ball.plist_stride;
+        /* phase 2: the queued (hypothesis, entry) pairs, all lanes busy */
+        auto drain = [&]() {
+            __syncthreads();
+            const uint32_t n_q = s_qn;
+            for (uint32_t i0 = threadIdx.x; i0 < n_q; i0 += 256u * kEdNTQ) {
+                uint32_t g[kEdNTQ], sidx[kEdNTQ], pos[kEdNTQ];
+                f3 pt[kEdNTQ];
+                bool live[kEdNTQ], tail[kEdNTQ], corr[kEdNTQ];
+                long long fx[kEdNTQ];
+#pragma unroll
+                for (int i = 0; i < kEdNTQ; ++i) {
+                    const uint32_t qi = i0 + (uint32_t)i * 256u;
+                    live[i] = qi < n_q;
+                    const uint32_t ent = live[i] ? s_q[qi] : 0u, e = ent & 0xFFFFFu;
+                    g[i] = ent >> 20;
+                    const float4 P = live[i] ? pp[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    pos[i] = live[i] ? pl[e].y : 0u;
+                    pt[i] = make3(P.x, P.y, P.z);
+                    sidx[i] = __float_as_uint(P.w);
+                }
+                eval_points_staged<kEdNTQ>(a.sc, [&](int i) { return load_pose(s_pose + g[i] * 16u); }, pt, sidx, live, tail,
+                                          corr, fx);
+#pragma unroll
+                for (int i = 0; i < kEdNTQ; ++i) {
+                    if (!tail[i]) continue; /* live entries always are: phase 1 ran the same test */
+                    if (corr[i] && ((unsigned long long)fx[i] >> 41)) s_over[g[i]] = 1u;
+                    if (pos[i] < x0) {
+                        if (corr[i]) {
+                            atomicAdd(&s_cnt[g[i]], 1u);
+                            atomicAdd(&s_fx[g[i]], (unsigned long long)fx[i]);
+                        }
+                    } else {
+                        const unsigned long long key = ((unsigned long long)pos[i] << 42) | (corr[i] ? 0ull : 1ull << 41) |
+                                                       (corr[i] ? ((unsigned long long)fx[i] & ((1ull << 41) - 1ull)) : 0ull);
+                        if (key < s_min[g[i]]) atomicMin(&s_min[g[i]], key);
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_qn = 0u;
+            __syncthreads();
+        };
+        for (uint32_t e0 = 0; e0 < n_e; e0 += 256u * kEdPK) {
+            float4 P[kEdPK];
+            uint32_t pos[kEdPK]; /* 0xFFFFFFFF = no entry */
+#pragma unroll
+            for (uint32_t k = 0; k < kEdPK; ++k) {
+                const uint32_t e = e0 + k * 256u + threadIdx.x;
+                pos[k] = 0xFFFFFFFFu;
+                P[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < n_e) {
+                    P[k] = pp[e];
+                    const uint32_t q = pl[e].y;
+                    if (q < n_pos) pos[k] = q; /* the list was cut for this slot's B; a shorter prefix takes less */
+                }
+            }
+            for (uint32_t g = g0; g < g1; ++g) {
+                const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + h_first + g) * 16);
+#pragma unroll
+                for (uint32_t k = 0; k < kEdPK; ++k) {
+                    /* eval_point up to its in-grid test; a point in a super-brick without any brick in reach of the
+                     * surface is evaluated ("tail") but never a correspondence: it can only be the test position */
+                    f3 q;
+                    uint32_t brick, lin;
+                    bool in = ev_grid(a.sc, T, make3(P[k].x, P[k].y, P[k].z), q, brick, lin) && pos[k] != 0xFFFFFFFFu;
+                    if (in && sbits && !((sbits[brick >> 11] >> ((brick >> 6) & 31u)) & 1u)) {
+                        in = false;
+                        if (pos[k] >= x0) {
+                            const unsigned long long key = ((unsigned long long)pos[k] << 42) | (1ull << 41);
+                            if (key < s_min[g]) atomicMin(&s_min[g], key);
+                        }
+                    }
+                    const unsigned long long m = __ballot(in);
+                    if (m) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_qn, (uint32_t)__popcll(m));
+                        base = __shfl(base, 0);
+                        if (in) s_q[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (g << 20) | (e0 + k * 256u + threadIdx.x);
+                    }
+                }
+                /* one pose adds at most 2048 entries */
+                __syncthreads();
+                const uint32_t queued = s_qn;
+                __syncthreads(); /* everybody has read it before the next pose appends */
+                if (queued > kEdPQ - 256u * kEdPK) drain();
+            }
+        }
+        drain();
+        g0 = g1;
+    }
+    if (threadIdx.x < n_g) {
+        const uint32_t g = threadIdx.x, hl = h_first + g, hyp = a.h0 + hl;
+        const unsigned long long key = s_min[g];
+        bool decided = false;
+        if (key != ~0ull && !s_over[g]) {
+            const uint32_t S = a.ball.S_of_slot[s_slot[g]];
+            const uint32_t pos = (uint32_t)(key >> 42);
+            const bool is_corr = !((key >> 41) & 1ull);
+            const uint32_t corrs = s_cnt[g] + (is_corr ? 1u : 0u);
+            const uint32_t upper = early_drop_upper(pos + 1u, S, corrs);
+            if ((float)upper < accept_thresh) { /* reference :500: dropped at the first checkpoint */
+                o.counts[hyp] = corrs;
+                o.dropped_at[hyp] = 0;
+                o.saved[hyp] = S - (pos + 1u);
+                o.limit[hyp] = pos;
+                a.sc.scores_fx[hyp] = s_fx[g] + (is_corr ? (key & ((1ull << 41) - 1ull)) : 0ull);
+                decided = true;
+            }
+        }
+        if (!decided) pending[atomicAdd(n_pending, 1u)] = hl;
+    }
+}
+
 /* The pending list of one step in visit order: ascending hypothesis index (the prefix kernel appends in no order),
  * and per row its position among the pending rows of its batch | batch << 20 (ed_args::row_info). One workgroup,
  * rank sort in LDS for up to kPendingSortMax rows; a longer list is left as it is with position 0 everywhere, which
@@ -1031,9 +1537,73 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         hipError_t e = hipMemsetAsync(d_n, 0, 4, c->stream);
         if (e != hipSuccess) return e;
     }
-    const dim3 pgrid = n_ranges ? dim3(a.seg_len, n_ranges) : dim3(n_hyp);
-    hipLaunchKernelGGL(k_ed_fused<true>, pgrid, dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
-                       accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
+    if (c->opt.ed_prefix_group && a.ball.slot_of_hyp && a.ball.plist_p && a.S < (1u << kEdHistPosBits)) {
+        /* hypotheses per workgroup: as many as keep ~16k workgroups in the launch (65,536 hypotheses: 7.2 ms per batch
+         * with 16, 6.7 ms with 4; a search step has 14k hypotheses) */
+        const uint32_t G = c->opt.ed_prefix_group > 1 ? std::min<uint32_t>((uint32_t)c->opt.ed_prefix_group, kEdPG)
+                                                      : std::max(1u, std::min(kEdPG, n_hyp / 16384u));
+        const dim3 ggrid = n_ranges ? dim3((a.seg_len + G - 1u) / G, n_ranges) : dim3((n_hyp + G - 1u) / G);
+        const uint32_t sb_words = a.sc.super_near ? (uint32_t)(((size_t)(a.sc.n_super + 255u) / 256u) * 8u) : 0u;
+        const uint32_t sb_lds = sb_words * 4u <= 32u * 1024u ? sb_words : 0u;
+        hipLaunchKernelGGL(k_ed_prefix_group, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, a, o, accept_thresh,
+                           n_ranges ? 0u : n_hyp, G, sb_lds, s->ed_pending.p, d_n);
+    } else {
+        const dim3 pgrid = n_ranges ? dim3(a.seg_len, n_ranges) : dim3(n_hyp);
+        hipLaunchKernelGGL(k_ed_fused<true>, pgrid, dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
+                           accept_thresh, d_tests, s->oref.p, s->ed_pending.p, d_n);
+    }
+    const bool hist = c->opt.ed_hist && a.ball.slot_of_hyp && !c->opt.ed_narrow && fused_lds <= kEdFusedLdsMax &&
+                      a.S < (1u << kEdHistPosBits);
+    if (hist) {
+        /* continuation on interval reductions (k_ed_hist_wide): no bit rows, so every pending row fits one pass */
+        ed_args aw = a;
+        const uint32_t gs = (cu.n_tiles + 63u) / 64u;
+        const uint32_t wave_rows = check ? (uint32_t)c->opt.ed_wave_rows : 0u;
+        /* rows in visit order: the waves below need it, and consecutive rows are hypotheses of one first point with
+         * near-identical poses — a workgroup of k_ed_hist_list takes a run of them and finds the lines of the
+         * previous one in L1 / L2 */
+        if (s->ed_row_info.ensure(n_hyp) != TM_OK) return hipErrorOutOfMemory;
+        hipLaunchKernelGGL(k_pending_sort, dim3(1), dim3(1024), 0, c->stream, s->ed_pending.p, d_n, a.rng_starts, n_ranges,
+                           n_hyp, s->ed_row_info.p);
+        if (wave_rows) aw.row_info = s->ed_row_info.p;
+        if (s->ed_hist.ensure((size_t)n_hyp * kEdHistWords) != TM_OK || s->ed_fb.ensure((size_t)n_hyp + 2) != TM_OK)
+            return hipErrorOutOfMemory;
+        uint32_t* fb_n = s->ed_fb.p + n_hyp;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+        const uint32_t gy = std::min(n_hyp, 256u);
+        hipLaunchKernelGGL(k_ed_hist_init, dim3((uint32_t)(((size_t)n_hyp * kEdHistWords + 255) / 256)), dim3(256), 0,
+                           c->stream, s->ed_hist.p, d_n, 0u, n_hyp, fb_n);
+        for (uint32_t wave = 0; wave < (wave_rows ? 2u : 1u); ++wave) {
+            if (wave_rows) {
+                aw.ord_lo = wave == 0 ? 0u : wave_rows;
+                aw.ord_hi = wave == 0 ? wave_rows : 0xFFFFFFFFu;
+            }
+            if (aw.ball.blist)
+                hipLaunchKernelGGL(k_ed_hist_list, dim3((a.S + kEdListChunk - 1u) / kEdListChunk, gy), dim3(256), 0, c->stream,
+                                   aw, cu.spos, s->ed_pending.p, d_n, 0u, n_hyp, s->ed_hist.p);
+            else
+                hipLaunchKernelGGL(k_ed_hist_wide, dim3(gs, gy), dim3(256), 0, c->stream, aw, cu, s->ed_pending.p, d_n, 0u,
+                                   n_hyp, s->ed_hist.p);
+            hipLaunchKernelGGL(k_ed_hist_walk, dim3((n_hyp + 63u) / 64u), dim3(64), 0, c->stream, aw, o, accept_thresh,
+                               s->ed_pending.p, d_n, 0u, n_hyp, s->ed_hist.p, s->ed_fb.p, fb_n + wave);
+            /* rows the reductions cannot decide (an empty interval before a later test position): bit arrays in LDS */
+            ed_args af = a;
+            af.row_info = nullptr;
+            hipLaunchKernelGGL(k_ed_fused<false>, dim3(std::min<uint32_t>(n_hyp, (uint32_t)cus)), dim3(256), fused_lds,
+                               c->stream, af, cu, o, accept_thresh, d_tests, s->oref.p, s->ed_fb.p, fb_n + wave);
+            run_check();
+        }
+        if (c->opt.debug_ed) {
+            uint32_t h_fb[2] = {0u, 0u}, n_pend = 0;
+            (void)hipMemcpyAsync(h_fb, fb_n, 8, hipMemcpyDeviceToHost, c->stream);
+            (void)hipMemcpyAsync(&n_pend, d_n, 4, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            fprintf(stderr, "[early drop] interval reductions: %u pending, %u rows to the bit-array kernel\n", n_pend,
+                    h_fb[0] + h_fb[1]);
+        }
+        return hipGetLastError();
+    }
     if (rows_cap && a.ball.slot_of_hyp && a.tail_bits && a.corr_bits && !c->opt.ed_narrow) {
         /* wide continuation (ball mode: the scan order is the neighbourhood list): bits of all positions of the
          * pending hypotheses, then the rule and the score terms on those rows; rows_cap rows of bit arrays */
@@ -1082,9 +1652,49 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
     return hipGetLastError();
 }
 
+/* score_args::super_near: bit sb = some brick of super-brick sb has code <= code_max; a wave = 64 super-bricks */
+__global__ __launch_bounds__(256) void k_super_near(const unsigned char* __restrict__ bcode, uint32_t n_super,
+                                                    uint32_t code_max, uint32_t* __restrict__ bits) {
+    const uint32_t sb = blockIdx.x * 256 + threadIdx.x;
+    bool near = false;
+    if (sb < n_super) {
+        const uint4* p = reinterpret_cast<const uint4*>(bcode + (size_t)sb * 64);
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = p[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 4; ++j)
+                for (int b = 0; b < 4; ++b) near = near || ((w[j] >> (8 * b)) & 0xFFu) <= code_max;
+        }
+    }
+    const unsigned long long m = __ballot(near);
+    if ((threadIdx.x & 63u) == 0u) {
+        bits[sb >> 5] = (uint32_t)m;
+        bits[(sb >> 5) + 1u] = (uint32_t)(m >> 32);
+    }
+}
+
 }  // namespace tmx
 
 using namespace tmx;
+
+/* the super-brick bits that go with sc.bcode / sc.code_max (built once per threshold) */
+static int ed_super_filter(tm_model* m, score_args& sc) {
+    sc.super_near = nullptr;
+    if (!sc.bcode || sc.bcode != m->brick_code.p) return TM_OK;
+    const uint32_t n_super = (uint32_t)(m->voxel_slots / 4096u);
+    const size_t words = ((size_t)(n_super + 255u) / 256u) * 8u;
+    if (m->super_near_code != sc.code_max || m->super_near_src != sc.bcode) {
+        TM_FORWARD(m->super_near.ensure(words));
+        hipLaunchKernelGGL(k_super_near, dim3((n_super + 255u) / 256u), dim3(256), 0, m->ctx->stream, sc.bcode, n_super,
+                           sc.code_max, m->super_near.p);
+        TM_HIP_CHECK(hipGetLastError());
+        m->super_near_code = sc.code_max;
+        m->super_near_src = sc.bcode;
+    }
+    sc.super_near = m->super_near.p;
+    sc.n_super = n_super;
+    return TM_OK;
+}
 
 /* brick near-filter for the correspondence part of eval_point (same bound as the scoring kernel): a voxel
  * whose brick code exceeds code_max has no model point within thres; Euclidean metrics only */
@@ -1357,14 +1967,23 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
         B_max = std::max(B_max, h_B[k]);
     }
     const bool use_plist = c->opt.ed_prefix_list && B_max > 0;
+    /* the whole neighbourhoods the same way for the continuation (ed_ball::blist), while that stays below 1 GiB */
+    const bool use_blist = use_plist && c->opt.ed_hist && c->opt.ed_ball_list && (size_t)n_slots * list_stride * 8 <= (1ull << 30);
     if (use_plist) {
+        if (use_blist) {
+            TM_FORWARD(s->ed_blist.ensure((size_t)n_slots * list_stride));
+            TM_FORWARD(s->ed_blist_n.ensure(n_slots));
+            TM_HIP_CHECK(hipMemsetAsync(s->ed_blist_n.p, 0, (size_t)n_slots * 4, c->stream));
+        }
         TM_FORWARD(s->ed_plist.ensure((size_t)n_slots * B_max));
+        TM_FORWARD(s->ed_plist_p.ensure((size_t)n_slots * B_max));
         TM_FORWARD(s->ed_plist_n.ensure(2 * (size_t)n_slots));
         TM_HIP_CHECK(hipMemcpyAsync(s->ed_plist_n.p + n_slots, h_B.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, c->stream));
         TM_HIP_CHECK(hipMemsetAsync(s->ed_plist_n.p, 0, (size_t)n_slots * 4, c->stream));
         hipLaunchKernelGGL(k_ball_prefix_list, dim3((s->n_sorted + 255) / 256, n_slots), dim3(256), 0, c->stream, s->spos.p,
                            s->n_sorted, d_member.p, d_wprefix.p, mwords, s->ed_plist_n.p + n_slots, B_max, s->ed_plist_n.p,
-                           s->ed_plist.p);
+                           s->ed_plist.p, s->ed_plist_p.p, use_blist ? s->ed_blist_n.p : nullptr,
+                           use_blist ? s->ed_blist.p : nullptr, list_stride);
         TM_HIP_CHECK(hipGetLastError());
     }
     const uint64_t budget = 256ull << 20; /* bytes per bit array */
@@ -1384,8 +2003,12 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.ball.list_stride = list_stride;
     a.ball.radius = radius;
     a.ball.plist = use_plist ? s->ed_plist.p : nullptr;
+    a.ball.plist_p = use_plist ? s->ed_plist_p.p : nullptr;
     a.ball.plist_n = s->ed_plist_n.p;
     a.ball.plist_stride = B_max;
+    a.ball.blist = use_blist ? s->ed_blist.p : nullptr;
+    a.ball.blist_n = s->ed_blist_n.p;
+    a.ball.blist_stride = list_stride;
     a.sc.spos = nullptr;
     a.sc.spos3 = nullptr;
     a.sc.sref = s->sref.p; /* the culled kernel addresses scene points by their sorted slot */
@@ -1427,6 +2050,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     a.ord_hi = 0xFFFFFFFFu;
     a.prefix_words = ed_prefix_words(a.S);
     ed_brick_filter(m, dist_thres * m->resolution, a.sc);
+    TM_FORWARD(ed_super_filter(m, a.sc));
     ed_args as = a; /* k_ed_score addresses scene points by original index */
     as.sc.sref = s->oref.p;
     ed_cull cu;
@@ -1540,6 +2164,40 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
     return TM_OK;
 }
 
+/* distinct centres in ascending order and each hypothesis' slot among them; hypotheses come in runs of one centre
+ * (a few dozen distinct ones in 65,536), so a look-up per run and a sort of the distinct values replaces a sort of
+ * all hypotheses (1.5 ms of host time per batch) */
+static bool ed_slots_of_centres(const uint32_t* centers, uint32_t n_hyp, uint32_t n_scene, std::vector<uint32_t>& uniq,
+                                std::vector<uint32_t>& slot_of_hyp) {
+    std::unordered_map<uint32_t, uint32_t> id;
+    uint32_t prev = 0, prev_id = 0;
+    for (uint32_t h = 0; h < n_hyp; ++h) {
+        const uint32_t cidx = centers[h];
+        if (cidx >= n_scene) return false;
+        if (h == 0 || cidx != prev) {
+            auto it = id.find(cidx);
+            if (it == id.end()) {
+                it = id.emplace(cidx, (uint32_t)uniq.size()).first;
+                uniq.push_back(cidx);
+            }
+            prev = cidx;
+            prev_id = it->second;
+        }
+        slot_of_hyp[h] = prev_id;
+    }
+    std::vector<uint32_t> order(uniq.size()), remap(uniq.size());
+    for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return uniq[x] < uniq[y]; });
+    std::vector<uint32_t> sorted(uniq.size());
+    for (uint32_t k = 0; k < order.size(); ++k) {
+        remap[order[k]] = k;
+        sorted[k] = uniq[order[k]];
+    }
+    uniq.swap(sorted);
+    for (uint32_t h = 0; h < n_hyp; ++h) slot_of_hyp[h] = remap[slot_of_hyp[h]];
+    return true;
+}
+
 extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
                                                    const uint32_t* centers, float radius, float dist_thres,
                                                    float accept_prob, uint32_t* counts, double* scores,
@@ -1555,18 +2213,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
     TM_HIP_CHECK(hipSetDevice(c->device));
     /* distinct centres -> slots */
     std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
-        for (uint32_t h = 0; h < n_hyp; ++h) {
-            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
-            order[h] = {centers[h], h};
-        }
-        std::sort(order.begin(), order.end());
-        for (uint32_t k = 0; k < n_hyp; ++k) {
-            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
-            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
-        }
-    }
+    TM_REQUIRE(ed_slots_of_centres(centers, n_hyp, s->n, uniq, slot_of_hyp), TM_ERR_INVALID, "centre index out of range");
     TM_FORWARD(s->ed_slot.ensure(n_hyp));
     TM_FORWARD(s->w_poses.ensure((size_t)n_hyp * 16));
     TM_HIP_CHECK(hipMemcpyAsync(s->ed_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
@@ -1616,18 +2263,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball_dev(tm_scene* s, tm_model* m,
     tm_ctx* c = s->ctx;
     TM_HIP_CHECK(hipSetDevice(c->device));
     std::vector<uint32_t> uniq, slot_of_hyp(n_hyp);
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> order(n_hyp);
-        for (uint32_t h = 0; h < n_hyp; ++h) {
-            TM_REQUIRE(centers[h] < s->n, TM_ERR_INVALID, "centre index out of range");
-            order[h] = {centers[h], h};
-        }
-        std::sort(order.begin(), order.end());
-        for (uint32_t k = 0; k < n_hyp; ++k) {
-            if (k == 0 || order[k].first != order[k - 1].first) uniq.push_back(order[k].first);
-            slot_of_hyp[order[k].second] = (uint32_t)uniq.size() - 1;
-        }
-    }
+    TM_REQUIRE(ed_slots_of_centres(centers, n_hyp, s->n, uniq, slot_of_hyp), TM_ERR_INVALID, "centre index out of range");
     TM_FORWARD(s->ed_slot.ensure(n_hyp));
     TM_HIP_CHECK(hipMemcpyAsync(s->ed_slot.p, slot_of_hyp.data(), (size_t)n_hyp * 4, hipMemcpyHostToDevice, c->stream));
     TM_FORWARD(ed_ball_core(s, m, d_poses16, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres, accept_prob));

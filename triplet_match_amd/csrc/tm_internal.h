@@ -109,6 +109,13 @@ struct options {
                                  instead of the same positions in the scene's curve order */
     int ed_wave_rows = 8;     /* pending hypotheses per batch the continuation of a search step takes first (in visit
                                  order); the rest follows only for batches still without a sufficient one. 0 = all at once */
+    int ed_prefix_group = 1;  /* 0: the first step of the rule one workgroup per hypothesis (k_ed_fused<true>) instead of
+                                 up to 16 hypotheses of one neighbourhood per workgroup on interval reductions (1 = as many as
+                                 keep the launch at ~4096 workgroups, 2..16 = that many) */
+    int ed_ball_list = 1;     /* 0: the interval reductions walk the scene's tiles (k_ed_hist_wide) instead of the
+                                 neighbourhoods' own lists (k_ed_hist_list) */
+    int ed_hist = 1;          /* 0: the wide continuation keeps bit rows in global memory (k_ed_bits_wide / k_ed_walk /
+                                 k_ed_score_rows) instead of the interval reductions of k_ed_hist_wide */
     int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
 };
 
@@ -180,6 +187,11 @@ struct tm_model {
      * touching the big voxel table. */
     tmx::dbuf<uint32_t> brick_min_bits; /* f32 bits of min d2 per brick */
     tmx::dbuf<unsigned char> brick_code; /* floor(sqrt(min d2) / brick_q), clamped to 255 */
+    /* one bit per super-brick: does any of its 64 bricks pass `code <= super_near_code` (the early-drop kernels' first,
+     * LDS-resident filter); rebuilt when the threshold changes */
+    tmx::dbuf<uint32_t> super_near;
+    uint32_t super_near_code = 0xFFFFFFFFu;
+    const unsigned char* super_near_src = nullptr;
     /* the same two filters under a projector's intrinsic_distance (plane2: 2-D, cylinder: wrap-around in u), built
      * by tm_model_set_metric: per brick the quantised minimum over its voxels of (a) the intrinsic distance from the
      * voxel centre to the voxel's STORED nearest point (what a query in that voxel is tested against) and (b) the
@@ -263,8 +275,13 @@ struct tm_scene {
     bool tangent_idx_ready = false;
     tmx::dbuf<uint32_t> ed_tlist;      /* staging + CSR (rank, index) pairs of tm_scene_radius_tangent_lists */
     tmx::dbuf<uint2> ed_plist;         /* first-checkpoint positions of every neighbourhood in curve order */
+    tmx::dbuf<float4> ed_plist_p;      /* the same entries' (x, y, z, sorted slot): what k_ed_prefix_group streams */
+    tmx::dbuf<uint2> ed_blist;         /* every member of every neighbourhood in curve order (ed_ball::blist) */
+    tmx::dbuf<uint32_t> ed_blist_n;
     tmx::dbuf<uint32_t> ed_plist_n;    /* their counts, then the cut-off B per slot */
     tmx::dbuf<uint32_t> ed_row_info;   /* per pending row: position among its batch's pending rows | batch << 20 */
+    tmx::dbuf<unsigned long long> ed_hist; /* k_ed_hist_wide: interval counts / sums / minima per pending row */
+    tmx::dbuf<uint32_t> ed_fb;      /* rows k_ed_hist_walk hands to the bit-array kernel, + one count per wave */
     tmx::dbuf<uint32_t> ed_pending; /* hypotheses the prefix kernel of the early-drop rule hands to the full kernel, + count */
     tmx::dbuf<float4> ed_cpos;
     /* tm_search_batch: pairs, provenance, slot of a pair's first point, centre per hypothesis, result record */

@@ -1146,6 +1146,7 @@ int tm_model_destroy(tm_model* m) {
     m->voxels.release();
     m->brick_min_bits.release();
     m->brick_code.release();
+    m->super_near.release();
     m->brick_code_metric_pt.release();
     m->brick_code_metric_tile.release();
     m->seg_key.release();
@@ -1191,6 +1192,7 @@ int tm_model_build_voxels(tm_model* m) {
     TM_FORWARD(m->voxels.alloc(m->voxel_slots));
     TM_FORWARD(m->brick_min_bits.alloc(n_bricks));
     TM_FORWARD(m->brick_code.alloc(n_bricks));
+    m->super_near_code = 0xFFFFFFFFu; /* the early-drop kernels' super-brick bits are rebuilt on first use */
     m->brick_q = 0.25f * m->resolution;
     uint64_t per_block = 256ull * kVoxVPT;
     uint64_t blocks = (m->voxel_slots + per_block - 1) / per_block;

@@ -1674,6 +1674,11 @@ int tm_scene_destroy(tm_scene* s) {
     s->ed_row_info.release();
     s->ed_plist.release();
     s->ed_plist_n.release();
+    s->ed_plist_p.release();
+    s->ed_blist.release();
+    s->ed_blist_n.release();
+    s->ed_hist.release();
+    s->ed_fb.release();
     s->w_item_bin.release();
     s->w_items_sorted.release();
     s->w_item_hist.release();

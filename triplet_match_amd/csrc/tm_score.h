@@ -39,6 +39,8 @@ struct score_args {
     const unsigned char* bcode;  /* brick distance codes of the per-point near filter, or null (filter off) */
     const unsigned char* bcode_tile; /* brick codes of the tile-level distance-field test (= bcode for 3-D L2; the
                                         all-points field under a projector's metric), or null */
+    const uint32_t* super_near = nullptr; /* one bit per super-brick (16^3 voxels; index = brick >> 6): 1 = some brick
+                                             of it passes the bcode test. null = no such filter. Early-drop kernels */
     int bx, by;                  /* brick grid dims (x, y) */
     uint32_t code_max;           /* reject a voxel hit when its brick code exceeds this */
     int ablate;                  /* read only under TM_TIMING_EXPERIMENTS (see TM_ABLATE_EQ); 0 = full kernel */
@@ -54,45 +56,107 @@ struct score_args {
     float d2max; /* largest f32 whose sqrtf is <= thres: d2 <= d2max <=> !(sqrtf(d2) > thres) */
     uint32_t n_hyp;
     uint32_t hyp_per_block;
+    uint32_t n_super = 0; /* super-bricks behind super_near */
 };
 
-/* one (hypothesis, point) evaluation = reference include/impl/scene.hpp:432-490.
- * Returns 1 if the point becomes a correspondence; accumulates the fixed-point score term. */
-__device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12& T, f3 p,
-                                               uint32_t sorted_idx, long long& fx, uint32_t& pass,
-                                               uint32_t* model_idx, bool* in_grid = nullptr) {
-    f3 q = xform_point(T, p);
+/* One (hypothesis, point) evaluation = reference include/impl/scene.hpp:432-490, in the stages between its
+ * dependent loads. eval_point below is these stages in a row; kernels that keep several evaluations in flight
+ * (k_ed_hist_wide, k_ed_prefix_group) call the stages of four points level by level, so the four loads of a level
+ * are outstanding together. One source for the arithmetic either way. */
+/* transform + in-grid test (:436-452, voxel_query's bounds): q = T p, brick and bricked voxel index */
+__device__ __forceinline__ bool ev_grid(const score_args& a, const pose12& T, f3 p, f3& q, uint32_t& brick,
+                                        uint32_t& lin) {
+    q = xform_point(T, p);
     float vx = a.g.sx * q.x + a.g.tx;
     float vy = a.g.sy * q.y + a.g.ty;
     float vz = a.g.sz * q.z + a.g.tz;
     bool in = (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) & (vz < a.g.fez);
-    if (in_grid) *in_grid = in;
-    if (!in) return 0u;
+    brick = 0u;
+    lin = 0u;
+    if (!in) return false;
     const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-    const uint32_t brick = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
-    if (a.bcode) { /* exact-safe: every model point is farther than thres from this voxel's cell */
-        if ((uint32_t)a.bcode[brick] > a.code_max) return 0u;
-    }
-    uint32_t lin = brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)); /* bricked layout */
-    uint32_t m = a.vox[lin];
-    float4 mp = a.mpos[m];
+    brick = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
+    lin = brick * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u)); /* bricked layout */
+    return true;
+}
+/* distance test of the voxel's model point (:462-466) */
+__device__ __forceinline__ bool ev_dist(const score_args& a, f3 q, float4 mp) {
     if (a.kind == 0 || a.kind == 1) { /* identity / plane: 3-D L2 */
         float dx = q.x - mp.x, dy = q.y - mp.y, dz = q.z - mp.z;
         float d2 = (dx * dx + dy * dy) + dz * dz;
-        if (!(d2 <= a.d2max)) return 0u;
-    } else { /* plane2 (2-D) / cylinder (wrap-around): the traits' intrinsic_distance */
-        float dist = traits_distance(a.kind, a.radius, make3(q.x, q.y, q.z), make3(mp.x, mp.y, mp.z));
-        if (dist > a.dmax) return 0u;
+        return d2 <= a.d2max;
     }
-    ++pass;
-    float4 sr = a.sref[sorted_idx];
-    if (sr.w != mp.w) return 0u; /* use_tangent != is_tangent, reference :472 */
+    /* plane2 (2-D) / cylinder (wrap-around): the traits' intrinsic_distance */
+    float dist = traits_distance(a.kind, a.radius, make3(q.x, q.y, q.z), make3(mp.x, mp.y, mp.z));
+    return !(dist > a.dmax);
+}
+/* tangent flags (:472) and the score term (:476-486) in fixed point */
+__device__ __forceinline__ bool ev_term(const pose12& T, float4 sr, float4 mp, float4 mr, long long& fx) {
+    if (sr.w != mp.w) return false; /* use_tangent != is_tangent, reference :472 */
     f3 r = xform_dir(T, make3(sr.x, sr.y, sr.z));
-    float4 mr = a.mref[m];
     float term = fabsf(dot3(r, make3(mr.x, mr.y, mr.z)));
     fx += (long long)((double)term * kFx);
+    return true;
+}
+
+/* Returns 1 if the point becomes a correspondence; accumulates the fixed-point score term. */
+__device__ __forceinline__ uint32_t eval_point(const score_args& a, const pose12& T, f3 p,
+                                               uint32_t sorted_idx, long long& fx, uint32_t& pass,
+                                               uint32_t* model_idx, bool* in_grid = nullptr) {
+    f3 q;
+    uint32_t brick, lin;
+    const bool in = ev_grid(a, T, p, q, brick, lin);
+    if (in_grid) *in_grid = in;
+    if (!in) return 0u;
+    if (a.bcode) { /* exact-safe: every model point is farther than thres from this voxel's cell */
+        if ((uint32_t)a.bcode[brick] > a.code_max) return 0u;
+    }
+    uint32_t m = a.vox[lin];
+    float4 mp = a.mpos[m];
+    if (!ev_dist(a, q, mp)) return 0u;
+    ++pass;
+    float4 sr = a.sref[sorted_idx];
+    float4 mr = a.mref[m];
+    if (!ev_term(T, sr, mp, mr, fx)) return 0u;
     if (model_idx) *model_idx = m;
     return 1u;
+}
+
+/* N evaluations level by level (see above): live[i] in = the point takes part; out: tail[i] (in grid), corr[i],
+ * fx[i] (the score term). pose_at(i) = the pose of evaluation i (called twice: keep it cheap or a reference). */
+template <int N, class PoseAt>
+__device__ __forceinline__ void eval_points_staged(const score_args& a, PoseAt pose_at, const f3 (&p)[N],
+                                                   const uint32_t (&sorted_idx)[N], const bool (&live)[N],
+                                                   bool (&tail)[N], bool (&corr)[N], long long (&fx)[N]) {
+    f3 q[N];
+    uint32_t brick[N], lin[N], m[N];
+    bool near[N];
+    uint32_t code[N];
+    float4 mp[N], sr[N], mr[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        tail[i] = live[i] && ev_grid(a, pose_at(i), p[i], q[i], brick[i], lin[i]);
+        corr[i] = false;
+        fx[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) code[i] = (tail[i] && a.bcode) ? (uint32_t)a.bcode[brick[i]] : 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) near[i] = tail[i] && code[i] <= a.code_max;
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = near[i] ? a.vox[lin[i]] : 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) mp[i] = near[i] ? a.mpos[m[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) near[i] = near[i] && ev_dist(a, q[i], mp[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sr[i] = near[i] ? a.sref[sorted_idx[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mr[i] = near[i] ? a.mref[m[i]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (near[i]) corr[i] = ev_term(pose_at(i), sr[i], mp[i], mr[i], fx[i]);
 }
 
 /* Conservative culling test shared by the tile-culled kernels: can the sphere `tb` (centre xyz, radius w;
