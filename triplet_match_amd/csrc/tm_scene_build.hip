@@ -156,6 +156,19 @@ __global__ __launch_bounds__(256) void k_scene_morton(const float* __restrict__ 
     vals[i] = i;
 }
 
+/* live points of a 256-thread workgroup -> one atomic (one per wave on the same word serialises: 16k of them cost
+ * more than the pass over the points) */
+__device__ __forceinline__ void block_count_live(bool live, unsigned int* total) {
+    __shared__ unsigned int s_n[4];
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = (unsigned int)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+        if (t) atomicAdd(total, t);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_scene_gather(const float* __restrict__ cloud,
                                                       const int32_t* __restrict__ tmask,
                                                       const int32_t* __restrict__ mask,
@@ -182,8 +195,39 @@ __global__ __launch_bounds__(256) void k_scene_gather(const float* __restrict__ 
         spos3[3 * (size_t)k + 1] = p.y;
         spos3[3 * (size_t)k + 2] = p.z;
     }
-    unsigned long long b = __ballot(live);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&bnd->live, (unsigned int)__popcll(b));
+    block_count_live(live, &bnd->live);
+}
+
+/* tm_scene_set_mask on a scene that is already sorted: only x of a point (NaN = not live) depends on mask_, so the
+ * sorted arrays are patched in place — one coalesced pass over spos and a 4-byte look-up of the mask per point
+ * instead of re-gathering 48-byte surfels through the order (0.17 ms per million points, twice per search). Same
+ * result as k_scene_gather: live = finite and unmasked, y / z / index / sref do not change. */
+__global__ __launch_bounds__(256) void k_scene_remask(const float* __restrict__ cloud,
+                                                      const int32_t* __restrict__ mask, uint32_t n,
+                                                      float4* __restrict__ spos, float* __restrict__ spos3,
+                                                      scene_bounds* __restrict__ bnd) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    bool live = false;
+    if (k < n) {
+        float4 p = spos[k];
+        const uint32_t i = __float_as_uint(p.w);
+        const bool was_live = p.x == p.x;
+        float x = p.x;
+        if (mask[i] != 0)
+            live = false;
+        else if (was_live)
+            live = true;
+        else {
+            x = cloud[12 * (size_t)i];
+            live = finite3(x, p.y, p.z);
+        }
+        if (live != was_live) {
+            p.x = live ? x : __builtin_nanf("");
+            spos[k] = p;
+            spos3[3 * (size_t)k] = p.x;
+        }
+    }
+    block_count_live(live, &bnd->live);
 }
 
 __device__ __forceinline__ double wave_min(double v) {
@@ -413,8 +457,12 @@ int scene_build(tm_scene* s, bool resort) {
     } else {
         TM_HIP_CHECK(hipMemsetAsync(&bnd->live, 0, 4, c->stream));
     }
-    hipLaunchKernelGGL(k_scene_gather, dim3(n_pad / 256), blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p,
-                       s->d_mask.p, s->d_order.p, n, n_pad, s->spos.p, s->spos3.p, s->sref.p, bnd);
+    if (!resort && s->n_sorted == n_pad)
+        hipLaunchKernelGGL(k_scene_remask, dim3(n_pad / 256), blk, 0, c->stream, s->d_cloud.p, s->d_mask.p, n, s->spos.p,
+                           s->spos3.p, bnd);
+    else
+        hipLaunchKernelGGL(k_scene_gather, dim3(n_pad / 256), blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p,
+                           s->d_mask.p, s->d_order.p, n, n_pad, s->spos.p, s->spos3.p, s->sref.p, bnd);
     hipLaunchKernelGGL(k_scene_tiles, dim3((n_tiles + 3) / 4), blk, 0, c->stream, s->spos.p, n_tiles, s->tiles.p);
     hipLaunchKernelGGL(k_scene_subs, dim3((n_tiles + 3) / 4), blk, 0, c->stream, s->spos.p, n_tiles, s->subs.p);
     hipLaunchKernelGGL(k_scene_supers, dim3(n_super), blk, 0, c->stream, s->spos.p, n_pad, 4096u, s->supers.p);
