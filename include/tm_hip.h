@@ -7,8 +7,12 @@
  * reference interface it replaces (paths relative to the reference tree).
  *
  * Conventions: opaque handles; int status return (0 = TM_OK, negative = error, text via
- * tm_last_error()); caller-owned buffers; no exceptions cross the ABI; one HIP stream per context;
- * a context and the handles created from it are used by one thread at a time.
+ * tm_last_error(), per thread); caller-owned buffers; no exceptions cross the ABI; one HIP stream per context.
+ * Thread-safe per handle: every entry point that takes a context, or a model / scene / cloud / communicator created
+ * from it, holds that context's mutex for the call, so calls from several threads on one context serialise (the
+ * reference's workers call model::query / voxel_query / radius_search concurrently, include/impl/scene.hpp:146-166);
+ * contexts are independent of each other. Destroying a handle while another thread is inside a call on it is the
+ * caller's error, as with any C handle. The pure functions (tm_feature, tm_murmur3_32, tm_traits_* ...) take no lock.
  * Pointers are HOST pointers unless the parameter name starts with `d_` (device, on the ctx device).
  *
  * Layouts:

@@ -1257,3 +1257,38 @@ def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case):
     sub = gpu_ctx.cloud_curvature_subset(cloud, idx, 30)
     assert np.array_equal(sub.view(np.uint32), full[idx].view(np.uint32)) and (sub[0] == 0).all()
     assert len(idx) > 100
+
+
+def test_concurrent_calls_on_one_context(gpu_small, small_case):
+    """SURVEY §8b: thread-safe per handle. The reference's workers call model::query / voxel_query and score from
+    several threads at once (include/impl/scene.hpp:146-166,304); calls on one context serialise on its mutex, so
+    four threads that score different batches, query the table and look up voxels concurrently (ctypes releases the GIL
+    for the duration of a call) get what they get one after the other."""
+    import threading
+    gs, gm = gpu_small["scene"], gpu_small["model"]
+    batches = [random_poses_near_truth(small_case, 96, seed=40 + t) for t in range(4)]
+    want = [gs.score_hypotheses(gm, b, DT) for b in batches]
+    pts = small_case["model"][::97, :4].astype(np.float32).copy()
+    want_vox = [gm.voxel_query(p) for p in pts]
+    got = [None] * 4
+    vox = [None] * 4
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(6):
+                got[t] = gs.score_hypotheses(gm, batches[t], DT)
+                vox[t] = [gm.voxel_query(p) for p in pts]
+                gs.radius_subset(int(t), float(gm.diameter))
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1])
+        assert vox[t] == want_vox

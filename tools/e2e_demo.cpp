@@ -64,11 +64,12 @@ int main(int argc, char** argv) {
         auto t3 = std::chrono::steady_clock::now();
         auto again = s.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
         auto t4 = std::chrono::steady_clock::now();
-        printf("%s call %.3f s -> %zu matches\n", r == 0 ? "second" : "further", std::chrono::duration<double>(t4 - t3).count(),
+        printf("%s call %.4f s -> %zu matches\n", r == 0 ? "second" : "further", std::chrono::duration<double>(t4 - t3).count(),
                again.size());
         const auto& st = s.last_stats();
-        printf("   phases [s]: radius %.3f sample %.3f generate+score %.3f extract %.3f icp %.3f arbitration %.3f mask %.3f | "
-               "total %.3f\n", st.radius, st.sample, st.generate_score, st.extract, st.icp, st.arbitration, st.mask, st.total);
+        printf("   phases [ms]: radius %.2f sample %.2f generate+score %.2f extract %.2f icp %.2f arbitration %.2f mask %.2f | "
+               "total %.2f\n", 1e3 * st.radius, 1e3 * st.sample, 1e3 * st.generate_score, 1e3 * st.extract, 1e3 * st.icp,
+               1e3 * st.arbitration, 1e3 * st.mask, 1e3 * st.total);
         printf("   sampling: %llu rounds, %llu first points sampled, %llu positions drawn, %llu neighbourhood entries handed over\n",
                (unsigned long long)st.rounds, (unsigned long long)st.firsts_sampled, (unsigned long long)st.draws,
                (unsigned long long)st.neighbours);

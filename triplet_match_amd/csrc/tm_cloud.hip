@@ -42,6 +42,10 @@ struct tm_cloud {
 };
 
 namespace tmx {
+inline ctx_guard guard_of(const tm_cloud* c) { return guard_of(c ? c->ctx : nullptr); }
+}  // namespace tmx
+
+namespace tmx {
 
 constexpr int kCloudStack = 24;
 constexpr int kCloudK = 32;       /* capacity of the in-LDS neighbour list */
@@ -249,6 +253,7 @@ extern "C" {
 
 int tm_cloud_create(tm_ctx* ctx, const float* surfels, uint32_t n, const uint32_t* subset, uint32_t n_subset,
                     tm_cloud** out) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && out && (surfels || n == 0), TM_ERR_INVALID, "tm_cloud_create: null argument");
     TM_REQUIRE(subset || n_subset == 0, TM_ERR_INVALID, "tm_cloud_create: null subset");
     *out = nullptr;
@@ -309,7 +314,9 @@ int tm_cloud_create(tm_ctx* ctx, const float* surfels, uint32_t n, const uint32_
 
 int tm_cloud_destroy(tm_cloud* c) {
     if (!c) return TM_OK;
+    tmx::ctx_guard tm_guard_;
     if (ctx_alive(c->ctx)) {
+        tm_guard_ = tmx::guard_of(c->ctx);
         (void)hipSetDevice(c->ctx->device);
         (void)hipStreamSynchronize(c->ctx->stream);
         c->kd_lo.release();
@@ -326,10 +333,12 @@ int tm_cloud_destroy(tm_cloud* c) {
     return TM_OK;
 }
 
-uint32_t tm_cloud_tree_size(const tm_cloud* c) { return c ? c->n_kd : 0u; }
+uint32_t tm_cloud_tree_size(const tm_cloud* c) {
+    TM_GUARD(c); return c ? c->n_kd : 0u; }
 
 int tm_cloud_knn(tm_cloud* c, const float* queries_xyz, uint32_t n_queries, uint32_t k, int32_t* indices,
                  float* sq_dists, uint32_t* counts) {
+    TM_GUARD(c);
     TM_REQUIRE(c && (queries_xyz || n_queries == 0) && indices && sq_dists, TM_ERR_INVALID,
                "tm_cloud_knn: null argument");
     TM_REQUIRE(k >= 1, TM_ERR_INVALID, "tm_cloud_knn: k must be at least 1");
@@ -391,6 +400,7 @@ int tm_cloud_knn(tm_cloud* c, const float* queries_xyz, uint32_t n_queries, uint
 
 int tm_cloud_radius_search(tm_cloud* c, const float query_xyz[3], float radius, int32_t* indices, float* sq_dists,
                            uint32_t cap, uint32_t* count) {
+    TM_GUARD(c);
     TM_REQUIRE(c && query_xyz && count, TM_ERR_INVALID, "tm_cloud_radius_search: null argument");
     *count = 0;
     if (!(radius >= 0.f) || c->n_kd == 0) return TM_OK;
@@ -416,6 +426,7 @@ int tm_cloud_radius_search(tm_cloud* c, const float query_xyz[3], float radius, 
  * explicit neighbour list, as curvature(float r, idx) feeds it (:206-209). Same arithmetic as k_curvature. */
 int tm_cloud_curvature_of(const tm_cloud* c, uint32_t idx, const int32_t* neighbours, uint32_t n_neighbours,
                           float curv5[5]) {
+    TM_GUARD(c);
     TM_REQUIRE(c && curv5 && (neighbours || n_neighbours == 0), TM_ERR_INVALID, "tm_cloud_curvature_of: null argument");
     TM_REQUIRE(idx < c->n, TM_ERR_INVALID, "tm_cloud_curvature_of: index out of range");
     for (int k = 0; k < 5; ++k) curv5[k] = 0.f;

@@ -171,6 +171,10 @@ struct tm_comm {
     tmx::dbuf<tm_best_record> d_local, d_all;
 };
 
+namespace tmx {
+inline ctx_guard guard_of(const tm_comm* c) { return guard_of(c ? c->ctx : nullptr); }
+}  // namespace tmx
+
 using namespace tmx;
 
 extern "C" {
@@ -186,6 +190,7 @@ int tm_comm_get_unique_id(unsigned char id[TM_COMM_ID_BYTES]) {
 }
 
 int tm_comm_create(tm_ctx* ctx, int rank, int world, const unsigned char id[TM_COMM_ID_BYTES], tm_comm** out) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && out, TM_ERR_INVALID, "tm_comm_create: null argument");
     TM_REQUIRE(world >= 1 && rank >= 0 && rank < world, TM_ERR_INVALID, "tm_comm_create: bad rank / world");
     *out = nullptr;
@@ -220,7 +225,9 @@ int tm_comm_create(tm_ctx* ctx, int rank, int world, const unsigned char id[TM_C
 
 int tm_comm_destroy(tm_comm* c) {
     if (!c) return TM_OK;
+    tmx::ctx_guard tm_guard_;
     if (ctx_alive(c->ctx)) {
+        tm_guard_ = tmx::guard_of(c->ctx);
         (void)hipSetDevice(c->ctx->device);
         (void)hipStreamSynchronize(c->ctx->stream);
         c->d_local.release();
@@ -231,12 +238,15 @@ int tm_comm_destroy(tm_comm* c) {
     return TM_OK;
 }
 
-int tm_comm_rank(const tm_comm* c) { return c ? c->rank : 0; }
-int tm_comm_world(const tm_comm* c) { return c ? c->world : 1; }
+int tm_comm_rank(const tm_comm* c) {
+    TM_GUARD(c); return c ? c->rank : 0; }
+int tm_comm_world(const tm_comm* c) {
+    TM_GUARD(c); return c ? c->world : 1; }
 
 int tm_best_of_batch_prov(tm_ctx* c, const uint32_t* d_counts, const double* d_scores, const float* d_poses16,
                           const uint32_t* d_provenance4, uint32_t n_hyp, uint32_t pair_offset, uint32_t pair_stride,
                           uint32_t query_limit, tm_best_record* d_best) {
+    TM_GUARD(c);
     TM_REQUIRE(c && d_best, TM_ERR_INVALID, "tm_best_of_batch_prov: null argument");
     TM_REQUIRE((d_counts && d_scores && d_poses16 && d_provenance4) || n_hyp == 0, TM_ERR_INVALID,
                "tm_best_of_batch_prov: null device buffers");
@@ -261,6 +271,7 @@ int tm_comm_probe(void) {
  * records an event and returns; _end waits for that event only. Between the two the caller may queue further
  * work on the context (the next batch), which then overlaps the exchange. */
 int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models, int* ticket) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && d_local && ticket, TM_ERR_INVALID, "tm_best_reduce_begin: null argument");
     TM_REQUIRE(n_models >= 1, TM_ERR_INVALID, "tm_best_reduce_begin: no records");
     TM_REQUIRE(!comm || comm->ctx == ctx, TM_ERR_INVALID, "tm_best_reduce_begin: communicator of another context");
@@ -306,6 +317,7 @@ int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_loc
 }
 
 int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && best, TM_ERR_INVALID, "tm_best_reduce_end: null argument");
     TM_REQUIRE(ticket >= 0 && ticket < kReduceSlots && ctx->red[ticket].busy, TM_ERR_INVALID,
                "tm_best_reduce_end: no reduction in flight under this ticket");
@@ -319,6 +331,7 @@ int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best) {
 /* both halves in one call */
 int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models,
                    tm_best_record* best) {
+    TM_GUARD(ctx);
     TM_REQUIRE(best, TM_ERR_INVALID, "tm_best_reduce: null argument");
     int ticket = -1;
     TM_FORWARD(tm_best_reduce_begin(ctx, comm, d_local, n_models, &ticket));
@@ -328,6 +341,7 @@ int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, ui
 /* host records in, host records out (the candidates of find_parallel's chunks): staged through the device
  * because RCCL moves device memory; all[r * n + k] = rank r's k-th record */
 int tm_comm_allgather_records(tm_comm* comm, const tm_best_record* local, uint32_t n, tm_best_record* all) {
+    TM_GUARD(comm);
     TM_REQUIRE(comm && local && all, TM_ERR_INVALID, "tm_comm_allgather_records: null argument");
     if (n == 0) return TM_OK;
     tm_ctx* ctx = comm->ctx;

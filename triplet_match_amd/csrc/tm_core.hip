@@ -117,6 +117,7 @@ static const opt_entry kOptions[] = {
 extern "C" {
 
 int tm_ctx_set_option(tm_ctx* c, const char* name, int value) {
+    TM_GUARD(c);
     TM_REQUIRE(c && name, TM_ERR_INVALID, "tm_ctx_set_option: null argument");
     for (const opt_entry& o : kOptions) {
         if (strcmp(o.name, name) != 0) continue;
@@ -139,6 +140,7 @@ int tm_ctx_set_option(tm_ctx* c, const char* name, int value) {
 }
 
 int tm_ctx_get_option(const tm_ctx* c, const char* name, int* value) {
+    TM_GUARD(c);
     TM_REQUIRE(c && name && value, TM_ERR_INVALID, "tm_ctx_get_option: null argument");
     for (const opt_entry& o : kOptions)
         if (strcmp(o.name, name) == 0) {
@@ -216,6 +218,7 @@ int tm_ctx_destroy(tm_ctx* c) {
 }
 
 int tm_ctx_synchronize(tm_ctx* c) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return TM_OK;
@@ -224,23 +227,27 @@ int tm_ctx_synchronize(tm_ctx* c) {
 void* tm_ctx_stream(tm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int tm_device_alloc(tm_ctx* c, uint64_t bytes, void** d_ptr) {
+    TM_GUARD(c);
     TM_REQUIRE(c && d_ptr, TM_ERR_INVALID, "tm_device_alloc: null argument");
     TM_HIP_CHECK(hipSetDevice(c->device));
     TM_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 1));
     return TM_OK;
 }
 int tm_device_free(tm_ctx* c, void* d_ptr) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     if (d_ptr) TM_HIP_CHECK(hipFree(d_ptr));
     return TM_OK;
 }
 int tm_memcpy_h2d(tm_ctx* c, void* d_dst, const void* src, uint64_t bytes) {
+    TM_GUARD(c);
     TM_REQUIRE(c && d_dst && src, TM_ERR_INVALID, "tm_memcpy_h2d: null argument");
     TM_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return TM_OK;
 }
 int tm_memcpy_d2h(tm_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
+    TM_GUARD(c);
     TM_REQUIRE(c && dst && d_src, TM_ERR_INVALID, "tm_memcpy_d2h: null argument");
     TM_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -249,12 +256,14 @@ int tm_memcpy_d2h(tm_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
 
 /* a stopwatch on the context's stream (HIP events): everything queued between the two calls */
 int tm_ctx_time_begin(tm_ctx* c) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     TM_HIP_CHECK(hipSetDevice(c->device));
     TM_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     return TM_OK;
 }
 int tm_ctx_time_end(tm_ctx* c, float* ms) {
+    TM_GUARD(c);
     TM_REQUIRE(c && ms, TM_ERR_INVALID, "tm_ctx_time_end: null argument");
     TM_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     TM_HIP_CHECK(hipEventSynchronize(c->ev1));
@@ -263,6 +272,7 @@ int tm_ctx_time_end(tm_ctx* c, float* ms) {
 }
 
 int tm_ctx_enable_timing(tm_ctx* c, int on) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     if (on && c->ev_ring.empty()) {
         TM_HIP_CHECK(hipSetDevice(c->device));
@@ -307,6 +317,7 @@ extern "C" {
 
 int tm_ctx_last_score_timing(tm_ctx* c, float* ms, uint64_t* evaluations, uint64_t* passing,
                              uint64_t* hypotheses) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     score_timing t;
     uint32_t n = 0;
@@ -319,6 +330,7 @@ int tm_ctx_last_score_timing(tm_ctx* c, float* ms, uint64_t* evaluations, uint64
 }
 
 int tm_ctx_score_timing_totals(tm_ctx* c, uint32_t* launches, float* total_ms, uint64_t totals6[6]) {
+    TM_GUARD(c);
     TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
     score_timing t;
     uint32_t n = 0;
@@ -394,6 +406,7 @@ int tm_features_batch(tm_ctx* c, const float* surfels, uint32_t n_points, const 
                       uint32_t n_pairs, const float bmin[4], const float bmax[4],
                       float distance_step_count, float angle_step, float* features4,
                       uint32_t* keys4, uint32_t* hashes) {
+    TM_GUARD(c);
     TM_REQUIRE(c && surfels && ab_pairs && features4, TM_ERR_INVALID, "tm_features_batch: null argument");
     if (n_pairs == 0) return TM_OK;
     for (uint32_t i = 0; i < 2 * n_pairs; ++i)

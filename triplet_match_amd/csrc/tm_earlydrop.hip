@@ -1733,6 +1733,7 @@ extern "C" int tm_score_hypotheses_early_drop(tm_scene* s, tm_model* m, const fl
                                               uint32_t n_hyp, const int32_t* subset, uint32_t n_subset,
                                               float dist_thres, float accept_prob, uint32_t* counts,
                                               double* scores, int32_t* dropped_at, uint32_t* saved) {
+    TM_GUARD(s);
     TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2219,6 +2220,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball(tm_scene* s, tm_model* m, con
                                                    const uint32_t* centers, float radius, float dist_thres,
                                                    float accept_prob, uint32_t* counts, double* scores,
                                                    int32_t* dropped_at, uint32_t* saved) {
+    TM_GUARD(s);
     TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2270,6 +2272,7 @@ extern "C" int tm_score_hypotheses_early_drop_ball_dev(tm_scene* s, tm_model* m,
                                                        const uint32_t* centers, float radius, float dist_thres,
                                                        float accept_prob, uint32_t* d_counts, double* d_scores,
                                                        int32_t* d_dropped_at, uint32_t* d_saved) {
+    TM_GUARD(s);
     TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2368,6 +2371,7 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
                                  const uint32_t* batch_offsets, uint32_t n_batches, float minf, float maxf, int force_up,
                                  int query_limit, float radius, float dist_thres, float accept_prob, int early_drop,
                                  float sufficient, tm_batch_result* out) {
+    TM_GUARD(s);
     TM_REQUIRE(s && m && out && batch_offsets, TM_ERR_INVALID, "tm_search_batches: null argument");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2459,6 +2463,7 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
 extern "C" int tm_search_batch(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, uint32_t n_pairs, float minf,
                                float maxf, int force_up, int query_limit, float radius, float dist_thres,
                                float accept_prob, int early_drop, float sufficient, tm_batch_result* out) {
+    TM_GUARD(s);
     TM_REQUIRE(out, TM_ERR_INVALID, "tm_search_batch: null argument");
     const uint32_t offsets[2] = {0u, n_pairs};
     return tm_search_batches(s, m, ij_pairs, n_pairs, offsets, 1, minf, maxf, force_up, query_limit, radius, dist_thres,
@@ -2498,6 +2503,7 @@ __global__ __launch_bounds__(256) void k_score_points(score_args sc /* sref = or
 extern "C" int tm_score_hypotheses_on_points(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
                                              const int32_t* points, uint32_t n_points, float dist_thres,
                                              uint32_t* counts, double* scores) {
+    TM_GUARD(s);
     TM_REQUIRE(s && m, TM_ERR_INVALID, "null scene or model");
     TM_REQUIRE(s->ctx == m->ctx, TM_ERR_INVALID, "scene and model belong to different contexts");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2582,6 +2588,7 @@ extern "C" int tm_score_hypotheses_on_points(tm_scene* s, tm_model* m, const flo
 extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
                                              uint32_t* counts, uint32_t* t_counts, uint32_t* pairs, uint32_t cap_pairs,
                                              uint32_t* n_pairs) {
+    TM_GUARD(s);
     TM_REQUIRE(s && counts && t_counts && n_pairs && (centers || n_centers == 0), TM_ERR_INVALID,
                "tm_scene_radius_tangent_lists: null argument");
     *n_pairs = 0;
@@ -2647,6 +2654,7 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
 
 extern "C" int tm_scene_radius_lists(tm_scene* s, const uint32_t* centers, uint32_t n_centers, float radius,
                                      int32_t* lists, uint32_t stride, uint32_t* counts) {
+    TM_GUARD(s);
     TM_REQUIRE(s && counts && (centers || n_centers == 0), TM_ERR_INVALID, "tm_scene_radius_lists: null argument");
     if (n_centers == 0) return TM_OK;
     for (uint32_t k = 0; k < n_centers; ++k)

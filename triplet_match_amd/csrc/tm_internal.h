@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -133,6 +134,11 @@ struct reduce_slot {
 }  // namespace tmx
 
 struct tm_ctx {
+    /* Every entry point that takes a context or a handle created from it holds this for the duration of the call
+     * (TM_GUARD): calls from several threads on one context serialise instead of racing on its stream and work
+     * buffers — the reference's workers call model::query / voxel_query / radius_search concurrently
+     * (include/impl/scene.hpp:146-166,304). Recursive: entry points call each other. */
+    mutable std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
@@ -297,6 +303,15 @@ struct tm_scene {
     void* h_pinned = nullptr; /* pinned staging memory of tm_scene_radius_lists */
     size_t h_pinned_bytes = 0;
 };
+
+namespace tmx {
+using ctx_guard = std::unique_lock<std::recursive_mutex>;
+inline ctx_guard guard_of(const tm_ctx* c) { return c ? ctx_guard(c->mu) : ctx_guard(); }
+inline ctx_guard guard_of(const tm_model* m) { return guard_of(m ? m->ctx : nullptr); }
+inline ctx_guard guard_of(const tm_scene* s) { return guard_of(s ? s->ctx : nullptr); }
+}  // namespace tmx
+/* first statement of an entry point: the handle's context stays locked until the call returns */
+#define TM_GUARD(h) tmx::ctx_guard tm_guard_ = tmx::guard_of(h)
 
 namespace tmx {
 int scratch_ensure(tm_ctx* ctx, size_t bytes);

@@ -830,6 +830,7 @@ extern "C" {
 
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,
                     float distance_step_count, float angle_step, tm_model** out) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && surfels && out, TM_ERR_INVALID, "tm_model_create: null argument");
     TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_model_create: empty cloud");
     TM_REQUIRE(resolution > 0.f, TM_ERR_INVALID, "tm_model_create: resolution must be > 0");
@@ -963,6 +964,7 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
 }
 
 int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* resolution, float* nn_dist) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && surfels && resolution, TM_ERR_INVALID, "tm_cloud_resolution: null argument");
     *resolution = 0.f;
     if (n < 2) return TM_OK;
@@ -1020,6 +1022,7 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
 }
 
 int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, float* curv5) {
+    TM_GUARD(ctx);
     return tm_cloud_curvature_subset(ctx, surfels, n, k, nullptr, n, curv5);
 }
 
@@ -1028,6 +1031,7 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
  * (:50, :96-99): 4 % of the points at the configs[1] sizes. The neighbours still come from the whole cloud. */
 int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
                               uint32_t n_idx, float* curv5) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && surfels && curv5, TM_ERR_INVALID, "tm_cloud_curvature: null argument");
     TM_REQUIRE(k >= 1 && k <= (uint32_t)kCurvK, TM_ERR_UNSUPPORTED, "tm_cloud_curvature: k must be in 1..32");
     if (n == 0 || (indices && n_idx == 0)) return TM_OK;
@@ -1132,6 +1136,7 @@ int tm_model_destroy(tm_model* m) {
         delete m;
         return TM_OK;
     }
+    TM_GUARD(m);
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     m->pos.release();
@@ -1159,6 +1164,7 @@ int tm_model_destroy(tm_model* m) {
 }
 
 int tm_model_set_grid_subset(tm_model* m, const uint32_t* subset, uint32_t n_subset) {
+    TM_GUARD(m);
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");
     TM_REQUIRE(subset || n_subset == 0, TM_ERR_INVALID, "tm_model_set_grid_subset: null subset");
     for (uint32_t k = 0; k < n_subset; ++k)
@@ -1176,6 +1182,7 @@ int tm_model_set_grid_subset(tm_model* m, const uint32_t* subset, uint32_t n_sub
 }
 
 int tm_model_build_voxels(tm_model* m) {
+    TM_GUARD(m);
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");
     TM_REQUIRE(m->grid_ready, TM_ERR_NOT_INITIALIZED, "model grid not set up");
     tm_ctx* c = m->ctx;
@@ -1224,6 +1231,7 @@ int tm_model_build_voxels(tm_model* m) {
 
 int tm_model_build_pairs(tm_model* m, const uint32_t* subset, uint32_t n_t,
                          float min_diameter_factor, float max_diameter_factor) {
+    TM_GUARD(m);
     TM_REQUIRE(m && subset, TM_ERR_INVALID, "tm_model_build_pairs: null argument");
     TM_REQUIRE(n_t >= 2, TM_ERR_EMPTY, "tm_model_build_pairs: subset needs at least two points");
     TM_REQUIRE(n_t < 65536, TM_ERR_UNSUPPORTED, "tm_model_build_pairs: subset >= 65536 points");
@@ -1398,6 +1406,7 @@ int tm_model_build_pairs(tm_model* m, const uint32_t* subset, uint32_t n_t,
 }
 
 int tm_model_set_metric(tm_model* m, int traits_kind, float radius) {
+    TM_GUARD(m);
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");
     TM_REQUIRE(traits_kind >= TM_TRAITS_IDENTITY && traits_kind <= TM_TRAITS_CYLINDER, TM_ERR_INVALID,
                "bad traits kind");
@@ -1456,6 +1465,7 @@ int tm_model_set_metric(tm_model* m, int traits_kind, float radius) {
 
 int tm_model_get_info(const tm_model* m, float* diameter, uint32_t* cloud_size, uint32_t* point_count,
                       float* resolution) {
+    TM_GUARD(m);
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");
     if (diameter) *diameter = m->diameter;
     if (cloud_size) *cloud_size = m->n;
@@ -1465,6 +1475,7 @@ int tm_model_get_info(const tm_model* m, float* diameter, uint32_t* cloud_size, 
 }
 
 int tm_model_get_grid(const tm_model* m, int extents[3], float to_voxel16[16]) {
+    TM_GUARD(m);
     TM_REQUIRE(m && m->grid_ready, TM_ERR_NOT_INITIALIZED, "model grid not set up");
     if (extents)
         for (int d = 0; d < 3; ++d) extents[d] = m->extents[d];
@@ -1474,6 +1485,7 @@ int tm_model_get_grid(const tm_model* m, int extents[3], float to_voxel16[16]) {
 }
 
 int tm_model_download_voxels(const tm_model* m, uint32_t* voxels, uint64_t cap, uint64_t* count) {
+    TM_GUARD(m);
     TM_REQUIRE(m, TM_ERR_INVALID, "null model");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
     if (count) *count = m->voxel_count;
@@ -1498,6 +1510,7 @@ int tm_model_download_voxels(const tm_model* m, uint32_t* voxels, uint64_t cap, 
 }
 
 int tm_model_get_feature_bounds(const tm_model* m, float bmin[4], float bmax[4]) {
+    TM_GUARD(m);
     TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
     for (int d = 0; d < 4; ++d) {
         bmin[d] = m->bmin[d];
@@ -1508,6 +1521,7 @@ int tm_model_get_feature_bounds(const tm_model* m, float bmin[4], float bmax[4])
 
 int tm_model_get_pair_counts(const tm_model* m, uint64_t* entries, uint64_t* valid_pairs,
                              uint32_t* distinct_keys) {
+    TM_GUARD(m);
     TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
     if (entries) *entries = m->n_entries;
     if (valid_pairs) *valid_pairs = m->n_valid;
@@ -1517,6 +1531,7 @@ int tm_model_get_pair_counts(const tm_model* m, uint64_t* entries, uint64_t* val
 
 int tm_model_download_table(const tm_model* m, uint32_t* keys4, uint32_t* offsets, uint32_t key_cap,
                             uint32_t* pairs_ij, uint64_t pair_cap) {
+    TM_GUARD(m);
     TM_REQUIRE(m && m->pairs_ready, TM_ERR_NOT_INITIALIZED, "pair table not built");
     TM_REQUIRE(key_cap >= m->n_keys && pair_cap >= m->n_entries, TM_ERR_CAPACITY,
                "table buffers too small");
@@ -1543,6 +1558,7 @@ int tm_model_download_table(const tm_model* m, uint32_t* keys4, uint32_t* offset
 
 int tm_model_query_key(const tm_model* m, const uint32_t key[4], uint32_t* pairs_ij, uint32_t cap,
                        uint32_t* count_total) {
+    TM_GUARD(m);
     TM_REQUIRE(m && key, TM_ERR_INVALID, "tm_model_query: null argument");
     if (!m->pairs_ready) {
         set_error("Cannot query uninitialized model");
@@ -1570,6 +1586,7 @@ int tm_model_query_key(const tm_model* m, const uint32_t key[4], uint32_t* pairs
 
 int tm_model_query(const tm_model* m, const float feature[4], uint32_t* pairs_ij, uint32_t cap,
                    uint32_t* count_total) {
+    TM_GUARD(m);
     TM_REQUIRE(m && feature, TM_ERR_INVALID, "tm_model_query: null argument");
     if (!m->pairs_ready) {
         set_error("Cannot query uninitialized model");
@@ -1581,6 +1598,7 @@ int tm_model_query(const tm_model* m, const float feature[4], uint32_t* pairs_ij
 }
 
 int tm_model_voxel_query(const tm_model* m, const float pos4[4], uint32_t* index, int* found) {
+    TM_GUARD(m);
     TM_REQUIRE(m && pos4 && index && found, TM_ERR_INVALID, "tm_model_voxel_query: null argument");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
     const grid_t& g = m->grid;

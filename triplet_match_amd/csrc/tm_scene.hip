@@ -1639,6 +1639,7 @@ extern "C" {
 
 int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
                     tm_scene** out) {
+    TM_GUARD(ctx);
     TM_REQUIRE(ctx && surfels && tangent_mask && out, TM_ERR_INVALID, "tm_scene_create: null argument");
     TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_scene_create: empty cloud");
     TM_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1664,6 +1665,7 @@ int tm_scene_destroy(tm_scene* s) {
         delete s;
         return TM_OK;
     }
+    TM_GUARD(s);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
@@ -1738,6 +1740,7 @@ int tm_scene_destroy(tm_scene* s) {
 }
 
 int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
+    TM_GUARD(s);
     TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
     TM_HIP_CHECK(hipSetDevice(s->ctx->device));
     if (mask)
@@ -1749,10 +1752,13 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
     return scene_build(s, false);
 }
 
-uint32_t tm_scene_size(const tm_scene* s) { return s ? s->n : 0; }
-uint64_t tm_scene_live_count(const tm_scene* s) { return s ? s->n_live : 0; }
+uint32_t tm_scene_size(const tm_scene* s) {
+    TM_GUARD(s); return s ? s->n : 0; }
+uint64_t tm_scene_live_count(const tm_scene* s) {
+    TM_GUARD(s); return s ? s->n_live : 0; }
 
 int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) {
+    TM_GUARD(s);
     TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
     if (s->h_sparse && surfels) { /* a projected scene keeps only its tangent points on the host: fetch the rest */
         TM_HIP_CHECK(hipSetDevice(s->ctx->device));
@@ -1768,6 +1774,7 @@ int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) 
 /* the points with tangent_mask set, ascending, with their surfels as the kernels see them (uvw surfels for a
  * projected scene): all the host side of a search reads of a scene's cloud */
 int tm_scene_tangent_points(const tm_scene* s, uint32_t* indices, float* surfels, uint32_t cap, uint32_t* count) {
+    TM_GUARD(s);
     TM_REQUIRE(s && count, TM_ERR_INVALID, "tm_scene_tangent_points: null argument");
     if (s->h_sparse) {
         *count = (uint32_t)s->h_tan_idx.size();
@@ -1793,6 +1800,7 @@ int tm_scene_tangent_points(const tm_scene* s, uint32_t* indices, float* surfels
 
 int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, uint32_t j, float minf,
                             float maxf) {
+    TM_GUARD(s);
     if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
     if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
     const float* a = scene_row(s, i);
@@ -1816,6 +1824,7 @@ int tm_generate_hypotheses_dev(tm_scene* s, tm_model* m, const uint32_t* d_ij_pa
                                float min_diameter_factor, float max_diameter_factor, int force_up,
                                int query_limit, float* d_poses16, uint32_t* d_provenance4, uint32_t cap,
                                uint32_t* count, uint32_t* count_total) {
+    TM_GUARD(s);
     TM_REQUIRE(d_ij_pairs && d_poses16 && d_provenance4, TM_ERR_INVALID,
                "tm_generate_hypotheses_dev: null argument");
     return generate_device(s, m, (const uint2*)d_ij_pairs, n_pairs, min_diameter_factor,
@@ -1827,6 +1836,7 @@ int tm_generate_hypotheses(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, u
                            float min_diameter_factor, float max_diameter_factor, int force_up,
                            int query_limit, float* poses16, uint32_t* provenance4, uint32_t cap,
                            uint32_t* count, uint32_t* count_total) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     TM_REQUIRE(ij_pairs || n_pairs == 0, TM_ERR_INVALID, "tm_generate_hypotheses: null pairs");
     if (count) *count = 0;
@@ -1866,6 +1876,7 @@ int tm_generate_hypotheses(tm_scene* s, tm_model* m, const uint32_t* ij_pairs, u
 int tm_score_hypotheses_dev(tm_scene* s, tm_model* m, int traits_kind, const float* d_poses16,
                             uint32_t n_hyp, float dist_thres, int mode, uint32_t* d_counts,
                             double* d_scores) {
+    TM_GUARD(s);
     TM_REQUIRE(d_poses16 && d_counts && d_scores, TM_ERR_INVALID, "tm_score_hypotheses_dev: null argument");
     TM_FORWARD(check_pair(s, m));
     return score_device(s, m, traits_kind, d_poses16, n_hyp, nullptr, count_active(s), dist_thres, mode,
@@ -1875,6 +1886,7 @@ int tm_score_hypotheses_dev(tm_scene* s, tm_model* m, int traits_kind, const flo
 int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* poses16, uint32_t n_hyp,
                         const int32_t* subset, uint32_t n_subset, float dist_thres, int mode,
                         uint32_t* counts, double* scores) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     TM_REQUIRE(poses16 || n_hyp == 0, TM_ERR_INVALID, "tm_score_hypotheses: null poses");
     TM_REQUIRE(counts && scores, TM_ERR_INVALID, "tm_score_hypotheses: null outputs");
@@ -1935,6 +1947,7 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
 int tm_score_hypotheses_ball_dev(tm_scene* s, tm_model* m, const float* d_poses16, uint32_t n_hyp,
                                  const uint32_t* d_centers, float radius, float dist_thres, uint32_t* d_counts,
                                  double* d_scores) {
+    TM_GUARD(s);
     TM_REQUIRE(d_poses16 && d_centers && d_counts && d_scores, TM_ERR_INVALID,
                "tm_score_hypotheses_ball_dev: null argument");
     TM_FORWARD(check_pair(s, m));
@@ -1949,6 +1962,7 @@ int tm_score_hypotheses_ball_dev(tm_scene* s, tm_model* m, const float* d_poses1
 int tm_score_hypotheses_ball(tm_scene* s, tm_model* m, const float* poses16, uint32_t n_hyp,
                              const uint32_t* centers, float radius, float dist_thres, uint32_t* counts,
                              double* scores) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     TM_REQUIRE(counts && scores, TM_ERR_INVALID, "tm_score_hypotheses_ball: null outputs");
     if (n_hyp == 0) return TM_OK;
@@ -2038,6 +2052,7 @@ static int extract_on_device(tm_scene* s, tm_model* m, const float* d_pose, floa
 int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
                                      uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride, uint32_t* counts,
                                      double* scores) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     if (n == 0) return TM_OK;
     TM_REQUIRE(poses16 && counts, TM_ERR_INVALID, "tm_extract_correspondences_batch: null argument");
@@ -2096,6 +2111,7 @@ int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* pose
 int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres,
                                uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t cap, uint32_t* count,
                                double* score) {
+    TM_GUARD(s);
     TM_REQUIRE(pose16 && count, TM_ERR_INVALID, "tm_extract_correspondences: null argument");
     return tm_extract_correspondences_batch(s, m, pose16, 1, dist_thres, scene_corrs, model_corrs, cap, count, score);
 }
@@ -2130,6 +2146,7 @@ static void icp_score_args(const tm_scene* s, const tm_model* m, float dist_thre
 
 int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t* count,
                       long long sums15[15]) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     TM_REQUIRE(pose16 && count && sums15, TM_ERR_INVALID, "tm_icp_accumulate: null argument");
     TM_REQUIRE(m->voxels_ready, TM_ERR_NOT_INITIALIZED, "voxel grid not built");
@@ -2164,6 +2181,7 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
  * launches is max_iterations + 1 passes long instead of candidates x (max_iterations + 1). */
 int tm_icp_refine_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
                         uint32_t max_iterations, float* out_poses16, uint32_t* out_counts, uint32_t* out_iterations) {
+    TM_GUARD(s);
     TM_FORWARD(check_pair(s, m));
     if (n == 0) return TM_OK;
     TM_REQUIRE(poses16 && out_poses16 && out_counts, TM_ERR_INVALID, "tm_icp_refine_batch: null argument");
@@ -2203,6 +2221,7 @@ int tm_icp_refine_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t
 
 int tm_icp_refine(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres, uint32_t max_iterations,
                   float out_pose16[16], uint32_t* out_count, uint32_t* out_iterations) {
+    TM_GUARD(s);
     TM_REQUIRE(pose16 && out_pose16 && out_count, TM_ERR_INVALID, "tm_icp_refine: null argument");
     return tm_icp_refine_batch(s, m, pose16, 1, dist_thres, max_iterations, out_pose16, out_count, out_iterations);
 }
@@ -2217,6 +2236,7 @@ int tm_rigid_fit(const long long sums15[15], uint32_t count, float pose16[16]) {
 
 int tm_best_of_batch(tm_ctx* c, const uint32_t* d_counts, const double* d_scores, const float* d_poses16,
                      uint32_t n_hyp, uint32_t id_offset, uint32_t id_stride, tm_best_record* best) {
+    TM_GUARD(c);
     TM_REQUIRE(c && best, TM_ERR_INVALID, "tm_best_of_batch: null argument");
     TM_REQUIRE((d_counts && d_scores && d_poses16) || n_hyp == 0, TM_ERR_INVALID,
                "tm_best_of_batch: null device buffers");

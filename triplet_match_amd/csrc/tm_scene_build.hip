@@ -488,6 +488,7 @@ using namespace tmx;
 
 extern "C" int tm_scene_radius_subset(tm_scene* s, uint32_t center_idx, float radius, int32_t* out, uint32_t cap,
                                       uint32_t* count) {
+    TM_GUARD(s);
     TM_REQUIRE(s && count, TM_ERR_INVALID, "tm_scene_radius_subset: null argument");
     TM_REQUIRE(center_idx < s->n, TM_ERR_INVALID, "tm_scene_radius_subset: centre index out of range");
     tm_ctx* c = s->ctx;
@@ -523,6 +524,7 @@ extern "C" int tm_scene_radius_subset(tm_scene* s, uint32_t center_idx, float ra
 /* entries ranks[0..n) (ascending order not required) of the list the LAST tm_scene_radius_subset call on this scene
  * described — for a caller that needs a few members of a large neighbourhood and not the list */
 extern "C" int tm_scene_radius_select(const tm_scene* s, const uint32_t* ranks, uint32_t n_ranks, int32_t* out) {
+    TM_GUARD(s);
     TM_REQUIRE(s && (ranks || n_ranks == 0) && (out || n_ranks == 0), TM_ERR_INVALID, "tm_scene_radius_select: null argument");
     TM_REQUIRE(!s->h_words.empty(), TM_ERR_NOT_INITIALIZED, "tm_scene_radius_select: no tm_scene_radius_subset call before");
     for (uint32_t q = 0; q < n_ranks; ++q) {

@@ -233,6 +233,7 @@ float tm_traits_intrinsic_distance(int kind, const float* state, const float p0[
 
 int tm_traits_project_cloud(tm_ctx* c, int kind, const float* state, const float* surfels, uint32_t n,
                             float* uvw_surfels, int32_t* valid) {
+    TM_GUARD(c);
     TM_REQUIRE(c && state && surfels && uvw_surfels && valid, TM_ERR_INVALID,
                "tm_traits_project_cloud: null argument");
     TM_REQUIRE(kind >= 0 && kind <= 3, TM_ERR_INVALID, "bad traits kind");
@@ -273,6 +274,7 @@ int tm_traits_project_cloud(tm_ctx* c, int kind, const float* state, const float
 }
 
 int tm_scene_create_projected(tm_scene* src, int kind, const float* state, tm_scene** out) {
+    TM_GUARD(src);
     TM_REQUIRE(src && state && out, TM_ERR_INVALID, "tm_scene_create_projected: null argument");
     TM_REQUIRE(kind >= 0 && kind <= 3, TM_ERR_INVALID, "bad traits kind");
     tm_ctx* c = src->ctx;
@@ -351,6 +353,7 @@ int tm_scene_create_projected(tm_scene* src, int kind, const float* state, tm_sc
  * surface (abs(w) <= band; band < 0 = no test). The same two kernels into scratch memory + a count. */
 int tm_scene_probe_projected(tm_scene* src, int kind, const float* state, float band, uint64_t* live,
                              uint32_t* tangent_on_surface) {
+    TM_GUARD(src);
     TM_REQUIRE(src && state && live && tangent_on_surface, TM_ERR_INVALID, "tm_scene_probe_projected: null argument");
     TM_REQUIRE(kind >= 0 && kind <= 3, TM_ERR_INVALID, "bad traits kind");
     tm_ctx* c = src->ctx;
@@ -389,6 +392,7 @@ int tm_cl_icp_projection(tm_ctx* c, const float* pnts4, int n, const float* imag
                          const int img_margin[2], const float* mat_align16, const float* mat_uvw16,
                          const float* mat_proj16, const float* mat_norm16, float max_corr_dist,
                          float* out_positions4, int* model_indices, int* scene_indices, uint32_t* n_corr) {
+    TM_GUARD(c);
     TM_REQUIRE(c && pnts4 && image4 && img_size && img_margin && mat_align16 && mat_uvw16 && mat_proj16 &&
                    mat_norm16 && out_positions4 && model_indices && scene_indices,
                TM_ERR_INVALID, "tm_cl_icp_projection: null argument");
@@ -443,6 +447,7 @@ int tm_cl_icp_projection(tm_ctx* c, const float* pnts4, int n, const float* imag
 int tm_cl_icp_correlation(tm_ctx* c, const float* scene4, uint32_t n_scene, const float* model4, uint32_t n_model,
                           const int* indices_scene, const int* indices_model, int n, const float centroid_scene[4],
                           const float centroid_model[4], double cov9[9]) {
+    TM_GUARD(c);
     TM_REQUIRE(c && scene4 && model4 && indices_scene && indices_model && centroid_scene && centroid_model && cov9,
                TM_ERR_INVALID, "tm_cl_icp_correlation: null argument");
     TM_REQUIRE(n >= 2, TM_ERR_INVALID, "tm_cl_icp_correlation: needs at least two correspondences");
