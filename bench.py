@@ -581,9 +581,10 @@ def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres
                                "frac_basis": "measured_l2_fabric_bytes: Infinity Cache + HBM, upper bound of HBM",
                                "infinity_cache_frac": round(gbs / INFINITY_CACHE_RANDOM_GBS, 4),
                                "kernel_busy_ms_under_profiler": t.get("kernel_busy_ms_per_call"),
-                               "note": "most of these bytes are the continuation's (k_ed_fused<false>: each pending hypothesis "
-                                       "culls the whole scene for itself, requests_per_call_by_kernel in "
-                                       "profiles/r03/early_drop_traffic.json): traffic far above what the rule needs"}
+                               "note": "bytes by kernel in profiles/r03/early_drop_traffic.json: the continuation "
+                                       "(k_ed_hist_list) streams the neighbourhood of every pending hypothesis once (scene "
+                                       "entries, voxel lines, model points and refs of ~100k positions per hypothesis), the "
+                                       "first step (k_ed_prefix_group) the voxel side of the first 5 % of every hypothesis"}
     except (OSError, ValueError, KeyError):
         pass
     return out
