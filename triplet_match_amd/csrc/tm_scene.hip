@@ -426,32 +426,67 @@ __global__ __launch_bounds__(256) void k_pose_aux(const float* __restrict__ pose
     aux[h] = make_float2(rnorm, 1e-6f * (3.f * rnorm * coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f));
 }
 
+/* One workgroup per (group, 256 super-tiles of 8 chunks). Phase 1: a thread = a super-tile, its sphere under each of the
+ * group's poses (uniform: scalar loads); the (super-tile, pose) pairs that pass — one in ten — go to a list in LDS.
+ * Phase 2: the list's pairs x 8 chunks as dense tasks (pose per lane from LDS), hits OR-ed into the masks in LDS.
+ * With a thread per (group, chunk), or the chunk tests inside phase 1's loop, nearly every pose had some lane of the
+ * wave to serve and the wave ran all 16 x 8 chunk tests mostly idle (0.26 ms per batch, VALU-bound). Same tests, hence
+ * the same masks. */
+constexpr uint32_t kCullSupers = 256, kCullMaxHyps = 32;
 __global__ __launch_bounds__(256) void k_group_cull(score_args a, cull_args ca, group_args ga) {
-    const uint32_t chunk = blockIdx.y * 256 + threadIdx.x; /* groups along x: any batch size fits one launch */
-    const uint32_t group = blockIdx.x;
-    const bool live = chunk < ga.n_chunks;
-    float4 sb = make_float4(0.f, 0.f, 0.f, -1.f), ss = sb;
-    if (live) {
-        sb = ga.chunks[chunk];
-        ss = ca.supers[chunk >> 3];
+    __shared__ float s_pose[kCullMaxHyps * 16];
+    __shared__ float2 s_aux[kCullMaxHyps];
+    __shared__ float4 s_ctr[kCullMaxHyps];
+    __shared__ uint32_t s_m[kCullSupers * 8];
+    __shared__ unsigned short s_pair[kCullSupers * kCullMaxHyps];
+    __shared__ uint32_t s_np;
+    const uint32_t group = blockIdx.x; /* groups along x: any batch size fits one launch */
+    const uint32_t sup = blockIdx.y * kCullSupers + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t h0 = group * ga.group_hyps;
+    const uint32_t n_g = min(ga.group_hyps, a.n_hyp > h0 ? a.n_hyp - h0 : 0u);
+    for (uint32_t i = threadIdx.x; i < n_g * 16u; i += 256u) s_pose[i] = a.poses[(size_t)h0 * 16 + i];
+    if (threadIdx.x < n_g) {
+        s_aux[threadIdx.x] = ga.aux[h0 + threadIdx.x];
+        s_ctr[threadIdx.x] = ca.centers ? ca.opos[ca.centers[h0 + threadIdx.x]] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    uint32_t m = 0;
-    for (uint32_t g = 0; g < ga.group_hyps; ++g) {
-        const uint32_t h = group * ga.group_hyps + g; /* uniform: the pose comes through scalar loads */
-        if (h >= a.n_hyp) break;
-        const pose12 T = load_pose(a.poses + (size_t)h * 16);
-        const float2 ax = ga.aux[h];
-        const float rnorm = ax.x, abs_eps = ax.y;
-        bool hit = sphere_hits_box(a, T, rnorm, abs_eps, ss);
-        if (hit) hit = sphere_hits_box(a, T, rnorm, abs_eps, sb);
+    for (uint32_t i = threadIdx.x; i < kCullSupers * 8u; i += 256u) s_m[i] = 0u;
+    if (threadIdx.x == 0) s_np = 0u;
+    __syncthreads();
+    const float4 ss = sup * 8u < ga.n_chunks ? ca.supers[sup] : make_float4(0.f, 0.f, 0.f, -1.f);
+    for (uint32_t g = 0; g < n_g; ++g) {
+        const pose12 T = load_pose(a.poses + (size_t)(h0 + g) * 16); /* uniform: the pose comes through scalar loads */
+        const float2 ax = ga.aux[h0 + g];
+        const bool hit = sphere_hits_box(a, T, ax.x, ax.y, ss);
+        const unsigned long long b = __ballot(hit);
+        if (b) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_np, (uint32_t)__popcll(b));
+            base = (uint32_t)__shfl((int)base, 0);
+            if (hit) s_pair[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)((threadIdx.x << 5) | g);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_task = s_np * 8u;
+    const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
+    for (uint32_t t = threadIdx.x; t < n_task; t += 256u) {
+        const uint32_t pr = s_pair[t >> 3], k = t & 7u, sl = pr >> 5, g = pr & 31u;
+        const uint32_t chunk = (blockIdx.y * kCullSupers + sl) * 8u + k;
+        if (chunk >= ga.n_chunks) continue;
+        const float4 sb = ga.chunks[chunk];
+        const pose12 T = load_pose(s_pose + g * 16u);
+        const float2 ax = s_aux[g];
+        bool hit = sphere_hits_box(a, T, ax.x, ax.y, sb);
         if (ca.centers) { /* neighbourhood restriction: the chunk must reach the ball of the hypothesis' first point */
-            const float4 C = ca.opos[ca.centers[h]];
-            const float ball_margin = 1e-5f * ca.ball_r + 4e-6f * ca.coord_max + 1e-12f;
+            const float4 C = s_ctr[g];
             hit = hit && !(len(make3(sb.x, sb.y, sb.z) - make3(C.x, C.y, C.z)) > ca.ball_r + sb.w * 1.00001f + ball_margin);
         }
-        m |= hit ? (1u << g) : 0u;
+        if (hit) atomicOr(&s_m[sl * 8u + k], 1u << g);
     }
-    if (live) ga.masks[(size_t)group * ga.n_chunks + chunk] = (group_mask_t)m;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kCullSupers * 8u; i += 256u) {
+        const uint32_t chunk = blockIdx.y * kCullSupers * 8u + i;
+        if (chunk < ga.n_chunks) ga.masks[(size_t)group * ga.n_chunks + chunk] = (group_mask_t)s_m[i];
+    }
 }
 
 /* Items in the order of the MODEL region they land in (option item_sort). L2 (4 MB per XCD) turns over every few
@@ -490,7 +525,16 @@ __global__ __launch_bounds__(256) void k_item_bins(score_args a, group_args ga, 
                   (spread3((uint32_t)vz >> cell_shift) << 2);
         bin = min(bin, n_bins - 1u);
         bin_of[it] = bin;
-        atomicAdd(&hist[bin], 1u);
+        /* consecutive items are neighbouring chunks of one group: a wave holds a handful of distinct bins, and one
+         * atomic per (wave, bin) instead of one per item (776k per batch, the hot bins serialising: 0.24 ms) */
+        unsigned long long todo = __ballot(true);
+        const uint32_t lane = threadIdx.x & 63u;
+        while (todo) {
+            const uint32_t b = (uint32_t)__shfl((int)bin, __builtin_ctzll(todo));
+            const unsigned long long same = __ballot(bin == b) & todo;
+            if (lane == (uint32_t)__builtin_ctzll(same)) atomicAdd(&hist[b], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 
@@ -498,8 +542,24 @@ __global__ __launch_bounds__(256) void k_item_scatter(group_args ga, const uint3
                                                       uint32_t* __restrict__ cursor /* exclusive offsets, advanced here */,
                                                       uint32_t* __restrict__ sorted) {
     const uint32_t n_items = *ga.n_items;
-    for (uint32_t it = blockIdx.x * 256 + threadIdx.x; it < n_items; it += gridDim.x * 256)
-        sorted[atomicAdd(&cursor[bin_of[it]], 1u)] = ga.items[it];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t it = blockIdx.x * 256 + threadIdx.x; it < n_items; it += gridDim.x * 256) {
+        const uint32_t bin = bin_of[it];
+        /* one cursor atomic per (wave, bin); the items of a wave keep their order inside the bin */
+        unsigned long long todo = __ballot(true);
+        uint32_t dst = 0;
+        while (todo) {
+            const uint32_t b = (uint32_t)__shfl((int)bin, __builtin_ctzll(todo));
+            const unsigned long long same = __ballot(bin == b) & todo;
+            const int leader = __builtin_ctzll(same);
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&cursor[b], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (bin == b) dst = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        sorted[dst] = ga.items[it];
+    }
 }
 
 /* sum over the 16 lanes of a DPP row; lane 15 of every row ends up with the row's total */
@@ -1386,7 +1446,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                 ga.steal = c->opt.item_nosteal ? 0u : 1u;
                 ga.run_shift = c->opt.item_run >= 0 ? (uint32_t)c->opt.item_run : 0xFFFFFFFFu;
             }
-            hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, (ga.n_chunks + 255) / 256), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, ((ga.n_chunks + 7) / 8 + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
             size_t tmp = 0;
             rocprim::counting_iterator<uint32_t> slots(0u);
