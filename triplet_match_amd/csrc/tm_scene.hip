@@ -545,20 +545,24 @@ __global__ __launch_bounds__(256) void k_item_scatter(group_args ga, const uint3
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t it = blockIdx.x * 256 + threadIdx.x; it < n_items; it += gridDim.x * 256) {
         const uint32_t bin = bin_of[it];
-        /* one cursor atomic per (wave, bin); the items of a wave keep their order inside the bin */
+        /* one cursor atomic per (wave, bin), all of a wave's in one instruction (a returning atomic per distinct bin,
+         * one after the other, is a microsecond each); the items of a wave keep their order inside the bin */
         unsigned long long todo = __ballot(true);
-        uint32_t dst = 0;
+        uint32_t leader = lane, rank = 0, cnt = 1;
         while (todo) {
             const uint32_t b = (uint32_t)__shfl((int)bin, __builtin_ctzll(todo));
             const unsigned long long same = __ballot(bin == b) & todo;
-            const int leader = __builtin_ctzll(same);
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&cursor[b], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (bin == b) dst = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (bin == b) {
+                leader = (uint32_t)__builtin_ctzll(same);
+                rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                cnt = (uint32_t)__popcll(same);
+            }
             todo &= ~same;
         }
-        sorted[dst] = ga.items[it];
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[bin], cnt);
+        base = (uint32_t)__shfl((int)base, (int)leader);
+        sorted[base + rank] = ga.items[it];
     }
 }
 
