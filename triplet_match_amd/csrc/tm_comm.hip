@@ -112,17 +112,34 @@ __global__ __launch_bounds__(1024) void k_best_prov(const uint32_t* __restrict__
     b.hyp_id = 0xFFFFFFFFu;
     b.score = 0.0;
     uint32_t bi = 0xFFFFFFFFu;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint4 pv = prov[i];
-        tm_best_record c;
-        c.inlier_count = counts[i];
-        c.score = scores[i];
-        c.hyp_id = (pair_offset + pv.x * pair_stride) * limit + pv.w;
-        if (record_better(c, b)) {
-            b.inlier_count = c.inlier_count;
-            b.score = c.score;
-            b.hyp_id = c.hyp_id;
-            bi = i;
+    /* one workgroup walks the batch: four records per turn, their loads in flight together (64 dependent turns of
+     * three loads each were 53 us for 65,536 hypotheses) */
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+        uint4 pv[4];
+        uint32_t cn[4];
+        double sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * 1024u;
+            const bool in = i < n;
+            pv[k] = in ? prov[i] : make_uint4(0u, 0u, 0u, 0u);
+            cn[k] = in ? counts[i] : 0u;
+            sc[k] = in ? scores[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * 1024u;
+            if (i >= n) break;
+            tm_best_record c;
+            c.inlier_count = cn[k];
+            c.score = sc[k];
+            c.hyp_id = (pair_offset + pv[k].x * pair_stride) * limit + pv[k].w;
+            if (record_better(c, b)) {
+                b.inlier_count = c.inlier_count;
+                b.score = c.score;
+                b.hyp_id = c.hyp_id;
+                bi = i;
+            }
         }
     }
     /* wave reduction on (count, score, id, index), then the 16 wave winners in LDS */
