@@ -141,6 +141,15 @@ int tm_cloud_curvature(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k
  * reads it only where the tangent test passes (:50, :96-99) — 4 % of the points at the configs[1] sizes. */
 int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
                               uint32_t n_indices, float* curv5);
+/* The same for a scene that is already on the device (mask_ is ignored: the neighbours come from every finite point):
+ * no second upload of the cloud and no tree built on the host — the scene's points are in curve order already, and a
+ * complete binary tree over that order with true bounding boxes is a few launches (a 1M-point scene: 70 ms of host
+ * preparation for a 3 ms kernel otherwise). Same neighbours, same arithmetic, same rows as tm_cloud_curvature_subset.
+ * With tm_scene_set_tangent_mask this lets a caller create the scene first, ask the curvature of the candidate
+ * points, and hand in tangent_mask_ (include/impl/scene.hpp:46-54) afterwards. */
+int tm_scene_curvature_subset(tm_scene* scene, uint32_t k, const uint32_t* indices, uint32_t n_idx, float* curv5);
+/* replaces tangent_mask_ of an existing scene (the sorted order and the cloud stay) */
+int tm_scene_set_tangent_mask(tm_scene* scene, const int32_t* tangent_mask);
 
 /* ---- neighbour queries of pointcloud<Point> (include/pointcloud:38-63, include/impl/pointcloud.hpp:100-210) ----
  * tm_cloud = the cloud's search structure: kdtree() / build_tree_ (:100-136, :224-240), over all finite points or

@@ -13,6 +13,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <optional>
@@ -20,6 +21,10 @@
 #include <string>
 #include <tuple>
 #include <vector>
+
+#if defined(__GLIBC__)
+#include <malloc.h>
+#endif
 
 #include "../tm_hip.h"
 
@@ -176,7 +181,25 @@ struct context_holder {
     explicit context_holder(int device) { check(tm_ctx_create(device, &ctx), "tm_ctx_create"); }
     ~context_holder() { tm_ctx_destroy(ctx); }
 };
+/* A search allocates and frees vectors of 0.4-4 MB per call (correspondence lists of the candidates, masks). glibc
+ * serves blocks above M_MMAP_THRESHOLD (128 KB until the process happens to free a larger mapping, then up to 32 MB)
+ * by mmap/munmap: every such vector is then mapped, page-faulted and unmapped again — 2-3 ms of a 10-ms search, and
+ * whether a process pays it depended on what it had freed before. The threshold is therefore pinned once (glibc only;
+ * TM_KEEP_MALLOC_DEFAULTS in the environment leaves the allocator alone). */
+inline void tune_allocator_once() {
+#if defined(__GLIBC__)
+    static const bool done = [] {
+        if (std::getenv("TM_KEEP_MALLOC_DEFAULTS") == nullptr) {
+            mallopt(M_MMAP_THRESHOLD, 32 << 20);
+            mallopt(M_TRIM_THRESHOLD, 128 << 20);
+        }
+        return true;
+    }();
+    (void)done;
+#endif
+}
 inline std::shared_ptr<context_holder> default_context(int device = 0) {
+    tune_allocator_once();
     static std::weak_ptr<context_holder> cached[16];
     auto sp = cached[device & 15].lock();
     if (!sp) {

@@ -182,13 +182,26 @@ public:
      * scene::find_all_parallel ask before their mask loops — they read the curvature of the points that pass the
      * tangent test only (include/impl/model.hpp:96-99, scene.hpp:50), 4 % of a cloud, where the reference computes
      * all of them (:68-71, :48-49). A later curvature(k, idx) of another point recomputes the whole cloud. */
-    void prepare_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
-        if (curv_k_ == k && curv_.size() == 5 * points.size()) {
-            bool all = true;
-            if (!curv_have_.empty())
-                for (uint32_t i : indices) all = all && curv_have_[i];
-            if (all) return;
+    bool has_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
+        if (curv_k_ != k || curv_.size() != 5 * points.size()) return false;
+        if (!curv_have_.empty())
+            for (uint32_t i : indices)
+                if (!curv_have_[i]) return false;
+        return true;
+    }
+    /* rows computed elsewhere for this cloud's content (tm_scene_curvature_subset on a scene's device copy of it) */
+    void store_curvature(uint32_t k, const std::vector<uint32_t>& indices, const std::vector<float>& rows) const {
+        curv_.assign(5 * points.size(), 0.f);
+        curv_have_.assign(points.size(), 0);
+        for (size_t q = 0; q < indices.size(); ++q) {
+            std::memcpy(&curv_[5 * (size_t)indices[q]], &rows[5 * q], 20);
+            curv_have_[indices[q]] = 1;
         }
+        curv_k_ = k;
+        curv_hash_ = content_hash();
+    }
+    void prepare_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
+        if (has_curvature(k, indices)) return;
         curv_.assign(5 * points.size(), 0.f);
         curv_have_.assign(points.size(), 0);
         if (!indices.empty()) {

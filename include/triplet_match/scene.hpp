@@ -23,7 +23,8 @@ namespace detail {
  * per chunk, the general subset call, the ICP loop on the host): same results either way. Read from the
  * environment ONCE per process, on first use — never inside the search loops. */
 struct search_switches {
-    bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods;
+    bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods,
+        host_curvature_tree;
 };
 inline const search_switches& env_once() {
     static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
@@ -31,7 +32,8 @@ inline const search_switches& env_once() {
                                        std::getenv("TM_SUBSET_GENERAL") != nullptr,
                                        std::getenv("TM_ICP_HOST_LOOP") != nullptr,
                                        std::getenv("TM_ICP_PER_CANDIDATE") != nullptr,
-                                       std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr};
+                                       std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr,
+                                       std::getenv("TM_HOST_CURVATURE_TREE") != nullptr};
     return sw;
 }
 
@@ -746,7 +748,15 @@ protected:
      * so an in-place edit of the points between two calls must be seen; the searches reset mask_ themselves */
     void ensure_scene(std::vector<int32_t>& tangent_mask) {
         const uint32_t n = (uint32_t)cloud_->size();
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { /* set_verbose(true): where the scene preparation's time goes */
+            if (!verbose_) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[scene] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         const uint64_t hash = cloud_->content_hash();
+        lap("content hash");
         cloud_->sync(hash); /* curvature computed for other content is forgotten */
         if (h_ && hash != cached_hash_) invalidate();
         if (h_ && cached_n_ == n && cached_curv_k_ == curvature_k_ && cached_curv_ok_ == curvature_ok_) {
@@ -754,11 +764,32 @@ protected:
             return;
         }
         tangent_mask.assign(n, 0);
+        bool created_now = false;
         if (curvature_k_) { /* the curvature of the points the test below can reach, in one call */
             std::vector<uint32_t> cand;
             for (uint32_t i = 0; i < n; ++i)
                 if (tangent(cloud_->points[i]).norm() > 0.7f && (curvature_ok_.empty() || curvature_ok_[i])) cand.push_back(i);
-            cloud_->prepare_curvature(curvature_k_, cand);
+            lap("candidates of the tangent test");
+            if (detail::env_once().host_curvature_tree) {
+                cloud_->prepare_curvature(curvature_k_, cand);
+            } else if (!cloud_->has_curvature(curvature_k_, cand)) {
+                /* from the scene's own device copy: the cloud goes up once, and the neighbour search runs on a tree
+                 * built there over the scene's curve order (tm_scene_curvature_subset) instead of 70 ms of host
+                 * preparation per million points; tangent_mask_ follows below (tm_scene_set_tangent_mask) */
+                if (h_ && cached_n_ != n) invalidate();
+                if (!h_) {
+                    detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
+                                  "tm_scene_create");
+                    created_now = true;
+                    lap("tm_scene_create");
+                }
+                std::vector<float> rows(5 * cand.size());
+                if (!cand.empty())
+                    detail::check(tm_scene_curvature_subset(h_, curvature_k_, cand.data(), (uint32_t)cand.size(), rows.data()),
+                                  "tm_scene_curvature_subset");
+                cloud_->store_curvature(curvature_k_, cand, rows);
+            }
+            lap("curvature of the candidates");
         }
         for (uint32_t i = 0; i < n; ++i) {
             bool t = tangent(cloud_->points[i]).norm() > 0.7f; /* :50 */
@@ -769,11 +800,15 @@ protected:
             }
             tangent_mask[i] = t ? 1 : 0;
         }
-        if (h_ && (cached_n_ != n || cached_tmask_ != tangent_mask)) invalidate();
+        lap("tangent_mask_");
+        if (h_ && !created_now && cached_n_ != n) invalidate();
         if (!h_) {
             detail::check(tm_scene_create(ctx_->ctx, cloud_->points[0].raw(), n, tangent_mask.data(), &h_),
                           "tm_scene_create");
+        } else if (created_now || cached_tmask_ != tangent_mask) { /* same cloud on the device, another tangent_mask_ */
+            detail::check(tm_scene_set_tangent_mask(h_, tangent_mask.data()), "tm_scene_set_tangent_mask");
         }
+        lap("scene on the device");
         cached_n_ = n;
         cached_tmask_ = tangent_mask;
         cached_hash_ = hash;

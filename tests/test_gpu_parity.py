@@ -1259,6 +1259,51 @@ def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case):
     assert len(idx) > 100
 
 
+def test_scene_curvature_and_late_tangent_mask(gpu_ctx, oracle_small, small_case):
+    """tm_scene_curvature_subset (tree built on the device over the scene's curve order) == tm_cloud_curvature_subset
+    (host-built kd-tree) == the oracle, bit for bit, with a mask set and non-finite points in the cloud; a scene
+    created with an empty tangent mask and given tangent_mask_ afterwards (tm_scene_set_tangent_mask) == a scene
+    created with it."""
+    S = small_case["scene"]["surfels"].copy()
+    tmk = small_case["scene"]["tangent_mask"]
+    S[123, 0] = np.nan
+    S[4567, 2] = np.inf
+    idx = np.concatenate([[123, 4567, 0, len(S) - 1], np.nonzero(tmk)[0]]).astype(np.uint32)
+    late = capi.Scene(gpu_ctx, S, np.zeros(len(S), np.int32))
+    mask = np.zeros(len(S), np.int32)
+    mask[::3] = 1
+    late.set_mask(mask)  # mask_ does not take points out of the neighbourhoods
+    got = late.curvature_subset(idx, 30)
+    want = gpu_ctx.cloud_curvature_subset(S, idx, 30)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got[0] == 0).all() and (got[1] == 0).all() and (got[2:] != 0).any()
+    ref = tmo.cloud_curvature(S, 30)[idx]
+    assert np.array_equal(got[2:].view(np.uint32), ref[2:].view(np.uint32))
+    for k in (1, 7, 32):
+        assert np.array_equal(late.curvature_subset(idx[:200], k).view(np.uint32),
+                              gpu_ctx.cloud_curvature_subset(S, idx[:200], k).view(np.uint32))
+    # tiny clouds: fewer points than k, a single leaf
+    for n in (1, 5, 9, 40):
+        tiny = capi.Scene(gpu_ctx, S[1000:1000 + n], np.zeros(n, np.int32))
+        ids = np.arange(n, dtype=np.uint32)
+        assert np.array_equal(tiny.curvature_subset(ids, 30).view(np.uint32),
+                              gpu_ctx.cloud_curvature_subset(S[1000:1000 + n], ids, 30).view(np.uint32))
+    late.set_mask(None)
+    late.set_tangent_mask(tmk)
+    early = capi.Scene(gpu_ctx, S, tmk)
+    gm = capi.Model(gpu_ctx, small_case["model"], small_case["resolution"])
+    gm.build_voxels()
+    gm.build_pairs(small_case["subset"])
+    poses = random_poses_near_truth(small_case, 24)
+    a, b = late.score_hypotheses(gm, poses, DT), early.score_hypotheses(gm, poses, DT)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[0].max() > 100
+    pairs = sample_pairs(small_case, oracle_small["model"], n_first=6, per_first=6, seed=3)
+    pa, pb = late.generate_hypotheses(gm, pairs), early.generate_hypotheses(gm, pairs)
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and len(pa[0]) > 10
+    ta, tb = late.tangent_points(), early.tangent_points()
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1].view(np.uint32), tb[1].view(np.uint32))
+
+
 def test_concurrent_calls_on_one_context(gpu_small, small_case):
     """SURVEY §8b: thread-safe per handle. The reference's workers call model::query / voxel_query and score from
     several threads at once (include/impl/scene.hpp:146-166,304); calls on one context serialise on its mutex, so

@@ -74,6 +74,8 @@ SIGNATURES = {
     "tm_cloud_resolution": (C.c_int, [vp, f32p, C.c_uint32, f32p, f32p]),
     "tm_cloud_curvature": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, f32p]),
     "tm_cloud_curvature_subset": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p]),
+    "tm_scene_curvature_subset": (C.c_int, [vp, C.c_uint32, u32p, C.c_uint32, f32p]),
+    "tm_scene_set_tangent_mask": (C.c_int, [vp, i32p]),
     "tm_cloud_create": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, C.POINTER(vp)]),
     "tm_cloud_destroy": (C.c_int, [vp]),
     "tm_cloud_tree_size": (C.c_uint32, [vp]),
@@ -768,6 +770,17 @@ class Scene:
         else:
             m, p = _i(mask)
             _check(lib().tm_scene_set_mask(self.h, p))
+
+    def curvature_subset(self, indices, k=30):
+        """curvature(k, idx) of the listed points from the scene's device copy (tm_scene_curvature_subset)"""
+        idx, pi = _u(indices)
+        out = np.zeros((len(idx), 5), np.float32)
+        _check(lib().tm_scene_curvature_subset(self.h, k, pi, len(idx), out.ctypes.data_as(f32p)))
+        return out
+
+    def set_tangent_mask(self, tangent_mask):
+        m, p = _i(tangent_mask)
+        _check(lib().tm_scene_set_tangent_mask(self.h, p))
 
     def radius_subset(self, center_idx, radius):
         cnt = C.c_uint32(0)

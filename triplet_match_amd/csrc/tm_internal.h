@@ -241,6 +241,8 @@ struct tm_scene {
     tmx::dbuf<float> d_cloud;         /* n x 12 floats: the surfels as handed over */
     tmx::dbuf<int32_t> d_tmask, d_mask;
     tmx::dbuf<uint32_t> d_order;      /* sorted slot -> original index (independent of the mask) */
+    tmx::dbuf<unsigned long long> d_keys; /* the sorted slots' curve keys (63 bits, an octree cell per 3-bit prefix step;
+                                             non-finite points ~0): what tm_scene_curvature_subset builds its tree from */
     tmx::dbuf<unsigned char> d_bounds; /* tmx::scene_bounds (tm_scene_build.hip) */
     uint64_t n_live = 0;              /* finite and unmasked points */
     /* original order (hypothesis generation addresses points by original index) */

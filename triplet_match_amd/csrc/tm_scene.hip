@@ -1750,6 +1750,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_item_hist.release();
     s->d_mask.release();
     s->d_order.release();
+    s->d_keys.release();
     s->d_bounds.release();
     s->opos.release();
     s->otan.release();
@@ -1813,6 +1814,18 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
         s->h_mask.assign(s->n, 0);
     TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)s->n * 4, hipMemcpyHostToDevice,
                                 s->ctx->stream));
+    return scene_build(s, false);
+}
+
+int tm_scene_set_tangent_mask(tm_scene* s, const int32_t* tangent_mask) {
+    TM_GUARD(s);
+    TM_REQUIRE(s && tangent_mask, TM_ERR_INVALID, "tm_scene_set_tangent_mask: null argument");
+    TM_REQUIRE(!s->h_sparse, TM_ERR_UNSUPPORTED, "tm_scene_set_tangent_mask: not for a projected scene");
+    TM_HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->h_tmask.assign(tangent_mask, tangent_mask + s->n);
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, s->h_tmask.data(), (size_t)s->n * 4, hipMemcpyHostToDevice, s->ctx->stream));
+    s->tangent_idx_ready = false; /* the ascending list of tangent points is rebuilt on its next use */
+    s->n_sorted = 0;              /* the refs of the sorted points depend on the mask: gather again, same order */
     return scene_build(s, false);
 }
 

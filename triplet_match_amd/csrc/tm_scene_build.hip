@@ -424,15 +424,15 @@ int scene_build(tm_scene* s, bool resort) {
         TM_HIP_CHECK(hipMemcpyAsync(bnd, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_scene_bounds, dim3(std::min<uint32_t>(512u, (n + 255) / 256)), blk, 0, c->stream,
                            s->d_cloud.p, n, bnd);
-        dbuf<unsigned long long> k_in, k_out;
+        dbuf<unsigned long long> k_in;
+        dbuf<unsigned long long>& k_out = s->d_keys; /* kept: the sorted keys are the skeleton of a tree over the points */
         dbuf<uint32_t> v_in;
         auto cleanup = [&]() {
             k_in.release();
-            k_out.release();
             v_in.release();
         };
         int rc;
-        if ((rc = k_in.alloc(n)) || (rc = k_out.alloc(n)) || (rc = v_in.alloc(n))) {
+        if ((rc = k_in.alloc(n)) || (rc = k_out.ensure(n)) || (rc = v_in.alloc(n))) {
             cleanup();
             return rc;
         }
