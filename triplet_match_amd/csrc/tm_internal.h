@@ -322,7 +322,7 @@ int read_timed(tm_ctx* ctx, uint64_t first, score_timing* sum, uint32_t* launche
 /* false once the context was destroyed or the process is exiting: destroy calls then free host memory only */
 bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
-int scene_upload(tm_scene* s);
+int scene_upload(tm_scene* s, const float* surfels = nullptr);
 int scene_build(tm_scene* s, bool resort);
 /* ascending indices of the points with tangent_mask set (s->d_tangent_idx, s->n_tangent), built once per scene */
 int scene_tangent_index(tm_scene* s);

@@ -378,13 +378,16 @@ __global__ __launch_bounds__(256) void k_radius_mask(const float4* __restrict__ 
 }
 
 /* uploads the cloud and the two masks (original order) */
-int scene_upload(tm_scene* s) {
+int scene_upload(tm_scene* s, const float* surfels) {
     tm_ctx* c = s->ctx;
     const uint32_t n = s->n;
     TM_FORWARD(s->d_cloud.ensure((size_t)n * 12));
     TM_FORWARD(s->d_tmask.ensure(n));
     TM_FORWARD(s->d_mask.ensure(n));
-    TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, s->h_cloud.data(), (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    /* surfels = the caller's buffer while the host mirror is still being filled on another thread (tm_scene_create),
+     * null = the mirror */
+    TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, surfels ? surfels : s->h_cloud.data(), (size_t)n * 48, hipMemcpyHostToDevice,
+                                c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, s->h_tmask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     return TM_OK;
