@@ -919,7 +919,7 @@ def test_early_drop_ball_batch_equals_per_neighbourhood_calls(gpu_small, oracle_
             os_.set_mask(None)
 
 
-def test_early_drop_interval_reductions_and_their_fallback(gpu_small, oracle_small, small_case, capfd):
+def test_early_drop_interval_reductions_and_their_fallback(gpu_ctx, gpu_small, oracle_small, small_case, capfd):
     """The continuation of the rule on interval reductions (k_ed_hist_wide) == the bit-array kernels == the oracle,
     also where the reductions cannot decide and hand the row over: nothing is ever dropped (accept_prob 0) so every
     checkpoint is visited, poses with a handful of in-grid points leave intervals without a test position, and
@@ -961,6 +961,18 @@ def test_early_drop_interval_reductions_and_their_fallback(gpu_small, oracle_sma
             assert got[0][h] == len(sc) and got[3][h] == saved, (radius, accept, h)
             assert abs(got[1][h] - score) <= SCORE_RTOL * abs(score) + SCORE_ATOL_PER_TERM * max(1, len(sc))
     assert fallbacks > 0
+    # a centre that is not a finite point has an empty neighbourhood: every hypothesis of it scores nothing
+    S2 = small_case["scene"]["surfels"].copy()
+    S2[int(cset[0]), 0] = np.nan
+    g2 = capi.Scene(gpu_ctx, S2, small_case["scene"]["tangent_mask"])
+    got = g2.score_hypotheses_early_drop_ball(gm, poses, centers, om.diameter, DT, 0.0)
+    with gpu_ctx.option("ed_hist", 0):
+        want = g2.score_hypotheses_early_drop_ball(gm, poses, centers, om.diameter, DT, 0.0)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    assert (got[0][centers == cset[0]] == 0).all() and (got[0][centers != cset[0]] > 0).any()
+    only = np.full(len(poses), cset[0], np.uint32)  # ... and a batch of nothing but such hypotheses
+    got = g2.score_hypotheses_early_drop_ball(gm, poses, only, om.diameter, DT, 0.0)
+    assert (got[0] == 0).all() and (got[1] == 0).all()
 
 
 def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_case):

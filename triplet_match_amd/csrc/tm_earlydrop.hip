@@ -1596,7 +1596,7 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
                 aw.ord_hi = wave == 0 ? wave_rows : 0xFFFFFFFFu;
             }
             if (aw.ball.blist)
-                hipLaunchKernelGGL(k_ed_hist_list, dim3((a.S + kEdListChunk - 1u) / kEdListChunk, gy), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL(k_ed_hist_list, dim3(std::max(1u, (a.S + kEdListChunk - 1u) / kEdListChunk), gy), dim3(256), 0, c->stream,
                                    aw, cu.spos, s->ed_pending.p, d_n, 0u, n_hyp, s->ed_hist.p);
             else
                 hipLaunchKernelGGL(k_ed_hist_wide, dim3(gs, gy), dim3(256), 0, c->stream, aw, cu, s->ed_pending.p, d_n, 0u,
