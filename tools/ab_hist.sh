@@ -18,7 +18,7 @@ _fixture("/tmp/c2.bin", model_n=100000, scene_n=1000000, copies=4)
 PY
 g++ -std=c++17 -O2 -Iinclude tools/e2e_demo.cpp -o /tmp/e2e_demo -Ltriplet_match_amd -ltm_hip -Wl,-rpath,$PWD/triplet_match_amd -pthread
 for v in 1 0; do
-  TM_ED_HIST=$v /tmp/e2e_demo /tmp/c2.bin 1 10 > $out/e2e_hist$v.txt 2>&1
+  TM_ED_HIST=$v /tmp/e2e_demo /tmp/c2.bin 1 10 3 3 > $out/e2e_hist$v.txt 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- /tmp/e2e_demo /tmp/c2.bin 1 10 4 > $out/e2e_under_trace.txt 2>&1
 python3 tools/trace_summary.py $out/trace --segments > $out/e2e_kernels.txt

@@ -74,6 +74,18 @@ int main(int argc, char** argv) {
                (unsigned long long)st.rounds, (unsigned long long)st.firsts_sampled, (unsigned long long)st.draws,
                (unsigned long long)st.neighbours);
     }
+    if (argc > 5) { /* a NEW scene object over the same cloud each time: what one frame of a stream costs */
+        const int frames = atoi(argv[5]);
+        for (int f = 0; f < frames; ++f) {
+            auto t5 = std::chrono::steady_clock::now();
+            scene<P> fresh(scloud);
+            fresh.set_early_drop(early_drop);
+            auto got = fresh.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
+            auto t6 = std::chrono::steady_clock::now();
+            printf("new scene %d: %.4f s -> %zu matches (search itself %.2f ms)\n", f, std::chrono::duration<double>(t6 - t5).count(),
+                   got.size(), 1e3 * fresh.last_stats().total);
+        }
+    }
     for (const auto& mt : matches) {
         double best = 1e30;
         for (const auto& t : truth) {
