@@ -115,6 +115,34 @@ def test_voxel_build_kdtree_equals_bruteforce():
     assert a.voxel_query(p) is None
 
 
+def test_voxel_grid_against_scipy():
+    """a6 pinned independently of both of the oracle's searches: the nearest model point of every voxel's query
+    position inv(to_voxel) * (i, j, k, 1) (reference include/impl/model.hpp:60-84; the matrix inverted here by numpy
+    in float64) from scipy's cKDTree. The same point wherever the nearest neighbour is unique by a margin, the same
+    distance (to float32 rounding of the query position) everywhere."""
+    from scipy.spatial import cKDTree
+    model, _ = synth.synth_model(2500, seed=11)
+    res = synth.resolution(model)
+    m = tmo.Model(model, res)
+    m.build_voxels(threads=8)
+    ext, tv = m.grid()
+    T = tv.reshape(4, 4).T.astype(np.float64)  # column-major 4x4
+    inv = np.linalg.inv(T)
+    k, j, i = np.meshgrid(np.arange(ext[2]), np.arange(ext[1]), np.arange(ext[0]), indexing="ij")  # lin = k*ex*ey + j*ex + i
+    ijk1 = np.stack([i.ravel(), j.ravel(), k.ravel(), np.ones(i.size)], axis=1).astype(np.float64)
+    q = (ijk1 @ inv.T)[:, :3]
+    pts = model[:, :3].astype(np.float64)
+    d, idx = cKDTree(pts).query(q, k=2)
+    vox = m.voxels()
+    assert vox.size == q.shape[0] > 100000
+    d_oracle = np.linalg.norm(pts[vox] - q, axis=1)
+    scale = np.abs(pts).max() + np.abs(q).max()
+    assert np.all(np.abs(d_oracle - d[:, 0]) <= 4e-6 * scale)  # the same nearest distance everywhere
+    clear = (d[:, 1] - d[:, 0]) > 2e-5 * scale                 # ... and the same point where it is the nearest by a margin
+    assert clear.mean() > 0.9
+    assert np.array_equal(vox[clear], idx[clear, 0])
+
+
 def test_query_before_init_raises():
     model, _ = synth.synth_model(200, seed=3)
     m = tmo.Model(model, synth.resolution(model))
