@@ -225,12 +225,24 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    # Stage counters (evaluations, in-grid, near, passing, staged items) are a property of the batch, and every step
+    # scores the same batch: they are read from the WARM-UP launches (measurement window with counters). The timed
+    # launches then run what a caller outside any measurement window runs — the kernel instantiation without the
+    # counters' bookkeeping — with the HIP events only (tm_ctx_enable_timing(ctx, 2)).
+    cnt = None
+    if args.warmup > 0:
+        ctx.enable_timing(1)
     for _ in range(args.warmup):
         step()[1].result()
-    # kernel timing = HIP events recorded on the library's own stream around each scoring launch, and the
-    # kernel's own counters reduced on the device; both are read AFTER the timed region. Inside it the host
-    # waits once per step, for the PREVIOUS step's 96-byte winner (an event behind its pinned copy).
-    ctx.enable_timing(True)
+    if args.warmup > 0:
+        cnt = ctx.score_timing_totals()
+        ctx.enable_timing(False)
+        if cnt["launches"] != args.warmup:
+            cnt = None
+    # kernel timing = HIP events recorded on the library's own stream around each scoring launch; read AFTER the
+    # timed region. Inside it the host waits once per step, for the PREVIOUS step's 96-byte winner (an event behind
+    # its pinned copy).
+    ctx.enable_timing(2 if cnt else 1)
     hyps = 0
     sync_all()
     t_start = time.perf_counter()
@@ -250,6 +262,10 @@ def main():
     ctx.enable_timing(False)
     if tot["launches"] != args.steps:
         log("warning: %d timed scoring launches for %d steps" % (tot["launches"], args.steps))
+    if cnt:  # per-launch counters of the warm-up window, scaled to the timed launches (same batch every step)
+        f = tot["launches"] / float(cnt["launches"])
+        for k in ("evaluations", "passing", "in_grid", "near", "staged_chunks"):
+            tot[k] = cnt[k] * f
     evals, passing = tot["evaluations"], tot["passing"]
 
     per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
@@ -301,6 +317,9 @@ def main():
                                "unavailable: the scoring kernel's sources changed since the committed PMC passes"),
                 "traffic": traffic,
                 "kernel": "k_pose_aux + k_group_cull + select + k_score_items", "kernel_ms": round(k_ms, 4),
+                "stage_counters": ("warm-up launches of the same batch (the timed launches run without the counters' "
+                                   "bookkeeping, as every launch outside a measurement window does)" if cnt else
+                                   "timed launches"),
                 # the guide's rate for uniformly random lines out of a table that fits the Infinity Cache (8.6 TB/s):
                 # the roof the measured line rate is really up against (the hot set, ~60 MB, is Infinity-Cache resident)
                 "infinity_cache_peak": INFINITY_CACHE_RANDOM_GBS,

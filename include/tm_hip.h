@@ -83,7 +83,9 @@ int tm_ctx_time_end(tm_ctx* ctx, float* ms);
 /* HIP-event timing of the scoring kernel launches on the ctx stream (bench.py roofline). While timing is
  * on, every scoring launch records an event pair and one row of device counters; nothing is copied to the
  * host and nothing synchronises until one of the two read-out calls below (they synchronise the stream).
- * tm_ctx_enable_timing(ctx, 1) opens a new measurement window (the totals start from zero). */
+ * tm_ctx_enable_timing(ctx, 1) opens a new measurement window (the totals start from zero); (ctx, 2) opens one with the
+ * events only: the stage counters read zero, and the grouped kernel runs the instantiation without their bookkeeping —
+ * the one every launch outside a measurement window runs (three to four VALU instructions per evaluation chain). */
 int tm_ctx_enable_timing(tm_ctx* ctx, int on);
 /* the most recent timed launch */
 int tm_ctx_last_score_timing(tm_ctx* ctx, float* ms, uint64_t* evaluations, uint64_t* passing,

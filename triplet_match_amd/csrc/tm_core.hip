@@ -108,6 +108,7 @@ static const opt_entry kOptions[] = {
     {"search_per_range", &options::search_per_range, 0, 1},
     {"ed_wave_rows", &options::ed_wave_rows, 0, 1 << 19},
     {"ed_prefix_list", &options::ed_prefix_list, 0, 1},
+    {"score_off32", &options::score_off32, 0, 1},
     {"ed_hist", &options::ed_hist, 0, 1},
     {"ed_ball_list", &options::ed_ball_list, 0, 1},
     {"ed_prefix_group", &options::ed_prefix_group, 0, 16},
@@ -281,6 +282,7 @@ int tm_ctx_enable_timing(tm_ctx* c, int on) {
     }
     if (on) c->n_timed = 0; /* a new measurement window */
     c->timing = on != 0;
+    c->timing_mode = on == 2 ? 2 : (on ? 1 : 0);
     return TM_OK;
 }
 

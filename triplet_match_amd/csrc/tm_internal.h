@@ -100,6 +100,7 @@ struct options {
                                  2^item_sort voxels (2..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and
                                  more against a voxel table of 256 MB and more (see score_device), 0 = never */
     int score_slot_mib = 256; /* byte budget of the grouped kernel's (group, chunk) slots per launch */
+    int score_off32 = 1;      /* 0: 64-bit addresses for the grouped kernel's gathers also when every table is below 4 GiB */
     int near_metric = 1;      /* brick filters under a plane2 / cylinder metric: 0 never, 1 when at least a tenth of
                                  the grid's bricks lies beyond the threshold (auto), 2 always */
     int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
@@ -142,6 +143,7 @@ struct tm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    int timing_mode = 0;     /* tm_ctx_enable_timing: 0 off, 1 events + stage counters, 2 events only */
     tmx::options opt;        /* switches, see tmx::options */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_ring;      /* 2 * kTimedRing, created on first use */

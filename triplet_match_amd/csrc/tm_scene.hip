@@ -601,10 +601,24 @@ __device__ __forceinline__ f3 lds_xform_dir(const float4 A, const float4 B, cons
     return make3(xy.x, xy.y, (C.x * px + C.y * py) + C.z * pz);
 }
 
+/* A gather as SGPR base + 32-bit byte offset (the `saddr` form of global_load): the 64-bit form costs three to four
+ * VALU instructions of address arithmetic and a register pair per gather, four gathers per chain. Valid while the
+ * table is below 4 GiB (k_score_items<.., W32>: voxel table, model and scene arrays, checked at the launch). */
+template <class T>
+__device__ __forceinline__ T ld_off32(const T* base, uint32_t byte_off) {
+    asm volatile("" : "+v"(byte_off)); /* keeps the offset a 32-bit value: the combiner otherwise widens index << 2 to 64 bits */
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+struct f3pack {
+    float x, y, z;
+};
+
 /* BALL: every hypothesis scores only the scene points within ca.ball_r of its own centre point (the reference's
  * nn = radius_search_inclusive(diameter, p1)): quarter-tiles conservatively by a sphere-sphere test, points exactly
  * by (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point, as k_score_culled does */
-template <bool L2, int NC, int G, bool BALL = false, bool NEAR = L2>
+/* STATS = false: without the per-stage bookkeeping (evaluations, in-grid, near, passing: three or four VALU
+ * instructions per chain) that only a measurement window with counters reads (tm_ctx_enable_timing(ctx, 1)) */
+template <bool L2, int NC, int G, bool BALL = false, bool NEAR = L2, bool W32 = false, bool STATS = true>
 __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, cull_args ca, group_args ga) {
     /* 8 KiB of LDS per wave, private to it: no workgroup barrier inside the loop */
     __shared__ __align__(16) unsigned char s_raw[4][item_lds(G, BALL)];
@@ -767,7 +781,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        evals += n * 16u / 64u + ((lane < (n * 16u) % 64u) ? 1u : 0u); /* sums to 16 n over the wave */
+        if (STATS) evals += n * 16u / 64u + ((lane < (n * 16u) % 64u) ? 1u : 0u); /* sums to 16 n over the wave */
         for (uint32_t i = 0; i < n; i += 4u * NC) {
             f3 q[NC];
             uint32_t pidx[NC], gk[NC], lin[NC], mi[NC], brick[NC], code[NC];
@@ -803,18 +817,27 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 near[k] = in[k] & (code[k] <= a.code_max);
-                n_in += in[k] ? 1u : 0u;
-                n_near += near[k] ? 1u : 0u;
+                if (STATS) {
+                    n_in += in[k] ? 1u : 0u;
+                    n_near += near[k] ? 1u : 0u;
+                }
                 lin[k] = near[k] ? lin[k] : 0u;
                 if (TM_ABLATE_EQ(a, 7)) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
             }
 #pragma unroll
-            for (int k = 0; k < NC; ++k) mi[k] = a.vox[lin[k]];
+            for (int k = 0; k < NC; ++k) mi[k] = W32 ? ld_off32(a.vox, lin[k] << 2) : a.vox[lin[k]];
             bool ok[NC];
             bool any_ok = false;
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const float* mp = a.mpos3 + 3u * (size_t)mi[k];
+                float mp[3];
+                if (W32) {
+                    const f3pack t = ld_off32(reinterpret_cast<const f3pack*>(a.mpos3), mi[k] * 12u);
+                    mp[0] = t.x, mp[1] = t.y, mp[2] = t.z;
+                } else {
+                    const float* src = a.mpos3 + 3u * (size_t)mi[k];
+                    mp[0] = src[0], mp[1] = src[1], mp[2] = src[2];
+                }
                 if (L2) {
                     float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
                     float d2 = (dx * dx + dy * dy) + dz * dz;
@@ -836,8 +859,13 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if (k0 + j < NC && ok[(k0 + j) % NC]) {
-                            sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]];
-                            mr[j] = a.mref[mi[(k0 + j) % NC]];
+                            if (W32) {
+                                sr[j] = ld_off32(a.sref, (chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]) << 4);
+                                mr[j] = ld_off32(a.mref, mi[(k0 + j) % NC] << 4);
+                            } else {
+                                sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]];
+                                mr[j] = a.mref[mi[(k0 + j) % NC]];
+                            }
                         }
                     }
 #pragma unroll
@@ -847,7 +875,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                          * two dwords to add up over the 16 lanes of the entry */
                         uint32_t w_lo = 0u, w_hi = 0u;
                         if (ok[k0 + j]) {
-                            ++pass;
+                            if (STATS) ++pass;
                             if (sr[j].w == mr[j].w) {
                                 const float4* pp = poses + 3u * gk[k0 + j];
                                 f3 r = lds_xform_dir(pp[0], pp[1], pp[2], sr[j].x, sr[j].y, sr[j].z);
@@ -885,6 +913,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         }
         if (!ga.heads) it += waves_per_xcd;
     }
+    if (!STATS) return;
     for (int off = 32; off > 0; off >>= 1) {
         evals += __shfl_down(evals, off);
         pass += __shfl_down(pass, off);
@@ -1386,6 +1415,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     TM_REQUIRE(grid.y <= 65535u, TM_ERR_UNSUPPORTED, "hypothesis batch too large for one launch");
     const size_t n_slots = culled ? (size_t)n_hyp : (size_t)grid.x * grid.y;
     size_t n_stat_slots = n_slots; /* slots the launched kernel actually writes */
+    bool stats_kept = true;        /* false: the launched kernel is an instantiation without stage counters */
     const uint32_t* d_n_items = nullptr; /* grouped kernel: device count of staged (group, chunk) items */
     TM_FORWARD(s->w_stats.ensure(n_slots));
     a.stat_slots = s->w_stats.p;
@@ -1500,6 +1530,16 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
              * resident at once, or the surplus workgroups run their share after everyone else */
             auto kern = ga.group_hyps == 16u ? (l2 ? k_score_items<true, 4, 16> : k_score_items<false, 4, 16>)
                                              : (l2 ? k_score_items<true, 4, 32> : k_score_items<false, 4, 32>);
+            /* every table a gather indexes below 4 GiB: 32-bit byte offsets (ld_off32) */
+            const bool w32 = c->opt.score_off32 && m->voxel_slots < (1ull << 30) && s->n_sorted < (1u << 28) && m->n < (1u << 28);
+            const bool stats = c->timing_mode == 1 || c->opt.debug_stats != 0;
+            if (w32 && ga.group_hyps == 16u) {
+                kern = l2 ? k_score_items<true, 4, 16, false, true, true> : k_score_items<false, 4, 16, false, false, true>;
+                if (!stats) /* nobody reads the stage counters: the kernel does not keep them */
+                    kern = l2 ? k_score_items<true, 4, 16, false, true, true, false>
+                              : k_score_items<false, 4, 16, false, false, true, false>;
+            }
+            stats_kept = stats || !(w32 && ga.group_hyps == 16u) || d_centers || near_metric;
             if (d_centers) kern = l2 ? k_score_items<true, 4, 16, true> : k_score_items<false, 4, 16, true>;
             if (near_metric)
                 kern = d_centers               ? k_score_items<false, 4, 16, true, true>
@@ -1561,10 +1601,14 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
                        s->w_scores_fx.p, n_hyp, 1.0 / kFx, (double)m->n, d_scores);
     TM_HIP_CHECK(hipGetLastError());
     if (c->timing) { /* no host synchronisation here: the counters stay on the device until asked for */
-        hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, c->stream, s->w_stats.p, (uint32_t)n_stat_slots,
-                           d_n_items,
-                           c->stats.p + (size_t)trow * kTimedWords);
-        TM_HIP_CHECK(hipGetLastError());
+        if (stats_kept) {
+            hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, c->stream, s->w_stats.p, (uint32_t)n_stat_slots,
+                               d_n_items,
+                               c->stats.p + (size_t)trow * kTimedWords);
+            TM_HIP_CHECK(hipGetLastError());
+        } else { /* events only (tm_ctx_enable_timing(ctx, 2)): the row reads zero */
+            TM_HIP_CHECK(hipMemsetAsync(c->stats.p + (size_t)trow * kTimedWords, 0, kTimedWords * 8, c->stream));
+        }
         c->timed_hyp[trow] = n_hyp;
         c->timed_evals_host[trow] = culled ? ~0ull : (uint64_t)n_hyp * n_active;
         ++c->n_timed;
