@@ -936,6 +936,22 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                                               (s_st[0][3] + s_st[1][3]) + (s_st[2][3] + s_st[3][3]));
 }
 
+/* the instantiation for a launch: metric filter / neighbourhood restriction / group size / 32-bit gathers */
+using items_kernel_t = void (*)(score_args, cull_args, group_args);
+template <bool STATS>
+static items_kernel_t items_kernel(bool l2, uint32_t group_hyps, bool ball, bool near_metric, bool w32) {
+    if (near_metric)
+        return ball               ? k_score_items<false, 4, 16, true, true, false, STATS>
+               : group_hyps == 16u ? k_score_items<false, 4, 16, false, true, false, STATS>
+                                   : k_score_items<false, 4, 32, false, true, false, STATS>;
+    if (ball) return l2 ? k_score_items<true, 4, 16, true, true, false, STATS> : k_score_items<false, 4, 16, true, false, false, STATS>;
+    if (group_hyps == 16u) {
+        if (w32) return l2 ? k_score_items<true, 4, 16, false, true, true, STATS> : k_score_items<false, 4, 16, false, false, true, STATS>;
+        return l2 ? k_score_items<true, 4, 16, false, true, false, STATS> : k_score_items<false, 4, 16, false, false, false, STATS>;
+    }
+    return l2 ? k_score_items<true, 4, 32, false, true, false, STATS> : k_score_items<false, 4, 32, false, false, false, STATS>;
+}
+
 /* sums the per-workgroup stat slots of one scoring launch into that launch's row of device counters
  * (one workgroup, plain stores: nothing for the host to wait for inside a timed loop) */
 __global__ __launch_bounds__(1024) void k_stats_reduce(const uint4* __restrict__ slots, uint32_t n_slots,
@@ -1528,23 +1544,13 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
             /* persistent waves with a static share of the items each: the grid must be exactly what is
              * resident at once, or the surplus workgroups run their share after everyone else */
-            auto kern = ga.group_hyps == 16u ? (l2 ? k_score_items<true, 4, 16> : k_score_items<false, 4, 16>)
-                                             : (l2 ? k_score_items<true, 4, 32> : k_score_items<false, 4, 32>);
             /* every table a gather indexes below 4 GiB: 32-bit byte offsets (ld_off32) */
             const bool w32 = c->opt.score_off32 && m->voxel_slots < (1ull << 30) && s->n_sorted < (1u << 28) && m->n < (1u << 28);
+            /* nobody reads the stage counters outside a measurement window with counters: the kernel does not keep them */
             const bool stats = c->timing_mode == 1 || c->opt.debug_stats != 0;
-            if (w32 && ga.group_hyps == 16u) {
-                kern = l2 ? k_score_items<true, 4, 16, false, true, true> : k_score_items<false, 4, 16, false, false, true>;
-                if (!stats) /* nobody reads the stage counters: the kernel does not keep them */
-                    kern = l2 ? k_score_items<true, 4, 16, false, true, true, false>
-                              : k_score_items<false, 4, 16, false, false, true, false>;
-            }
-            stats_kept = stats || !(w32 && ga.group_hyps == 16u) || d_centers || near_metric;
-            if (d_centers) kern = l2 ? k_score_items<true, 4, 16, true> : k_score_items<false, 4, 16, true>;
-            if (near_metric)
-                kern = d_centers               ? k_score_items<false, 4, 16, true, true>
-                       : ga.group_hyps == 16u ? k_score_items<false, 4, 16, false, true>
-                                              : k_score_items<false, 4, 32, false, true>;
+            auto kern = stats ? items_kernel<true>(l2, ga.group_hyps, d_centers != nullptr, near_metric, w32)
+                              : items_kernel<false>(l2, ga.group_hyps, d_centers != nullptr, near_metric, w32);
+            stats_kept = stats;
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
             if (per_cu < 1) per_cu = 1;
