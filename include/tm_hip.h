@@ -275,6 +275,12 @@ int tm_scene_radius_tangent_lists(tm_scene* scene, const uint32_t* centers, uint
  * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */
 int tm_pair_is_valid_sample(const tm_scene* scene, const tm_model* model, uint32_t i, uint32_t j,
                             float min_diameter_factor, float max_diameter_factor);
+/* The same filters (:293-302: distance window, collinearity, feature validity) on two surfels the caller holds, with
+ * the model's diameter and feature bounds (tm_model_get_info, tm_model_get_feature_bounds): a pure function — no
+ * handle, no lock — for a sampling loop that runs on several host threads; the mask tests of :290 are the caller's.
+ * tm_pair_is_valid_sample = mask tests + this on the scene's own rows. */
+int tm_pair_valid_raw(const float* surfel_i, const float* surfel_j, float model_diameter, float min_diameter_factor,
+                      float max_diameter_factor, const float bmin[4], const float bmax[4]);
 
 /* hypothesis generation: inner body of find_in_subset, include/impl/scene.hpp:288-319, for an
  * ordered batch of scene (i,j) sample pairs: filters -> feature -> valid -> query (first

@@ -24,7 +24,7 @@ namespace detail {
  * environment ONCE per process, on first use — never inside the search loops. */
 struct search_switches {
     bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods,
-        host_curvature_tree;
+        host_curvature_tree, sequential_sampling;
 };
 inline const search_switches& env_once() {
     static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
@@ -33,7 +33,8 @@ inline const search_switches& env_once() {
                                        std::getenv("TM_ICP_HOST_LOOP") != nullptr,
                                        std::getenv("TM_ICP_PER_CANDIDATE") != nullptr,
                                        std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr,
-                                       std::getenv("TM_HOST_CURVATURE_TREE") != nullptr};
+                                       std::getenv("TM_HOST_CURVATURE_TREE") != nullptr,
+                                       std::getenv("TM_SEQUENTIAL_SAMPLING") != nullptr};
     return sw;
 }
 
@@ -56,7 +57,16 @@ struct hip_backend {
     float model_diameter() const { return diam; }
     const float* scene_surfel(uint32_t i) const { return scloud->points[i].raw(); }
     const float* model_surfel(uint32_t i) const { return mcloud->points[i].raw(); }
+    /* raw_rows: the scene on the device holds exactly scloud's surfels (the identity search): the filters of
+     * include/impl/scene.hpp:293-302 then run on the caller's rows through the pure tm_pair_valid_raw — no handle, no
+     * lock, callable from several sampling threads (the loop has done the mask tests of :290 before it asks). A
+     * projected scene's rows live in the library: tm_pair_is_valid_sample. */
+    bool raw_rows = false;
+    float bmin[4] = {0.f, 0.f, 0.f, 0.f}, bmax[4] = {0.f, 0.f, 0.f, 0.f};
     bool pair_is_valid_sample(uint32_t i, uint32_t j) const {
+        if (raw_rows)
+            return i != j && tm_pair_valid_raw(scloud->points[i].raw(), scloud->points[j].raw(), diam, p.min_diameter_factor,
+                                               p.max_diameter_factor, bmin, bmax) != 0;
         return tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor) != 0;
     }
     /* radius_search_inclusive(radius, i), include/impl/scene.hpp:273: the ascending index lists are built on
@@ -125,6 +135,15 @@ struct hip_backend {
         /* the pairs arrive slot after slot, each slot in ascending index (= ascending rank) order */
         t_offsets.assign(batch.size() + 1, 0u);
         for (size_t k = 0; k < batch.size(); ++k) t_offsets[k + 1] = t_offsets[k] + tc[k];
+    }
+    /* search::find_parallel: fetches the views of the announced round; true = every first point of the round is in the
+     * window, so tangent_view() of any of them only reads, and the validity test runs without the library
+     * (raw_rows): the chunks may be sampled on concurrent threads */
+    bool round_views_ready(float radius) {
+        if (!raw_rows || !round_announced || upcoming.empty() || !supports_tangent_view() || env_once().sequential_sampling)
+            return false;
+        if (!(t_radius == radius && t_lo == 0 && t_hi == upcoming.size())) fetch_tangent_lists(upcoming[0], radius);
+        return t_radius == radius && t_lo == 0 && t_hi == upcoming.size();
     }
     void tangent_view(uint32_t i, float radius, size_t& n_nn, const uint32_t*& rank_index_pairs, size_t& n_pairs) {
         size_t k = t_lo;
@@ -457,6 +476,7 @@ public:
         be.mcloud = m.cloud().get();
         be.n_t = m.point_count();
         be.diam = m.diameter();
+        be.raw_rows = tm_model_get_feature_bounds(be.m, be.bmin, be.bmax) == TM_OK; /* the device scene = this cloud's rows */
         stats_ = search::stats_t();
         fill_params(be.p, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
         std::vector<search::candidate_t> found;

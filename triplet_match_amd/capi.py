@@ -111,6 +111,7 @@ SIGNATURES = {
     "tm_scene_radius_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, i32p, C.c_uint32, u32p]),
     "tm_scene_radius_tangent_lists": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, u32p, u32p, u32p, C.c_uint32, u32p]),
     "tm_pair_is_valid_sample": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
+    "tm_pair_valid_raw": (C.c_int, [f32p, f32p, C.c_float, C.c_float, C.c_float, f32p, f32p]),
     "tm_generate_hypotheses": (C.c_int, [vp, vp, u32p, C.c_uint32, C.c_float, C.c_float, C.c_int,
                                          C.c_int, f32p, u32p, C.c_uint32, u32p, u32p]),
     "tm_generate_hypotheses_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, C.c_int,

@@ -1929,17 +1929,12 @@ int tm_scene_tangent_points(const tm_scene* s, uint32_t* indices, float* surfels
     return TM_OK;
 }
 
-int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, uint32_t j, float minf,
-                            float maxf) {
-    TM_GUARD(s);
-    if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
-    if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
-    const float* a = scene_row(s, i);
-    const float* b = scene_row(s, j);
-    if (!a || !b) return 0; /* a sparse mirror holds the tangent points: i is a first sample, hence one of them */
+int tm_pair_valid_raw(const float* a, const float* b, float diameter, float minf, float maxf, const float bmin[4],
+                      const float bmax[4]) {
+    if (!a || !b || !bmin || !bmax) return 0;
     f3 p1 = make3(a[0], a[1], a[2]), p2 = make3(b[0], b[1], b[2]);
     f3 t1 = make3(a[9], a[10], a[11]), t2 = make3(b[9], b[10], b[11]);
-    float lower = m->diameter * minf, upper = m->diameter * maxf;
+    float lower = diameter * minf, upper = diameter * maxf;
     lower *= lower;
     upper *= upper;
     f3 d = p2 - p1;
@@ -1948,7 +1943,16 @@ int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, ui
     if (sq < lower || sq > upper) return 0;
     if (1.f - fabsf(dot3(d, t1)) < 0.01f) return 0;
     feat4 f = pair_feature(p1, t1, p2, t2);
-    return feature_valid(f, m->bmin[0], m->bmax[0]) ? 1 : 0;
+    return feature_valid(f, bmin[0], bmax[0]) ? 1 : 0;
+}
+
+int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, uint32_t j, float minf,
+                            float maxf) {
+    TM_GUARD(s);
+    if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
+    if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
+    /* a sparse mirror holds the tangent points: i is a first sample, hence one of them */
+    return tm_pair_valid_raw(scene_row(s, i), scene_row(s, j), m->diameter, minf, maxf, m->bmin, m->bmax);
 }
 
 int tm_generate_hypotheses_dev(tm_scene* s, tm_model* m, const uint32_t* d_ij_pairs, uint32_t n_pairs,
