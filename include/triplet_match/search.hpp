@@ -35,6 +35,8 @@
 #include <thread>
 #include <vector>
 
+#include "worker_pool.hpp"
+
 namespace triplet_match {
 namespace search {
 
@@ -334,97 +336,6 @@ template <class B>
 inline bool round_views_ready(B& be, float radius, std::true_type) { return be.round_views_ready(radius); }
 template <class B>
 inline bool round_views_ready(B&, float, std::false_type) { return false; }
-
-/* A few long-lived worker threads for the chunks of a round (the reference starts hardware_concurrency() - 1
- * std::async tasks per find_parallel call, include/impl/scene.hpp:146-166; a thread per chunk and round cost more
- * than the 1.6 ms of sampling it spread out). run(n, fn) calls fn(0 .. n-1), the caller taking part, and returns when
- * all are done; one batch at a time. The threads are created on first use and joined when the process exits. */
-class worker_pool {
-public:
-    static worker_pool& instance() {
-        static worker_pool pool;
-        return pool;
-    }
-    size_t size() const { return threads_.size(); }
-    void run(size_t n, const std::function<void(size_t)>& fn) {
-        if (n <= 1 || threads_.empty()) {
-            for (size_t i = 0; i < n; ++i) fn(i);
-            return;
-        }
-        std::lock_guard<std::mutex> one_batch(run_mutex_);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn;
-            total_ = n;
-            next_.store(0);
-            done_ = 0;
-            ++generation_;
-        }
-        cv_.notify_all();
-        work(fn, n);
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
-        job_ = nullptr;
-    }
-
-private:
-    worker_pool() {
-        const unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n = hw > 1 ? std::min(6u, hw - 1u) : 0u;
-        for (unsigned t = 0; t < n; ++t) threads_.emplace_back([this] { loop(); });
-    }
-    ~worker_pool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    void work(const std::function<void(size_t)>& fn, size_t n) {
-        size_t finished = 0;
-        for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= n) break;
-            fn(i);
-            ++finished;
-        }
-        if (finished) {
-            std::lock_guard<std::mutex> lk(m_);
-            done_ += finished;
-        }
-    }
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(size_t)>* fn = nullptr;
-            size_t n = 0;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (generation_ != seen && job_ != nullptr); });
-                if (stop_) return;
-                seen = generation_;
-                fn = job_;
-                n = total_;
-                ++active_;
-            }
-            work(*fn, n);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                --active_;
-            }
-            cv_done_.notify_all();
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_, run_mutex_;
-    std::condition_variable cv_, cv_done_;
-    const std::function<void(size_t)>* job_ = nullptr;
-    size_t total_ = 0, done_ = 0, active_ = 0;
-    std::atomic<size_t> next_{0};
-    uint64_t generation_ = 0;
-    bool stop_ = false;
-};
 
 /* does the backend run finish_find for several poses in one call? (hip_backend: tm_extract_correspondences_batch) */
 template <class B, class = void>
@@ -944,7 +855,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
          * shared state only. Here too when the backend has every neighbourhood view of the round at hand: the chunks'
          * sampling loops (80k draws per search at the configs[1] size) run on the worker pool and their batches are
          * joined in chunk order — the same batches as one chunk after the other. */
-        const bool side_by_side = chunks.size() > 1 && p.workers > 1 && detail::worker_pool::instance().size() > 0 &&
+        const bool side_by_side = chunks.size() > 1 && p.workers > 1 && ::triplet_match::detail::worker_pool::instance().size() > 0 &&
                                   detail::round_views_ready(be, be.model_diameter(), detail::has_round_views_ready<Backend>{});
         if (side_by_side) {
             detail::timed whole(p.stats ? &p.stats->sample : nullptr);
@@ -952,7 +863,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             std::vector<stats_t> chunk_stats(chunks.size());
             std::vector<std::exception_ptr> failed(chunks.size());
             cons_of.assign(chunks.size(), 0u);
-            detail::worker_pool::instance().run(chunks.size(), [&](size_t ci) {
+            ::triplet_match::detail::worker_pool::instance().run(chunks.size(), [&](size_t ci) {
                 try {
                     params_t pl = p;
                     pl.stats = p.stats ? &chunk_stats[ci] : nullptr;
