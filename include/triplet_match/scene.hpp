@@ -356,12 +356,13 @@ struct hip_backend {
             check(rc, "tm_extract_correspondences_batch");
             break;
         }
-        for (uint32_t k = 0; k < n; ++k) {
+        /* the candidates' lists copied side by side (0.4 MB each way per candidate) */
+        ::triplet_match::detail::worker_pool::instance().run(n, [&](size_t k) {
             out[k].transform = Ts[k];
             out[k].signed_score = scores[k];
             out[k].scene_corrs.assign(sc_scratch.begin() + k * stride, sc_scratch.begin() + k * stride + counts[k]);
             out[k].model_corrs.assign(mc_scratch.begin() + k * stride, mc_scratch.begin() + k * stride + counts[k]);
-        }
+        });
     }
     size_t batch_stride = 0;
     /* the whole ICP loop on the device (tm_icp_refine); TM_ICP_HOST_LOOP=1: one call per pass, fits on the host */
@@ -480,12 +481,20 @@ public:
         stats_ = search::stats_t();
         fill_params(be.p, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
         std::vector<search::candidate_t> found;
+        /* the backend's staging vectors (correspondence lists of a round's candidates, neighbourhood views: a few MB)
+         * outlive the call: a search does not allocate and zero them again */
+        be.sc_scratch.swap(keep_sc_);
+        be.mc_scratch.swap(keep_mc_);
+        be.t_pairs.swap(keep_pairs_);
         if (comm_ && tm_comm_world(comm_) > 1) {
             detail::hip_exchange hx{comm_};
             found = search::find_all(be, tangent_mask, be.p, hx);
         } else {
             found = search::find_all(be, tangent_mask, be.p);
         }
+        be.sc_scratch.swap(keep_sc_);
+        be.mc_scratch.swap(keep_mc_);
+        be.t_pairs.swap(keep_pairs_);
         std::vector<match_t> results;
         for (auto& c : found) {
             match_t r;
@@ -853,6 +862,7 @@ protected:
     typename cloud_t::Ptr cloud_;
     std::shared_ptr<detail::context_holder> ctx_;
     tm_scene* h_ = nullptr;
+    std::vector<uint32_t> keep_sc_, keep_mc_, keep_pairs_; /* hip_backend staging kept between searches */
     uint32_t last_projector_searches_ = 0;
     std::vector<uint32_t> tan_idx_; /* tangent points of the current projected scene */
     std::vector<float> tan_rows_;
