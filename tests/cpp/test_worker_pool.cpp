@@ -1,0 +1,55 @@
+// the drop-in headers' worker pool (include/triplet_match/worker_pool.hpp): every index of a batch runs exactly once,
+// batches from several callers do not mix, an exception inside a task does not wedge the pool
+#include <triplet_match/worker_pool.hpp>
+
+#include <atomic>
+#include <cstdio>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+using triplet_match::detail::worker_pool;
+
+int main() {
+    int failures = 0;
+    worker_pool& pool = worker_pool::instance();
+    for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(7), size_t(64), size_t(1000)}) {
+        for (int rep = 0; rep < 200; ++rep) {
+            std::vector<std::atomic<int>> hit(n);
+            for (auto& h : hit) h.store(0);
+            pool.run(n, [&](size_t i) { hit[i].fetch_add(1); });
+            for (size_t i = 0; i < n; ++i)
+                if (hit[i].load() != 1) ++failures;
+        }
+    }
+    {   // two callers at once: each batch sums its own indices
+        std::atomic<long> sums[2];
+        sums[0].store(0), sums[1].store(0);
+        auto caller = [&](int who) {
+            for (int rep = 0; rep < 300; ++rep) {
+                std::atomic<long> s{0};
+                pool.run(50, [&](size_t i) { s.fetch_add((long)i + who); });
+                if (s.load() != 50 * 49 / 2 + 50 * who) sums[who].fetch_add(1);
+            }
+        };
+        std::thread other(caller, 1);
+        caller(0);
+        other.join();
+        failures += (int)(sums[0].load() + sums[1].load());
+    }
+    {   // a task that throws is the caller's business (find_parallel catches inside the task); the pool must go on
+        std::atomic<int> ran{0};
+        pool.run(8, [&](size_t i) {
+            try {
+                if (i == 3) throw std::runtime_error("x");
+                ran.fetch_add(1);
+            } catch (...) {
+            }
+        });
+        if (ran.load() != 7) ++failures;
+        pool.run(8, [&](size_t) { ran.fetch_add(1); });
+        if (ran.load() != 15) ++failures;
+    }
+    std::printf("%zu workers; %s (%d failures)\n", pool.size(), failures ? "FAILED" : "PASSED", failures);
+    return failures ? 1 : 0;
+}

@@ -68,6 +68,13 @@ def test_reference_header_names_compile():
     assert r.returncode == 0 and "PASSED" in r.stdout
 
 
+def test_worker_pool():
+    """the headers' thread pool: every index once, concurrent callers, a task that throws"""
+    exe = _compile("test_worker_pool")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
 def test_host_orchestration_over_oracle_backend(tmp_path):
     exe = _compile("test_search", _oracle_link())
     fx = _fixture(str(tmp_path / "case.bin"))
