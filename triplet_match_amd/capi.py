@@ -292,7 +292,10 @@ class Context:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except TypeError:  # interpreter shutdown: the module's globals are gone already, and the process is ending
+            pass
 
     def synchronize(self):
         _check(lib().tm_ctx_synchronize(self.h))
