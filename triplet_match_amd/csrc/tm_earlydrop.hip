@@ -680,7 +680,10 @@ __global__ __launch_bounds__(256) void k_ed_score_rows(ed_args a, const uint32_t
  * [10, 29) sums, [29, 47) minima. */
 constexpr uint32_t kEdHistWords = 48, kEdHistFx = 10, kEdHistMin = 29;
 constexpr uint32_t kEdHistPosBits = 22; /* scan positions below 4,194,304 */
-constexpr int kEdNT = 4;                /* evaluations a lane keeps in flight (eval_points_staged) */
+#ifndef TM_ED_NT
+#define TM_ED_NT 2
+#endif
+constexpr int kEdNT = TM_ED_NT;                /* evaluations a lane keeps in flight (eval_points_staged) */
 
 __global__ __launch_bounds__(256) void k_ed_hist_init(unsigned long long* __restrict__ hist,
                                                       const uint32_t* __restrict__ n_pending, uint32_t row0,
@@ -805,7 +808,11 @@ __global__ __launch_bounds__(256) void k_ed_hist_wide(ed_args a, ed_cull ca, con
  * (the rows are hypotheses that passed the first checkpoint: most of their neighbourhood lands in the grid anyway)
  * and no rank look-ups — the position rides in the entry. A point inside the grid whose super-brick has no brick in
  * reach of the surface is a test position at most (score_args::super_near). */
-constexpr uint32_t kEdListChunk = 256u * 2u * (uint32_t)kEdNT;
+#ifndef TM_ED_LIST_ROUNDS
+#define TM_ED_LIST_ROUNDS 1
+#endif
+constexpr uint32_t kEdListRounds = TM_ED_LIST_ROUNDS; /* rounds of kEdNT entries per thread a workgroup takes of one row */
+constexpr uint32_t kEdListChunk = 256u * kEdListRounds * (uint32_t)kEdNT;
 __global__ __launch_bounds__(256) void k_ed_hist_list(ed_args a, const float4* __restrict__ spos,
                                                       const uint32_t* __restrict__ pending,
                                                       const uint32_t* __restrict__ n_pending, uint32_t row0,
@@ -835,7 +842,7 @@ __global__ __launch_bounds__(256) void k_ed_hist_list(ed_args a, const float4* _
         __syncthreads();
         const float per_pos = S ? 20.f / (float)S : 0.f;
         const uint2* bl = a.ball.blist + (size_t)slot * a.ball.blist_stride;
-        for (uint32_t r = 0; r < 2u; ++r) {
+        for (uint32_t r = 0; r < kEdListRounds; ++r) {
             uint32_t sidx[kEdNT], pos[kEdNT];
             f3 pt[kEdNT];
             bool live[kEdNT], tail[kEdNT], corr[kEdNT];
@@ -1588,7 +1595,8 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         uint32_t* fb_n = s->ed_fb.p + n_hyp;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-        const uint32_t gy = std::min(n_hyp, 256u);
+        /* rows side by side: a search step has a few dozen pending rows per wave, the whole batch over a thousand */
+        const uint32_t gy = std::min(n_hyp, check ? 64u : 256u);
         hipLaunchKernelGGL(k_ed_hist_init, dim3((uint32_t)(((size_t)n_hyp * kEdHistWords + 255) / 256)), dim3(256), 0,
                            c->stream, s->ed_hist.p, d_n, 0u, n_hyp, fb_n);
         for (uint32_t wave = 0; wave < (wave_rows ? 2u : 1u); ++wave) {
