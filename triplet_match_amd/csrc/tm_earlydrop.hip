@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void k_ed_hist_wide(ed_args a, ed_cull ca, con
 }
 
 /* The same reductions from the neighbourhood's own list in curve order (ed_ball::blist) instead of the scene's
- * tiles: workgroup (c, y) takes entries [2048 c, 2048 c + 2048) of the list of every row it visits. No sphere tests
+ * tiles: workgroup (c, y) takes entries [c kEdListChunk, (c + 1) kEdListChunk) (512: two per lane) of the list of every
+ * row it visits — short pieces: with 2,048 or more entries per workgroup and row the batch was a fifth slower. No sphere tests
  * (the rows are hypotheses that passed the first checkpoint: most of their neighbourhood lands in the grid anyway)
  * and no rank look-ups — the position rides in the entry. A point inside the grid whose super-brick has no brick in
  * reach of the surface is a test position at most (score_args::super_near). */
