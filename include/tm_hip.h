@@ -468,7 +468,10 @@ int tm_best_reduce(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, ui
                    tm_best_record* best);
 /* The same in two halves, so that the exchange overlaps the next batch: _begin queues all-gather, selection and
  * the copy into pinned host memory on the context's stream and returns a ticket without waiting (at most 4 in
- * flight per context, TM_ERR_CAPACITY beyond); _end waits for that reduction alone and hands out the winners.
+ * flight per context in any order of ends, TM_ERR_CAPACITY beyond — checked before anything collective, so ranks
+ * that make the same sequence of calls fail together); _end waits for that reduction alone and hands out the
+ * winners. A ticket is opaque and good once: it names the slot and that use of it, a stale one is TM_ERR_INVALID
+ * even after the slot has been handed out again.
  * Counterpart in the reference: fut.get() of the worker futures, include/impl/scene.hpp:168-171. */
 int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_local, uint32_t n_models, int* ticket);
 int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best);

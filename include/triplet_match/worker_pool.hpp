@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -17,8 +18,13 @@ namespace triplet_match {
 namespace detail {
 
 /* The reference starts hardware_concurrency() - 1 std::async tasks per find_parallel call
- * (include/impl/scene.hpp:146-166); a thread per chunk and round cost more than the 1.6 ms of sampling it spread out. run(n, fn) calls fn(0 .. n-1), the caller taking part, and returns when
- * all are done; one batch at a time. The threads are created on first use and joined when the process exits. */
+ * (include/impl/scene.hpp:146-166); a thread per chunk and round cost more than the 1.6 ms of sampling it spread
+ * out. run(n, fn) calls fn(0 .. n-1), the caller taking part, and returns when all are done; one batch at a time.
+ * The threads are created on first use and joined when the process exits.
+ * A task that throws (on the caller's thread or on a worker) does not tear anything down: the first exception is
+ * kept, the indices not yet started are passed over, run() waits until every thread has left the batch and rethrows
+ * on the caller — as the reference's fut.get() would (:168-171). run() from inside a task (a pooled task that hashes
+ * a cloud, say) runs inline on that thread instead of waiting for the pool it is part of. */
 class worker_pool {
 public:
     static worker_pool& instance() {
@@ -27,7 +33,7 @@ public:
     }
     size_t size() const { return threads_.size(); }
     void run(size_t n, const std::function<void(size_t)>& fn) {
-        if (n <= 1 || threads_.empty()) {
+        if (n <= 1 || threads_.empty() || in_task()) {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
@@ -38,13 +44,21 @@ public:
             total_ = n;
             next_.store(0);
             done_ = 0;
+            failed_.store(false);
+            error_ = nullptr;
             ++generation_;
         }
         cv_.notify_all();
         work(fn, n);
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
-        job_ = nullptr;
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
+            job_ = nullptr;
+            err = error_;
+            error_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
 private:
@@ -61,17 +75,33 @@ private:
         cv_.notify_all();
         for (auto& t : threads_) t.join();
     }
+    static bool& in_task() {
+        static thread_local bool flag = false;
+        return flag;
+    }
     void work(const std::function<void(size_t)>& fn, size_t n) {
         size_t finished = 0;
+        std::exception_ptr err;
+        bool& nested = in_task();
+        nested = true;
         for (;;) {
             const size_t i = next_.fetch_add(1);
             if (i >= n) break;
-            fn(i);
-            ++finished;
+            if (!failed_.load(std::memory_order_relaxed)) {
+                try {
+                    fn(i);
+                } catch (...) {
+                    if (!err) err = std::current_exception();
+                    failed_.store(true);
+                }
+            }
+            ++finished; /* an index passed over after a failure still counts: run() waits for done_ == total_ */
         }
-        if (finished) {
+        nested = false;
+        if (finished || err) {
             std::lock_guard<std::mutex> lk(m_);
             done_ += finished;
+            if (err && !error_) error_ = err;
         }
     }
     void loop() {
@@ -102,6 +132,8 @@ private:
     const std::function<void(size_t)>* job_ = nullptr;
     size_t total_ = 0, done_ = 0, active_ = 0;
     std::atomic<size_t> next_{0};
+    std::atomic<bool> failed_{false};
+    std::exception_ptr error_;
     uint64_t generation_ = 0;
     bool stop_ = false;
 };

@@ -1,10 +1,11 @@
 // the drop-in headers' worker pool (include/triplet_match/worker_pool.hpp): every index of a batch runs exactly once,
-// batches from several callers do not mix, an exception inside a task does not wedge the pool
+// batches from several callers do not mix, an exception inside a task does not wedge the pool (caught or escaping), nested run() calls run inline
 #include <triplet_match/worker_pool.hpp>
 
 #include <atomic>
 #include <cstdio>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -49,6 +50,32 @@ int main() {
         if (ran.load() != 7) ++failures;
         pool.run(8, [&](size_t) { ran.fetch_add(1); });
         if (ran.load() != 15) ++failures;
+    }
+    {   // a task that lets its exception escape: run() waits for every thread, rethrows the first one on the caller,
+        // nothing dangles, and the pool takes the next batch (the reference's fut.get() rethrows likewise)
+        for (int rep = 0; rep < 100; ++rep) {
+            std::atomic<int> ran{0};
+            bool caught = false;
+            try {
+                pool.run(64, [&](size_t i) {
+                    if (i == (size_t)(rep % 64)) throw std::runtime_error("escaped");
+                    ran.fetch_add(1);
+                });
+            } catch (const std::runtime_error& e) {
+                caught = std::string(e.what()) == "escaped";
+            }
+            if (!caught || ran.load() > 63) ++failures;
+            std::atomic<int> after{0};
+            pool.run(64, [&](size_t) { after.fetch_add(1); });
+            if (after.load() != 64) ++failures;
+        }
+    }
+    {   // run() from inside a pooled task (content_hash() from a task, say) runs inline instead of deadlocking
+        std::atomic<long> total{0};
+        pool.run(16, [&](size_t i) {
+            pool.run(10, [&](size_t j) { total.fetch_add((long)(i * 10 + j)); });
+        });
+        if (total.load() != 160 * 159 / 2) ++failures;
     }
     std::printf("%zu workers; %s (%d failures)\n", pool.size(), failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;

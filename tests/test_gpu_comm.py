@@ -116,6 +116,22 @@ def test_best_reduce_in_two_halves_overlaps_and_is_bounded(gpu_ctx, scored, rout
     assert capi.lib().tm_best_reduce_end(gpu_ctx.h, pend[0].ticket, out) == capi.ERR_INVALID
     # the slots are free again
     assert capi.best_reduce_begin(gpu_ctx, comm, d_best[0], 1).result()[0].inlier_count == _expected(scored, 0, 1)[0]
+    # a stale ticket stays refused after its slot has been handed out again and is busy (the ticket carries the
+    # slot's generation), and the other caller's reduction is untouched
+    stale = [p.ticket for p in pend]
+    again = [capi.best_reduce_begin(gpu_ctx, comm, d_best[k], 1) for k in range(4)]
+    assert not set(stale) & {p.ticket for p in again}
+    for t in stale:
+        assert capi.lib().tm_best_reduce_end(gpu_ctx.h, t, out) == capi.ERR_INVALID
+    # tickets ended out of order leave holes: a new begin takes any free slot instead of CAPACITY
+    assert again[2].result()[0].inlier_count == _expected(scored, *params[2])[0]
+    assert again[0].result()[0].inlier_count == _expected(scored, *params[0])[0]
+    more = [capi.best_reduce_begin(gpu_ctx, comm, d_best[1], 1), capi.best_reduce_begin(gpu_ctx, comm, d_best[3], 1)]
+    with pytest.raises(capi.TmError) as e:
+        capi.best_reduce_begin(gpu_ctx, comm, d_best[0], 1)
+    assert e.value.code == capi.ERR_CAPACITY
+    for p, k in ((again[1], 1), (again[3], 3), (more[0], 1), (more[1], 3)):
+        assert p.result()[0].inlier_count == _expected(scored, *params[k])[0]
     assert capi.comm_probe() is True
     if comm is not None:
         comm.close()

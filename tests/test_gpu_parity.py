@@ -1073,6 +1073,48 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
         gs.search_batch(gm, np.array([[0, gs.n]], np.uint32), diam, DT, 0.5, True, 0.0)
 
 
+def test_search_batches_with_a_long_pending_list(gpu_small, oracle_small, small_case):
+    """A merged segment step with more pending hypotheses than k_pending_sort's LDS rank sort holds (4096): with
+    accept_prob 0 nothing drops at the first checkpoint, so every hypothesis of the step is pending. The rows must keep
+    their batch (each batch follows ITS stop word, reference include/impl/scene.hpp:330-338 per chunk) and their visit
+    order: the merged call == one batch after the other, for thresholds that stop batches at different places."""
+    gs, gm = gpu_small["scene"], gpu_small["model"]
+    om = oracle_small["model"]
+    pairs = sample_pairs(small_case, om, n_first=96, per_first=24, seed=77)
+    diam = om.diameter
+    poses, prov, _ = gs.generate_hypotheses(gm, pairs)
+    # batches of unequal length over the sample pairs; hypothesis offsets from the provenance rows
+    cuts = np.array([0, 1, 2, 4, 7, 11, 16, 24], np.float64) / 24.0
+    offs = np.unique((cuts * len(pairs)).astype(np.uint32))
+    offs[-1] = len(pairs)
+    per_pair = np.bincount(prov[:, 0], minlength=len(pairs))
+    hyp_starts = np.concatenate([[0], np.cumsum(per_pair)])[offs]
+    in_first_step = np.minimum(np.diff(hyp_starts), 2048).sum()
+    assert in_first_step > 4096 + 512, in_first_step  # the long-list route of k_pending_sort runs
+    centers = pairs[prov[:, 0], 0].astype(np.uint32)
+    c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.0)
+    assert (dr < 0).all()  # nothing dropped: every hypothesis went through the continuation
+    order = np.sort(c[sc > 0])
+    differing_stops = 0
+    for sufficient in (float(order[len(order) // 2]), float(order[-40]), float(order[-3]), 1e9):
+        many = gs.search_batches(gm, pairs, offs, diam, DT, 0.0, True, sufficient, min_diameter_factor=0.2)
+        with gs.ctx.option("search_per_range", 1):
+            seq = gs.search_batches(gm, pairs, offs, diam, DT, 0.0, True, sufficient, min_diameter_factor=0.2)
+        with gs.ctx.option("ed_wave_rows", 0):
+            nowave = gs.search_batches(gm, pairs, offs, diam, DT, 0.0, True, sufficient, min_diameter_factor=0.2)
+        for b, (got, want_, got2) in enumerate(zip(many, seq, nowave)):
+            # the host scan over the whole-batch scores says the same
+            h0, h1 = int(hyp_starts[b]), int(hyp_starts[b + 1])
+            ok = np.nonzero((sc[h0:h1] > 0) & (c[h0:h1].astype(np.float32) > np.float32(sufficient)))[0]
+            assert want_[0] == (int(ok[0]) if len(ok) else -1), (sufficient, b)
+            assert got[:5] == want_[:5] and got2[:5] == want_[:5], (sufficient, b)
+            if want_[0] >= 0:
+                assert np.array_equal(got[5], want_[5])
+        found = [r[0] >= 0 for r in many]
+        differing_stops += int(any(found) and not all(found))
+    assert differing_stops >= 1  # some batch had its hypothesis while another was still looking
+
+
 def test_extract_batch_equals_single_calls(gpu_small, small_case):
     """tm_extract_correspondences_batch (finish_find for several poses, one read-back) == one call per pose"""
     gm, gs = gpu_small["model"], gpu_small["scene"]
@@ -1159,6 +1201,23 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
     with pytest.raises(capi.TmError) as e:
         gpu_ctx.set_option("ablate", 1)
     assert e.value.code == capi.ERR_UNSUPPORTED and b"timing" not in capi.lib().tm_version()
+    # the environment is read once, in tm_ctx_create: a leftover TM_ABLATE is ignored with a warning by the product
+    # library (it used to fail every context creation), a value out of range is an error and leaves nothing behind
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from triplet_match_amd import capi\n"
+            "try:\n"
+            "    c = capi.Context(0)\n"
+            "    print('created', c.get_option('ablate'), c.get_option('group_hyps'))\n"
+            "except capi.TmError as e:\n"
+            "    print('refused', e.code)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TM_ABLATE="1", TM_GROUP_HYPS="32"))
+    assert r.returncode == 0 and r.stdout.split() == ["created", "0", "32"] and "TM_ABLATE=1 ignored" in r.stderr, r
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, TM_GROUP_HYPS="17"))
+    assert r.returncode == 0 and r.stdout.split() == ["refused", str(capi.ERR_INVALID)], r
     # a scene of 300 points: less than one chunk
     sc = small_case["scene"]
     inst = np.nonzero(sc["instance_id"] == 0)[0][:300]

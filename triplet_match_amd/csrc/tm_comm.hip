@@ -294,8 +294,14 @@ int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_loc
     TM_REQUIRE(!comm || comm->ctx == ctx, TM_ERR_INVALID, "tm_best_reduce_begin: communicator of another context");
     *ticket = -1;
     TM_HIP_CHECK(hipSetDevice(ctx->device));
-    reduce_slot& slot = ctx->red[ctx->red_next % kReduceSlots];
-    TM_REQUIRE(!slot.busy, TM_ERR_CAPACITY, "tm_best_reduce_begin: too many reductions in flight (tm_best_reduce_end first)");
+    /* any free slot, looked for from the one after the last hand-out (tickets ended out of order leave holes). The
+     * capacity check comes before anything collective: ranks that make the same sequence of begin / end calls reach
+     * it together, so none of them is left inside the all-gather. */
+    int si = -1;
+    for (int k = 0; k < kReduceSlots && si < 0; ++k)
+        if (!ctx->red[(ctx->red_next + (uint32_t)k) % kReduceSlots].busy) si = (int)((ctx->red_next + (uint32_t)k) % kReduceSlots);
+    TM_REQUIRE(si >= 0, TM_ERR_CAPACITY, "tm_best_reduce_begin: too many reductions in flight (tm_best_reduce_end first)");
+    reduce_slot& slot = ctx->red[si];
     const size_t bytes = (size_t)n_models * sizeof(tm_best_record);
     if (slot.bytes < bytes) {
         if (slot.pinned) (void)hipHostFree(slot.pinned);
@@ -328,17 +334,19 @@ int tm_best_reduce_begin(tm_ctx* ctx, tm_comm* comm, const tm_best_record* d_loc
     TM_HIP_CHECK(hipEventRecord(slot.ev, ctx->stream));
     slot.n = n_models;
     slot.busy = true;
-    *ticket = (int)(ctx->red_next % kReduceSlots);
-    ++ctx->red_next;
+    slot.gen = (slot.gen + 1u) & 0x3FFFFFu; /* a ticket names the slot AND this use of it: good once */
+    *ticket = si | (int)(slot.gen << 8);
+    ctx->red_next = (uint32_t)si + 1u;
     return TM_OK;
 }
 
 int tm_best_reduce_end(tm_ctx* ctx, int ticket, tm_best_record* best) {
     TM_GUARD(ctx);
     TM_REQUIRE(ctx && best, TM_ERR_INVALID, "tm_best_reduce_end: null argument");
-    TM_REQUIRE(ticket >= 0 && ticket < kReduceSlots && ctx->red[ticket].busy, TM_ERR_INVALID,
-               "tm_best_reduce_end: no reduction in flight under this ticket");
-    reduce_slot& slot = ctx->red[ticket];
+    const int si = ticket & 0xFF;
+    TM_REQUIRE(ticket >= 0 && si < kReduceSlots && ctx->red[si].busy && ctx->red[si].gen == (uint32_t)(ticket >> 8),
+               TM_ERR_INVALID, "tm_best_reduce_end: no reduction in flight under this ticket");
+    reduce_slot& slot = ctx->red[si];
     slot.busy = false;
     TM_HIP_CHECK(hipEventSynchronize(slot.ev));
     memcpy(best, slot.pinned, (size_t)slot.n * sizeof(tm_best_record));

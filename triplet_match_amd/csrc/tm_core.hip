@@ -166,22 +166,43 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     TM_HIP_CHECK(hipSetDevice(device_id));
     tm_ctx* c = new tm_ctx();
     c->device = device_id;
-    TM_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    TM_HIP_CHECK(hipEventCreate(&c->ev0));
-    TM_HIP_CHECK(hipEventCreate(&c->ev1));
-    TM_FORWARD(c->stats.alloc((size_t)kTimedRing * kTimedWords));
-    for (const opt_entry& o : kOptions) { /* the one place the environment is read */
+    /* the one place the environment is read — before anything is allocated, so a bad value leaves nothing behind */
+    for (const opt_entry& o : kOptions) {
         std::string env = "TM_";
         for (const char* p = o.name; *p; ++p) env += (char)toupper((unsigned char)*p);
         if (const char* v = getenv(env.c_str())) {
-            int rc = tm_ctx_set_option(c, o.name, *v ? atoi(v) : 1);
+            const int value = *v ? atoi(v) : 1;
+#ifndef TM_TIMING_EXPERIMENTS
+            if (o.field == &options::ablate) { /* a leftover benchmarking variable must not take the product down */
+                if (value != 0)
+                    fprintf(stderr, "libtm_hip: %s=%d ignored (stage ablation exists only in the timing-experiments build)\n",
+                            env.c_str(), value);
+                continue;
+            }
+#endif
+            int rc = tm_ctx_set_option(c, o.name, value);
             if (rc != TM_OK) {
-                (void)hipStreamDestroy(c->stream);
                 delete c;
                 return rc;
             }
         }
     }
+    auto undo = [&](int rc) {
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        c->stats.release();
+        delete c;
+        return rc;
+    };
+    hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev0);
+    if (he == hipSuccess) he = hipEventCreate(&c->ev1);
+    if (he != hipSuccess) {
+        set_error("tm_ctx_create: stream / event creation failed: %s", hipGetErrorString(he));
+        return undo(TM_ERR_HIP);
+    }
+    if (int rc = c->stats.alloc((size_t)kTimedRing * kTimedWords)) return undo(rc);
     {
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
         static bool registered = false;

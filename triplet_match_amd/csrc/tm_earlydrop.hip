@@ -1450,18 +1450,78 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
 }
 
 /* The pending list of one step in visit order: ascending hypothesis index (the prefix kernel appends in no order),
- * and per row its position among the pending rows of its batch | batch << 20 (ed_args::row_info). One workgroup,
- * rank sort in LDS for up to kPendingSortMax rows; a longer list is left as it is with position 0 everywhere, which
- * makes every row part of the first wave (= no waves). */
+ * and per row its position among the pending rows of its batch | batch << 20 (ed_args::row_info). One workgroup.
+ * Up to kPendingSortMax rows: rank sort in LDS. A longer list (many batches per step, a large search_segment, scenes
+ * on which most hypotheses pass the first checkpoint): the values are distinct hypothesis indices below `vmax`, so
+ * one bit per index in `scratch` (2 * ceil(vmax / 32) words: bits, then their exclusive prefix counts) sorts them —
+ * same list, same row_info. (The first version left a long list unsorted with row_info = 0, which also zeroed the
+ * batch id: the rows of every batch then followed batch 0's stop word.) */
 constexpr uint32_t kPendingSortMax = 4096;
+__device__ __forceinline__ uint32_t pending_batch_of(const uint32_t* __restrict__ rng_starts, uint32_t n_ranges,
+                                                     uint32_t v) {
+    /* last batch whose first hypothesis is <= v (empty batches share a start: the last of them is never the owner
+     * unless it is the one that holds v, because an empty batch's start equals the next batch's) */
+    uint32_t lo = 0, hi = n_ranges; /* invariant: rng_starts[lo] <= v, hi = first candidate known to start beyond v */
+    while (lo + 1 < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (rng_starts[mid] <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(1024) void k_pending_sort(uint32_t* __restrict__ pending,
                                                        const uint32_t* __restrict__ n_pending,
                                                        const uint32_t* __restrict__ rng_starts, uint32_t n_ranges,
-                                                       uint32_t cap, uint32_t* __restrict__ row_info) {
+                                                       uint32_t cap, uint32_t* __restrict__ row_info, uint32_t vmax,
+                                                       uint32_t* __restrict__ scratch) {
     __shared__ uint32_t s_h[kPendingSortMax];
+    __shared__ uint32_t s_run;
     const uint32_t n = min(*n_pending, cap);
     if (n > kPendingSortMax) {
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) row_info[i] = 0u;
+        const uint32_t W = (vmax + 31u) / 32u;
+        uint32_t* bits = scratch;
+        uint32_t* pre = scratch + W;
+        for (uint32_t w = threadIdx.x; w < W; w += 1024) bits[w] = 0u;
+        if (threadIdx.x == 0) s_run = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t v = pending[i];
+            if (v < vmax) atomicOr(&bits[v >> 5], 1u << (v & 31u));
+        }
+        __syncthreads();
+        for (uint32_t base = 0; base < W; base += 1024) { /* exclusive prefix counts of the words, 1024 at a time */
+            const uint32_t w = base + threadIdx.x;
+            const uint32_t cnt = w < W ? (uint32_t)__popc(bits[w]) : 0u;
+            s_h[threadIdx.x] = cnt;
+            __syncthreads();
+            for (uint32_t off = 1; off < 1024; off <<= 1) {
+                const uint32_t t = threadIdx.x >= off ? s_h[threadIdx.x - off] : 0u;
+                __syncthreads();
+                s_h[threadIdx.x] += t;
+                __syncthreads();
+            }
+            const uint32_t run = s_run;
+            if (w < W) pre[w] = run + s_h[threadIdx.x] - cnt;
+            __syncthreads();
+            if (threadIdx.x == 1023) s_run = run + s_h[1023];
+            __syncthreads();
+        }
+        for (uint32_t w = threadIdx.x; w < W; w += 1024) {
+            uint32_t word = bits[w], r = pre[w];
+            while (word) {
+                const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+                word &= word - 1u;
+                const uint32_t v = w * 32u + bit;
+                uint32_t b = 0, before_batch = 0;
+                if (rng_starts) {
+                    b = pending_batch_of(rng_starts, n_ranges, v);
+                    const uint32_t lo = rng_starts[b];
+                    before_batch = pre[lo >> 5] + (uint32_t)__popc(bits[lo >> 5] & ((1u << (lo & 31u)) - 1u));
+                }
+                pending[r] = v;
+                row_info[r] = min(r - before_batch, 0xFFFFFu) | (b << 20);
+                ++r;
+            }
+        }
         return;
     }
     for (uint32_t i = threadIdx.x; i < n; i += 1024) s_h[i] = pending[i];
@@ -1470,7 +1530,7 @@ __global__ __launch_bounds__(1024) void k_pending_sort(uint32_t* __restrict__ pe
         const uint32_t v = s_h[i];
         uint32_t b = 0, lo = 0;
         if (rng_starts) {
-            while (b + 1 < n_ranges && rng_starts[b + 1] <= v) ++b;
+            b = pending_batch_of(rng_starts, n_ranges, v);
             lo = rng_starts[b];
         }
         uint32_t rank = 0, before_batch = 0;
@@ -1555,6 +1615,8 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         run_check();
         return hipGetLastError();
     }
+    /* the pending list holds hypothesis indices: local ones (< n_hyp) or, in a merged step, global ones (< a.sc.n_hyp) */
+    const uint32_t sort_vmax = std::max(n_hyp, a.sc.n_hyp);
     uint32_t* d_n = d_n_step;
     if (!d_n) {
         if (s->ed_pending.ensure((size_t)n_hyp + 1) != TM_OK) return hipErrorOutOfMemory;
@@ -1587,9 +1649,10 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         /* rows in visit order: the waves below need it, and consecutive rows are hypotheses of one first point with
          * near-identical poses — a workgroup of k_ed_hist_list takes a run of them and finds the lines of the
          * previous one in L1 / L2 */
-        if (s->ed_row_info.ensure(n_hyp) != TM_OK) return hipErrorOutOfMemory;
+        if (s->ed_row_info.ensure(n_hyp) != TM_OK || s->ed_sort_scratch.ensure(2 * (size_t)((sort_vmax + 31u) / 32u)) != TM_OK)
+            return hipErrorOutOfMemory;
         hipLaunchKernelGGL(k_pending_sort, dim3(1), dim3(1024), 0, c->stream, s->ed_pending.p, d_n, a.rng_starts, n_ranges,
-                           n_hyp, s->ed_row_info.p);
+                           n_hyp, s->ed_row_info.p, sort_vmax, s->ed_sort_scratch.p);
         if (wave_rows) aw.row_info = s->ed_row_info.p;
         if (s->ed_hist.ensure((size_t)n_hyp * kEdHistWords) != TM_OK || s->ed_fb.ensure((size_t)n_hyp + 2) != TM_OK)
             return hipErrorOutOfMemory;
@@ -1642,9 +1705,11 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
          * reports every hypothesis: one wave. */
         const uint32_t wave_rows = check && rows_cap >= n_hyp ? (uint32_t)c->opt.ed_wave_rows : 0u;
         if (wave_rows) {
-            if (s->ed_row_info.ensure(n_hyp) != TM_OK) return hipErrorOutOfMemory;
+            if (s->ed_row_info.ensure(n_hyp) != TM_OK ||
+                s->ed_sort_scratch.ensure(2 * (size_t)((sort_vmax + 31u) / 32u)) != TM_OK)
+                return hipErrorOutOfMemory;
             hipLaunchKernelGGL(k_pending_sort, dim3(1), dim3(1024), 0, c->stream, s->ed_pending.p, d_n, a.rng_starts, n_ranges,
-                               n_hyp, s->ed_row_info.p);
+                               n_hyp, s->ed_row_info.p, sort_vmax, s->ed_sort_scratch.p);
             aw.row_info = s->ed_row_info.p;
         }
         ed_args as = aw; /* k_ed_score addresses scene points by original index */
@@ -2631,13 +2696,7 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
     TM_HIP_CHECK(hipGetLastError());
     /* sizes and tangent counts in one read-back, then exactly the pairs that were written */
     const size_t head = 2 * (size_t)n_centers * 4;
-    if (s->h_pinned_bytes < head + 64) {
-        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-        s->h_pinned = nullptr;
-        s->h_pinned_bytes = 0;
-        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, 1 << 20, hipHostMallocDefault));
-        s->h_pinned_bytes = 1 << 20;
-    }
+    TM_FORWARD(tmx::scene_pinned_ensure(s, head + 64));
     TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_S.p, head, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     memcpy(counts, s->h_pinned, (size_t)n_centers * 4);
@@ -2649,13 +2708,7 @@ extern "C" int tm_scene_radius_tangent_lists(tm_scene* s, const uint32_t* center
     if (total == 0) return TM_OK;
     TM_REQUIRE(pairs && cap_pairs >= total, TM_ERR_CAPACITY, "tm_scene_radius_tangent_lists: room for fewer pairs than found");
     const size_t need = (size_t)total * 8;
-    if (s->h_pinned_bytes < need) {
-        (void)hipHostFree(s->h_pinned);
-        s->h_pinned = nullptr;
-        s->h_pinned_bytes = 0;
-        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
-        s->h_pinned_bytes = need + need / 4;
-    }
+    TM_FORWARD(tmx::scene_pinned_ensure(s, need));
     TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, d_csr, need, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     memcpy(pairs, s->h_pinned, need);
@@ -2699,13 +2752,7 @@ extern "C" int tm_scene_radius_lists(tm_scene* s, const uint32_t* centers, uint3
     /* one copy into pinned staging memory (a pageable destination moves at a fraction of the PCIe rate), then the
      * rows go to the caller's buffer */
     const size_t need = (size_t)n_centers * S_max * 4;
-    if (s->h_pinned_bytes < need) {
-        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-        s->h_pinned = nullptr;
-        s->h_pinned_bytes = 0;
-        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
-        s->h_pinned_bytes = need + need / 4;
-    }
+    TM_FORWARD(tmx::scene_pinned_ensure(s, need));
     TM_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->ed_subset.p, need, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (uint32_t k = 0; k < n_centers; ++k)

@@ -129,6 +129,7 @@ struct reduce_slot {
     size_t bytes = 0;
     hipEvent_t ev = nullptr;
     uint32_t n = 0;
+    uint32_t gen = 0; /* incremented per hand-out; part of the ticket, so a stale ticket is refused after reuse */
     bool busy = false;
 };
 
@@ -289,6 +290,7 @@ struct tm_scene {
     tmx::dbuf<uint2> ed_blist;         /* every member of every neighbourhood in curve order (ed_ball::blist) */
     tmx::dbuf<uint32_t> ed_blist_n;
     tmx::dbuf<uint32_t> ed_plist_n;    /* their counts, then the cut-off B per slot */
+    tmx::dbuf<uint32_t> ed_sort_scratch; /* k_pending_sort beyond its LDS rank sort: one bit per hypothesis + prefix counts */
     tmx::dbuf<uint32_t> ed_row_info;   /* per pending row: position among its batch's pending rows | batch << 20 */
     tmx::dbuf<unsigned long long> ed_hist; /* k_ed_hist_wide: interval counts / sums / minima per pending row */
     tmx::dbuf<uint32_t> ed_fb;      /* rows k_ed_hist_walk hands to the bit-array kernel, + one count per wave */
@@ -328,6 +330,18 @@ int scene_upload(tm_scene* s, const float* surfels = nullptr);
 int scene_build(tm_scene* s, bool resort);
 /* ascending indices of the points with tangent_mask set (s->d_tangent_idx, s->n_tangent), built once per scene */
 int scene_tangent_index(tm_scene* s);
+/* the scene's pinned staging buffer (s->h_pinned) with room for at least `need` bytes; grown with a quarter of head
+ * room and never below 1 MiB, so the small read-backs of a search do not reallocate it */
+inline int scene_pinned_ensure(tm_scene* s, size_t need) {
+    if (s->h_pinned_bytes >= need && s->h_pinned) return TM_OK;
+    if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    s->h_pinned = nullptr;
+    s->h_pinned_bytes = 0;
+    const size_t bytes = std::max(need + need / 4, (size_t)1 << 20);
+    TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, bytes, hipHostMallocDefault));
+    s->h_pinned_bytes = bytes;
+    return TM_OK;
+}
 /* host mirror row of point i (12 floats), or null for a point a sparse mirror does not hold */
 const float* scene_row(const tm_scene* s, uint32_t i);
 }

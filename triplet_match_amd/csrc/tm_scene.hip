@@ -1792,6 +1792,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->d_tangent_idx.release();
     s->ed_tlist.release();
     s->ed_row_info.release();
+    s->ed_sort_scratch.release();
     s->ed_plist.release();
     s->ed_plist_n.release();
     s->ed_plist_p.release();
@@ -2216,13 +2217,7 @@ int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* pose
     if (!(scene_corrs || model_corrs) || total == 0) return TM_OK;
     TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
     const size_t need = total * 8;
-    if (s->h_pinned_bytes < need) {
-        if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-        s->h_pinned = nullptr;
-        s->h_pinned_bytes = 0;
-        TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, need + need / 4, hipHostMallocDefault));
-        s->h_pinned_bytes = need + need / 4;
-    }
+    TM_FORWARD(tmx::scene_pinned_ensure(s, need));
     uint32_t* stage = (uint32_t*)s->h_pinned;
     size_t off = 0;
     for (uint32_t k = 0; k < n; ++k) {
