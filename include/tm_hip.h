@@ -63,6 +63,12 @@ void* tm_ctx_stream(tm_ctx* ctx); /* hipStream_t all kernels of this ctx are lau
 /* device scratch owned by the ctx (for callers without their own allocator) */
 int tm_device_alloc(tm_ctx* ctx, uint64_t bytes, void** d_ptr);
 int tm_device_free(tm_ctx* ctx, void* d_ptr);
+/* The context's cache of released device blocks (work buffers of the calls, the arrays of destroyed scenes and
+ * models): a block goes to the next request of its size class instead of hipFree + hipMalloc, in stream order on the
+ * context's one stream. Budget = option "pool_mib" (default 1024 MiB, 0 = no cache; a smaller value trims at once).
+ * cached_bytes = held right now, reused / allocated = requests served from the cache / by hipMalloc so far. The
+ * reference has no counterpart (host vectors, include/impl/scene.hpp:424-430). */
+int tm_ctx_pool_stats(const tm_ctx* ctx, uint64_t* cached_bytes, uint64_t* reused, uint64_t* allocated);
 int tm_memcpy_h2d(tm_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 /* Switches of a context (cross-check kernels, timing comparisons; none changes a result). Every switch NAME is
@@ -71,7 +77,7 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
  * score_parts, score_slot_mib, item_sort, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
  * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
- * ed_prefix_group, score_off32 (DESIGN.md section 6 says what each selects).
+ * ed_prefix_group, score_off32, pool_mib (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */
@@ -153,6 +159,16 @@ int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uin
 int tm_scene_curvature_subset(tm_scene* scene, uint32_t k, const uint32_t* indices, uint32_t n_idx, float* curv5);
 /* replaces tangent_mask_ of an existing scene (the sorted order and the cloud stay) */
 int tm_scene_set_tangent_mask(tm_scene* scene, const int32_t* tangent_mask);
+/* tangent_mask_ built where the cloud already is (include/impl/scene.hpp:46-54 in one call on the device):
+ *   mask[i] = |tangent(p_i)| > min_norm  [&& ok[i] != 0]  && (k == 0 || pc_min(i) / pc_max(i) < max_ratio)
+ * (reference: 0.7, 0.2, k = 30; ok may be null), the curvature as tm_scene_curvature_subset computes it for exactly the
+ * points that pass the first tests. The mask becomes the scene's (as tm_scene_set_tangent_mask) and is handed back:
+ * tangent_mask (n entries), the candidates in ascending order with their curvature rows (cap entries / 5 * cap floats;
+ * TM_ERR_CAPACITY with *n_candidates set if more were found), each optional. Same mask as the three calls
+ * and the host loop it replaces, bit for bit. */
+int tm_scene_auto_tangent_mask(tm_scene* scene, uint32_t k, float min_norm, float max_ratio, const unsigned char* ok,
+                               int32_t* tangent_mask, uint32_t* candidates, float* curv5, uint32_t cap,
+                               uint32_t* n_candidates, uint32_t* n_tangent);
 
 /* ---- neighbour queries of pointcloud<Point> (include/pointcloud:38-63, include/impl/pointcloud.hpp:100-210) ----
  * tm_cloud = the cloud's search structure: kdtree() / build_tree_ (:100-136, :224-240), over all finite points or
@@ -230,7 +246,10 @@ int tm_model_query_key(const tm_model* model, const uint32_t key[4], uint32_t* p
 int tm_model_voxel_query(const tm_model* model, const float pos4[4], uint32_t* index, int* found);
 
 /* ---- scene: replaces scene<Point> (include/scene:10-59, include/impl/scene.hpp) ---- */
-/* scene(cloud) + tangent_mask_ (include/impl/scene.hpp:42,50-53) */
+/* scene(cloud) + tangent_mask_ (include/impl/scene.hpp:42,50-53). tangent_mask may be null: no tangent point yet
+ * (tm_scene_auto_tangent_mask builds the reference's mask on the device, tm_scene_set_tangent_mask takes one). The
+ * cloud is copied to the device only; host-side helpers that read rows (tm_scene_download, tm_pair_is_valid_sample,
+ * tm_scene_tangent_points) fetch a host mirror from there on first use. */
 int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
                     tm_scene** scene);
 int tm_scene_destroy(tm_scene* scene);

@@ -152,64 +152,72 @@ public:
     }
 
     /* curvature(k, idx), include/impl/pointcloud.hpp:200-204: kNN-k + principal curvatures of the projected
-     * normals (tm_cloud_curvature, GPU); all points are computed on first use and cached per k */
+     * normals (tm_cloud_curvature, GPU); all points are computed on first use and cached per k. A partial cache
+     * (store_curvature / prepare_curvature: the rows of the points a mask loop reads) answers for its points. */
     curvature_info_t curvature(uint32_t k, uint32_t idx) const {
-        const bool have = curv_k_ == k && curv_.size() == 5 * points.size();
-        if (!have || (!curv_have_.empty() && !curv_have_[idx])) { /* nothing yet, or a partial cache without idx */
-            curv_.assign(5 * points.size(), 0.f);
-            curv_have_.clear(); /* empty = every point */
-            auto ctx = detail::default_context(0);
-            if (!points.empty())
-                detail::check(tm_cloud_curvature(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, curv_.data()),
-                              "tm_cloud_curvature");
-            curv_k_ = k;
-            curv_hash_ = content_hash();
+        const float* row = nullptr;
+        if (curv_k_ == k && curv_sparse_) {
+            auto it = std::lower_bound(curv_idx_.begin(), curv_idx_.end(), idx);
+            if (it != curv_idx_.end() && *it == idx) row = &curv_rows_[5 * (size_t)(it - curv_idx_.begin())];
+        }
+        if (!row) {
+            if (!(curv_k_ == k && !curv_sparse_ && curv_.size() == 5 * points.size())) { /* nothing yet, or a partial cache without idx */
+                curv_.assign(5 * points.size(), 0.f);
+                auto ctx = detail::default_context(0);
+                if (!points.empty())
+                    detail::check(tm_cloud_curvature(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, curv_.data()),
+                                  "tm_cloud_curvature");
+                curv_sparse_ = false;
+                curv_idx_.clear();
+                curv_rows_.clear();
+                curv_k_ = k;
+                curv_hash_ = content_hash();
+            }
+            row = &curv_[5 * (size_t)idx];
         }
         curvature_info_t c;
-        c.pc_max_dir = {curv_[5 * (size_t)idx], curv_[5 * (size_t)idx + 1], curv_[5 * (size_t)idx + 2]};
-        c.pc_min = curv_[5 * (size_t)idx + 3];
-        c.pc_max = curv_[5 * (size_t)idx + 4];
+        c.pc_max_dir = {row[0], row[1], row[2]};
+        c.pc_min = row[3];
+        c.pc_max = row[4];
         return c;
     }
     /* curvature(k, .) of the listed points in one go (tm_cloud_curvature_subset): what model::init and
      * scene::find_all_parallel ask before their mask loops — they read the curvature of the points that pass the
      * tangent test only (include/impl/model.hpp:96-99, scene.hpp:50), 4 % of a cloud, where the reference computes
-     * all of them (:68-71, :48-49). A later curvature(k, idx) of another point recomputes the whole cloud. */
+     * all of them (:68-71, :48-49). A later curvature(k, idx) of another point recomputes the whole cloud.
+     * `indices` ascending. */
     bool has_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
-        if (curv_k_ != k || curv_.size() != 5 * points.size()) return false;
-        if (!curv_have_.empty())
-            for (uint32_t i : indices)
-                if (!curv_have_[i]) return false;
+        if (curv_k_ != k) return false;
+        if (!curv_sparse_) return curv_.size() == 5 * points.size();
+        size_t at = 0; /* both lists ascend: one pass */
+        for (uint32_t i : indices) {
+            while (at < curv_idx_.size() && curv_idx_[at] < i) ++at;
+            if (at == curv_idx_.size() || curv_idx_[at] != i) return false;
+        }
         return true;
     }
-    /* rows computed elsewhere for this cloud's content (tm_scene_curvature_subset on a scene's device copy of it) */
-    void store_curvature(uint32_t k, const std::vector<uint32_t>& indices, const std::vector<float>& rows) const {
-        curv_.assign(5 * points.size(), 0.f);
-        curv_have_.assign(points.size(), 0);
-        for (size_t q = 0; q < indices.size(); ++q) {
-            std::memcpy(&curv_[5 * (size_t)indices[q]], &rows[5 * q], 20);
-            curv_have_[indices[q]] = 1;
-        }
+    /* rows computed elsewhere for this cloud's content (tm_scene_curvature_subset / tm_scene_auto_tangent_mask on a
+     * scene's device copy of it); kept as (ascending index, row) pairs — a dense array cost 20 MB of stores per million
+     * points for 40k rows. `hash` = content_hash() of the content they belong to. */
+    void store_curvature(uint32_t k, std::vector<uint32_t> indices, std::vector<float> rows, uint64_t hash) const {
+        curv_idx_ = std::move(indices);
+        curv_rows_ = std::move(rows);
+        curv_sparse_ = true;
+        curv_.clear();
+        curv_.shrink_to_fit();
         curv_k_ = k;
-        curv_hash_ = content_hash();
+        curv_hash_ = hash;
     }
     void prepare_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
         if (has_curvature(k, indices)) return;
-        curv_.assign(5 * points.size(), 0.f);
-        curv_have_.assign(points.size(), 0);
+        std::vector<float> rows(5 * indices.size());
         if (!indices.empty()) {
             auto ctx = detail::default_context(0);
-            std::vector<float> rows(5 * indices.size());
             detail::check(tm_cloud_curvature_subset(ctx->ctx, points[0].raw(), (uint32_t)points.size(), k, indices.data(),
                                                     (uint32_t)indices.size(), rows.data()),
                           "tm_cloud_curvature_subset");
-            for (size_t q = 0; q < indices.size(); ++q) {
-                std::memcpy(&curv_[5 * (size_t)indices[q]], &rows[5 * q], 20);
-                curv_have_[indices[q]] = 1;
-            }
         }
-        curv_k_ = k;
-        curv_hash_ = content_hash();
+        store_curvature(k, indices, std::move(rows), content_hash());
     }
 
     /* ---- neighbour accessors (include/pointcloud:38-63) ---- */
@@ -340,8 +348,10 @@ private:
     mutable float resolution_ = -1.f;
     bool resolution_fixed_ = false;
     mutable float diameter_ = -1.f;
-    mutable std::vector<float> curv_;
-    mutable std::vector<uint8_t> curv_have_; /* which rows of curv_ are filled; empty = all */
+    mutable std::vector<float> curv_;         /* every point's row (dense cache) ... */
+    mutable std::vector<uint32_t> curv_idx_;  /* ... or the rows of these points only, ascending (partial cache) */
+    mutable std::vector<float> curv_rows_;
+    mutable bool curv_sparse_ = false;
     mutable uint32_t curv_k_ = 0;
     mutable uint64_t curv_hash_ = 0;
 };

@@ -2,6 +2,7 @@
 the CPU oracle on the same seeded inputs. Bar: bit-exact for keys, hashes, table contents, voxel
 indices, inlier counts, correspondences and (here) poses; scores (fp64 sums of fp32 terms,
 order-free fixed-point accumulation on the GPU) to 1e-9 relative plus 2^-40 per summed term (raw early-drop sums can be tiny)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -1373,6 +1374,46 @@ def test_scene_curvature_and_late_tangent_mask(gpu_ctx, oracle_small, small_case
     assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and len(pa[0]) > 10
     ta, tb = late.tangent_points(), early.tangent_points()
     assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1].view(np.uint32), tb[1].view(np.uint32))
+    # tangent_mask_ built on the device in one call (tm_scene_auto_tangent_mask) == the reference's loop
+    # (include/impl/scene.hpp:46-54) over the oracle's curvature, with and without the `ok` flags and the curvature test
+    T = S[:, 9:12]
+    nrm = np.sqrt(((T[:, 0] * T[:, 0] + T[:, 1] * T[:, 1]) + T[:, 2] * T[:, 2]).astype(np.float32))
+    curv = tmo.cloud_curvature(S, 30)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio_ok = (curv[:, 3] / curv[:, 4]) < np.float32(0.2)
+    ok = (np.arange(len(S)) % 5 != 0).astype(np.uint8)
+    for use_ok, k in ((False, 30), (True, 30), (False, 0), (True, 7)):
+        cand_want = (nrm > np.float32(0.7)) & ((ok != 0) if use_ok else True)
+        if k == 30:
+            want_mask = cand_want & ratio_ok
+        elif k == 0:
+            want_mask = cand_want
+        else:
+            rows_k = gpu_ctx.cloud_curvature_subset(S, np.nonzero(cand_want)[0].astype(np.uint32), k)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rk = (rows_k[:, 3] / rows_k[:, 4]) < np.float32(0.2)
+            want_mask = cand_want.copy()
+            want_mask[np.nonzero(cand_want)[0]] = rk
+        auto = capi.Scene(gpu_ctx, S, np.zeros(len(S), np.int32))
+        got_mask, cand, rows = auto.auto_tangent_mask(k, 0.7, 0.2, ok if use_ok else None)
+        assert np.array_equal(cand, np.nonzero(cand_want)[0]), (use_ok, k)
+        assert np.array_equal(got_mask != 0, want_mask), (use_ok, k)
+        if k == 30:
+            assert np.array_equal(rows.view(np.uint32), curv[cand].view(np.uint32))
+        assert want_mask.sum() > 50
+        # ... and the scene behaves as one created with that mask
+        twin = capi.Scene(gpu_ctx, S, want_mask.astype(np.int32))
+        a, b = auto.score_hypotheses(gm, poses, DT), twin.score_hypotheses(gm, poses, DT)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        ta, tb = auto.tangent_points(), twin.tangent_points()
+        assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1].view(np.uint32), tb[1].view(np.uint32))
+        assert np.array_equal(auto.download()[1], want_mask.astype(np.int32))
+    # room for fewer candidates than there are: the count comes back with TM_ERR_CAPACITY
+    nc = C.c_uint32(0)
+    small = np.zeros(4, np.uint32)
+    rc = capi.lib().tm_scene_auto_tangent_mask(auto.h, 30, 0.7, 0.2, None, None, small.ctypes.data_as(capi.u32p), None, 4,
+                                               C.byref(nc), None)
+    assert rc == capi.ERR_CAPACITY and nc.value == int((nrm > np.float32(0.7)).sum())
 
 
 def test_concurrent_calls_on_one_context(gpu_small, small_case):

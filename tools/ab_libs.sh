@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-run comparison of several builds of the library on the bench batch: tools/ab_libs.sh <reps> <lib.so>...
+reps=$1; shift
+cd $GRAFT_REPO_ROOT
+for r in $(seq 1 $reps); do
+  for L in "$@"; do
+    TM_LIB=$PWD/$L python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%-44s value %.0f  ms/step %.3f  kernel_ms %.4f  best %s' % ('$L', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['best']['inlier_count']))
+"
+  done
+done

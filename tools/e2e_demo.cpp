@@ -1,6 +1,7 @@
 /* e2e_demo.cpp — times the drop-in scene<Point>::find_all_parallel on a fixture written by
  * tests/test_cpp_dropin.py::_fixture (model, scene, resolution, ground-truth poses).
- * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] [repeats of the search on the kept scene] */
+ * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] [repeats of the search on the kept scene]
+ *        [new scene objects over the same cloud] [new clouds] */
 #include <chrono>
 #include <cstdio>
 #include <fstream>
@@ -83,6 +84,23 @@ int main(int argc, char** argv) {
             auto got = fresh.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
             auto t6 = std::chrono::steady_clock::now();
             printf("new scene %d: %.4f s -> %zu matches (search itself %.2f ms)\n", f, std::chrono::duration<double>(t6 - t5).count(),
+                   got.size(), 1e3 * fresh.last_stats().total);
+        }
+    }
+    if (argc > 6) { /* a NEW cloud (one coordinate nudged: other content) and a new scene per call: a frame of a live
+                     * stream, nothing cached — upload, curve order, curvature of the tangent candidates, masks, search */
+        const int frames = atoi(argv[6]);
+        for (int f = 0; f < frames; ++f) {
+            auto fcloud = pointcloud<P>::empty();
+            fcloud->points = scloud->points;
+            fcloud->points[(size_t)f * 7919u % fcloud->points.size()].x += 1e-4f;
+            auto t5 = std::chrono::steady_clock::now();
+            scene<P> fresh(fcloud);
+            fresh.set_early_drop(early_drop);
+            fresh.set_verbose(getenv("TM_FRAME_VERBOSE") != nullptr);
+            auto got = fresh.find_all_parallel(m, 3.0f, 0.5f, 0.9f, sp, icp);
+            auto t6 = std::chrono::steady_clock::now();
+            printf("new cloud %d: %.4f s -> %zu matches (search itself %.2f ms)\n", f, std::chrono::duration<double>(t6 - t5).count(),
                    got.size(), 1e3 * fresh.last_stats().total);
         }
     }

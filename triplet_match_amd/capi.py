@@ -46,6 +46,7 @@ SIGNATURES = {
     "tm_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "tm_ctx_destroy": (C.c_int, [vp]),
     "tm_ctx_synchronize": (C.c_int, [vp]),
+    "tm_ctx_pool_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tm_ctx_stream": (vp, [vp]),
     "tm_device_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "tm_device_free": (C.c_int, [vp, vp]),
@@ -76,6 +77,8 @@ SIGNATURES = {
     "tm_cloud_curvature_subset": (C.c_int, [vp, f32p, C.c_uint32, C.c_uint32, u32p, C.c_uint32, f32p]),
     "tm_scene_curvature_subset": (C.c_int, [vp, C.c_uint32, u32p, C.c_uint32, f32p]),
     "tm_scene_set_tangent_mask": (C.c_int, [vp, i32p]),
+    "tm_scene_auto_tangent_mask": (C.c_int, [vp, C.c_uint32, C.c_float, C.c_float, C.c_void_p, i32p, u32p, f32p, C.c_uint32,
+                                             u32p, u32p]),
     "tm_cloud_create": (C.c_int, [vp, f32p, C.c_uint32, u32p, C.c_uint32, C.POINTER(vp)]),
     "tm_cloud_destroy": (C.c_int, [vp]),
     "tm_cloud_tree_size": (C.c_uint32, [vp]),
@@ -299,6 +302,12 @@ class Context:
 
     def synchronize(self):
         _check(lib().tm_ctx_synchronize(self.h))
+
+    def pool_stats(self):
+        """tm_ctx_pool_stats: (cached bytes, requests served from the cache, requests served by hipMalloc)"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().tm_ctx_pool_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_option(self, name, value):
         """tm_ctx_set_option: a cross-check / timing switch of this context (never the environment)."""
@@ -785,6 +794,23 @@ class Scene:
     def set_tangent_mask(self, tangent_mask):
         m, p = _i(tangent_mask)
         _check(lib().tm_scene_set_tangent_mask(self.h, p))
+
+    def auto_tangent_mask(self, k=30, min_norm=0.7, max_ratio=0.2, ok=None):
+        """tm_scene_auto_tangent_mask: tangent_mask_ of the reference built on the device; returns
+        (tangent_mask int32[n], candidates uint32[c], curv5 float32[c, 5]) and makes the mask the scene's"""
+        okp = None
+        if ok is not None:
+            ok = np.ascontiguousarray(ok, dtype=np.uint8)
+            okp = ok.ctypes.data_as(C.c_void_p)
+        mask = np.zeros(self.n, np.int32)
+        nc, nt = C.c_uint32(0), C.c_uint32(0)
+        cand = np.zeros(self.n, np.uint32)
+        rows = np.zeros((self.n, 5), np.float32)
+        _check(lib().tm_scene_auto_tangent_mask(self.h, k, min_norm, max_ratio, okp, mask.ctypes.data_as(i32p),
+                                                cand.ctypes.data_as(u32p), rows.ctypes.data_as(f32p), self.n,
+                                                C.byref(nc), C.byref(nt)))
+        assert nt.value == int(mask.sum())
+        return mask, cand[:nc.value].copy(), rows[:nc.value].copy()
 
     def radius_subset(self, center_idx, radius):
         cnt = C.c_uint32(0)

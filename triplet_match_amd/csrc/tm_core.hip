@@ -74,6 +74,92 @@ static void mark_exit() {
 }  // namespace tmx
 
 namespace tmx {
+tm_ctx*& current_ctx_slot() {
+    static thread_local tm_ctx* cur = nullptr;
+    return cur;
+}
+
+/* size classes of the block cache: three significant bits (at most 12.5 % above the request), 4 KiB at least */
+static size_t pool_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    int top = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (top - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+
+static void pool_trim_locked(device_pool& pool, size_t keep) {
+    while (pool.cached_bytes > keep && !pool.free_blocks.empty()) {
+        auto it = std::prev(pool.free_blocks.end()); /* largest first: the least likely to be asked for again */
+        pool.cached_bytes -= it->first;
+        (void)hipFree(it->second);
+        pool.free_blocks.erase(it);
+    }
+}
+
+void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner) {
+    tm_ctx* c = current_ctx();
+    if (bytes == 0) bytes = 1;
+    *owner = nullptr;
+    *capacity = bytes;
+    void* p = nullptr;
+    if (c && c->opt.pool_mib > 0) {
+        const size_t cap = pool_class(bytes);
+        {
+            std::lock_guard<std::mutex> lk(c->pool.mu);
+            auto it = c->pool.free_blocks.find(cap);
+            if (it != c->pool.free_blocks.end()) {
+                p = it->second;
+                c->pool.cached_bytes -= cap;
+                c->pool.free_blocks.erase(it);
+                ++c->pool.hits;
+            } else {
+                ++c->pool.misses;
+            }
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, cap);
+            if (e != hipSuccess) { /* give the cache back to the device and try once more */
+                (void)hipGetLastError();
+                std::lock_guard<std::mutex> lk(c->pool.mu);
+                pool_trim_locked(c->pool, 0);
+                e = hipMalloc(&p, cap);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("hipMalloc(%zu bytes) failed: %s", cap, hipGetErrorString(e));
+                return nullptr;
+            }
+        }
+        *capacity = cap;
+        *owner = c;
+        return p;
+    }
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void device_give(void* p, size_t capacity, tm_ctx* owner) {
+    if (!p) return;
+    /* back to its context's cache while that context lives and keeps one; a block larger than half the budget is
+     * not worth holding on to (a voxel table) */
+    if (owner && ctx_alive(owner) && owner->opt.pool_mib > 0) {
+        const size_t limit = (size_t)owner->opt.pool_mib << 20;
+        if (capacity <= limit / 2) {
+            std::lock_guard<std::mutex> lk(owner->pool.mu);
+            owner->pool.free_blocks.emplace(capacity, p);
+            owner->pool.cached_bytes += capacity;
+            pool_trim_locked(owner->pool, limit);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 struct opt_entry {
     const char* name;
     int options::*field;
@@ -112,6 +198,7 @@ static const opt_entry kOptions[] = {
     {"ed_hist", &options::ed_hist, 0, 1},
     {"ed_ball_list", &options::ed_ball_list, 0, 1},
     {"ed_prefix_group", &options::ed_prefix_group, 0, 16},
+    {"pool_mib", &options::pool_mib, 0, 1 << 20},
 };
 }  // namespace tmx
 
@@ -134,6 +221,10 @@ int tm_ctx_set_option(tm_ctx* c, const char* name, int value) {
         }
 #endif
         c->opt.*(o.field) = value;
+        if (o.field == &options::pool_mib) { /* a smaller budget takes effect at once */
+            std::lock_guard<std::mutex> lk(c->pool.mu);
+            pool_trim_locked(c->pool, (size_t)value << 20);
+        }
         return TM_OK;
     }
     set_error("tm_ctx_set_option: unknown option '%s'", name);
@@ -227,6 +318,10 @@ int tm_ctx_destroy(tm_ctx* c) {
     c->scratch.release();
     c->stats.release();
     c->red_out.release();
+    {
+        std::lock_guard<std::mutex> lk(c->pool.mu);
+        pool_trim_locked(c->pool, 0);
+    }
     for (reduce_slot& r : c->red) {
         if (r.pinned) (void)hipHostFree(r.pinned);
         if (r.ev) (void)hipEventDestroy(r.ev);
@@ -236,6 +331,16 @@ int tm_ctx_destroy(tm_ctx* c) {
     for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return TM_OK;
+}
+
+int tm_ctx_pool_stats(const tm_ctx* c, uint64_t* cached_bytes, uint64_t* reused, uint64_t* allocated) {
+    TM_GUARD(c);
+    TM_REQUIRE(c, TM_ERR_INVALID, "null ctx");
+    std::lock_guard<std::mutex> lk(c->pool.mu);
+    if (cached_bytes) *cached_bytes = c->pool.cached_bytes;
+    if (reused) *reused = c->pool.hits;
+    if (allocated) *allocated = c->pool.misses;
     return TM_OK;
 }
 

@@ -6,7 +6,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -14,6 +16,7 @@
 #include "../../include/tm_hip.h"
 #include "tm_math.h"
 
+struct tm_ctx;
 namespace tmx {
 
 void set_error(const char* fmt, ...);
@@ -42,28 +45,37 @@ void set_error(const char* fmt, ...);
         if (_rc != TM_OK) return _rc; \
     } while (0)
 
+/* Device memory of a context goes through its block cache (device_pool, tm_core.hip): a released block is kept and
+ * handed to the next request of its size class instead of a hipFree (which waits for the whole device) and a hipMalloc
+ * (~0.3 ms each; a new scene per frame made ~40 of them). Everything a context does runs on its one stream, so a block
+ * that is reused is reused in stream order: work still queued on the old contents finishes first. The cache belongs
+ * to the context a TM_GUARD names (thread-local, tmx::current_ctx()); outside any guard, or with the option
+ * `pool_mib` = 0, the calls below are plain hipMalloc / hipFree. */
+void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner);
+void device_give(void* p, size_t capacity, tm_ctx* owner);
+
 /* RAII-less device buffer (freed explicitly by the owner's destroy) */
 template <typename T>
 struct dbuf {
     T* p = nullptr;
     size_t n = 0;
+    size_t cap_bytes = 0;    /* what the block really holds (size class of the cache) */
+    tm_ctx* owner = nullptr; /* whose cache it goes back to */
     int alloc(size_t count) {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
-            return TM_ERR_HIP;
-        }
+        p = (T*)device_take(count * sizeof(T), &cap_bytes, &owner);
+        if (!p) return TM_ERR_HIP; /* error text set by device_take */
         n = count;
         return TM_OK;
     }
     int ensure(size_t count) { return (count <= n && p) ? TM_OK : alloc(count); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) device_give(p, cap_bytes, owner);
         p = nullptr;
         n = 0;
+        cap_bytes = 0;
+        owner = nullptr;
     }
 };
 
@@ -119,6 +131,15 @@ struct options {
     int ed_hist = 1;          /* 0: the wide continuation keeps bit rows in global memory (k_ed_bits_wide / k_ed_walk /
                                  k_ed_score_rows) instead of the interval reductions of k_ed_hist_wide */
     int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
+    int pool_mib = 1024;      /* released device blocks the context keeps for reuse, in MiB (0: hipFree at once) */
+};
+
+/* released device blocks of one context by capacity (see device_take) */
+struct device_pool {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;
+    size_t cached_bytes = 0;
+    uint64_t hits = 0, misses = 0;
 };
 
 /* One tm_best_reduce in flight (tm_best_reduce_begin .. _end): the winners land in pinned host memory behind an
@@ -156,6 +177,7 @@ struct tm_ctx {
     tmx::reduce_slot red[tmx::kReduceSlots]; /* tm_best_reduce_begin / _end */
     tmx::dbuf<tm_best_record> red_out;        /* the selection kernel's output (stream-ordered reuse) */
     uint32_t red_next = 0;
+    mutable tmx::device_pool pool;            /* released device blocks kept for reuse (tmx::device_take) */
 };
 
 struct tm_model {
@@ -231,7 +253,10 @@ struct tm_model {
 struct tm_scene {
     tm_ctx* ctx = nullptr;
     uint32_t n = 0;
-    std::vector<float> h_cloud;
+    /* host mirror of the cloud (12 floats per point), filled from the device copy the first time a host-side helper
+     * reads a row (tmx::scene_mirror): copying it at creation cost 6.5 ms of a 9 ms tm_scene_create per million
+     * points, and the drop-in search never reads it */
+    mutable std::vector<float> h_cloud;
     std::vector<int32_t> h_tmask, h_mask;
     /* A projected scene (tm_scene_create_projected) keeps its host mirror SPARSE: the host side of the search only
      * ever reads the surfels of tangent points (sample filters), so only those come back from the device — 1.7 MB
@@ -311,8 +336,47 @@ struct tm_scene {
 };
 
 namespace tmx {
-using ctx_guard = std::unique_lock<std::recursive_mutex>;
-inline ctx_guard guard_of(const tm_ctx* c) { return c ? ctx_guard(c->mu) : ctx_guard(); }
+/* the context the calling thread is inside (innermost TM_GUARD), or null */
+tm_ctx*& current_ctx_slot();
+inline tm_ctx* current_ctx() { return current_ctx_slot(); }
+/* holds the context's mutex and names it as the thread's current context for the scope */
+class ctx_guard {
+public:
+    ctx_guard() = default;
+    explicit ctx_guard(const tm_ctx* c) : lock_(c->mu), ctx_(const_cast<tm_ctx*>(c)), active_(true) {
+        prev_ = current_ctx_slot();
+        current_ctx_slot() = ctx_;
+    }
+    ctx_guard(ctx_guard&& o) noexcept : lock_(std::move(o.lock_)), ctx_(o.ctx_), prev_(o.prev_), active_(o.active_) {
+        o.active_ = false;
+    }
+    ctx_guard& operator=(ctx_guard&& o) noexcept {
+        if (this != &o) {
+            leave();
+            lock_ = std::move(o.lock_);
+            ctx_ = o.ctx_;
+            prev_ = o.prev_;
+            active_ = o.active_;
+            o.active_ = false;
+        }
+        return *this;
+    }
+    ctx_guard(const ctx_guard&) = delete;
+    ctx_guard& operator=(const ctx_guard&) = delete;
+    ~ctx_guard() { leave(); }
+
+private:
+    void leave() {
+        if (active_) current_ctx_slot() = prev_;
+        active_ = false;
+        if (lock_.owns_lock()) lock_.unlock();
+    }
+    std::unique_lock<std::recursive_mutex> lock_;
+    tm_ctx* ctx_ = nullptr;
+    tm_ctx* prev_ = nullptr;
+    bool active_ = false;
+};
+inline ctx_guard guard_of(const tm_ctx* c) { return c ? ctx_guard(c) : ctx_guard(); }
 inline ctx_guard guard_of(const tm_model* m) { return guard_of(m ? m->ctx : nullptr); }
 inline ctx_guard guard_of(const tm_scene* s) { return guard_of(s ? s->ctx : nullptr); }
 }  // namespace tmx
@@ -342,6 +406,8 @@ inline int scene_pinned_ensure(tm_scene* s, size_t need) {
     s->h_pinned_bytes = bytes;
     return TM_OK;
 }
+/* fills s->h_cloud from the device copy if it is still empty (dense mirrors only); TM_OK or a HIP error */
+int scene_mirror(const tm_scene* s);
 /* host mirror row of point i (12 floats), or null for a point a sparse mirror does not hold */
 const float* scene_row(const tm_scene* s, uint32_t i);
 }

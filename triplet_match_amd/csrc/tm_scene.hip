@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <chrono>
 #include <thread>
 
 namespace tmx {
@@ -1755,20 +1756,31 @@ extern "C" {
 int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
                     tm_scene** out) {
     TM_GUARD(ctx);
-    TM_REQUIRE(ctx && surfels && tangent_mask && out, TM_ERR_INVALID, "tm_scene_create: null argument");
+    TM_REQUIRE(ctx && surfels && out, TM_ERR_INVALID, "tm_scene_create: null argument");
     TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_scene_create: empty cloud");
     TM_HIP_CHECK(hipSetDevice(ctx->device));
     tm_scene* s = new tm_scene();
     s->ctx = ctx;
     s->n = n;
-    s->h_tmask.assign(tangent_mask, tangent_mask + n);
+    const bool dbg = ctx->opt.debug_times != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[scene create] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    if (tangent_mask) s->h_tmask.assign(tangent_mask, tangent_mask + n);
+    else s->h_tmask.assign(n, 0); /* null: no tangent point yet (tm_scene_auto_tangent_mask / _set_tangent_mask follow) */
     s->h_mask.assign(n, 0);
-    /* the host mirror (48 B per point: 6 ms per million) is copied on a second thread while this one stages the same
-     * bytes to the device; both only read the caller's buffer */
-    std::thread mirror([&]() { s->h_cloud.assign(surfels, surfels + (size_t)n * 12); });
+    lap("host masks");
+    /* no host mirror of the cloud here: the helpers that read rows on the host fetch it from the device copy when
+     * they are first called (tmx::scene_mirror) */
     int rc = scene_upload(s, surfels);
+    lap("upload");
     if (!rc) rc = scene_build(s, true);
-    mirror.join();
+    lap("build");
     if (rc) {
         tm_scene_destroy(s);
         return rc;
@@ -1897,6 +1909,7 @@ int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) 
         TM_HIP_CHECK(hipMemcpyAsync(surfels, s->d_cloud.p, (size_t)s->n * 48, hipMemcpyDeviceToHost, s->ctx->stream));
         TM_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));
     } else if (surfels) {
+        TM_FORWARD(scene_mirror(s));
         memcpy(surfels, s->h_cloud.data(), (size_t)s->n * 48);
     }
     if (tangent_mask) memcpy(tangent_mask, s->h_tmask.data(), (size_t)s->n * 4);
@@ -1917,6 +1930,7 @@ int tm_scene_tangent_points(const tm_scene* s, uint32_t* indices, float* surfels
         return TM_OK;
     }
     uint32_t k = 0;
+    if (surfels) TM_FORWARD(scene_mirror(s));
     for (uint32_t i = 0; i < s->n; ++i) {
         if (!s->h_tmask[i]) continue;
         if ((indices || surfels) && k < cap) {

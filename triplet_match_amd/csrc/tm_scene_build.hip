@@ -384,10 +384,9 @@ int scene_upload(tm_scene* s, const float* surfels) {
     TM_FORWARD(s->d_cloud.ensure((size_t)n * 12));
     TM_FORWARD(s->d_tmask.ensure(n));
     TM_FORWARD(s->d_mask.ensure(n));
-    /* surfels = the caller's buffer while the host mirror is still being filled on another thread (tm_scene_create),
-     * null = the mirror */
-    TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, surfels ? surfels : s->h_cloud.data(), (size_t)n * 48, hipMemcpyHostToDevice,
-                                c->stream));
+    /* surfels = the caller's buffer (tm_scene_create); null = the cloud is on the device already */
+    if (surfels)
+        TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, surfels, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, s->h_tmask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     return TM_OK;
@@ -573,8 +572,25 @@ int tmx::scene_tangent_index(tm_scene* s) {
     return TM_OK;
 }
 
+int tmx::scene_mirror(const tm_scene* s) {
+    if (s->h_sparse || s->h_cloud.size() == (size_t)s->n * 12) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->h_cloud.resize((size_t)s->n * 12);
+    hipError_t e = hipMemcpyAsync(s->h_cloud.data(), s->d_cloud.p, (size_t)s->n * 48, hipMemcpyDeviceToHost, s->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->ctx->stream);
+    if (e != hipSuccess) {
+        s->h_cloud.clear();
+        set_error("scene mirror: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
 const float* tmx::scene_row(const tm_scene* s, uint32_t i) {
-    if (!s->h_sparse) return s->h_cloud.data() + (size_t)i * 12;
+    if (!s->h_sparse) {
+        if (s->h_cloud.empty() && scene_mirror(s) != TM_OK) return nullptr;
+        return s->h_cloud.data() + (size_t)i * 12;
+    }
     auto it = std::lower_bound(s->h_tan_idx.begin(), s->h_tan_idx.end(), i);
     if (it == s->h_tan_idx.end() || *it != i) return nullptr;
     return s->h_tan_rows.data() + 12 * (size_t)(it - s->h_tan_idx.begin());
