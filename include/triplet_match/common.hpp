@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -200,6 +201,8 @@ inline void tune_allocator_once() {
 }
 inline std::shared_ptr<context_holder> default_context(int device = 0) {
     tune_allocator_once();
+    static std::mutex guard; /* models and scenes may be constructed on several threads at once */
+    std::lock_guard<std::mutex> lk(guard);
     static std::weak_ptr<context_holder> cached[16];
     auto sp = cached[device & 15].lock();
     if (!sp) {
@@ -209,6 +212,17 @@ inline std::shared_ptr<context_holder> default_context(int device = 0) {
     return sp;
 }
 }  // namespace detail
+
+/* A context of its own (one HIP stream, one set of work buffers, one lock) for callers that run several searches at
+ * once: model<Point> and scene<Point> constructed WITHOUT one share the process-wide default context of their device,
+ * whose calls serialise; objects constructed on different contexts run side by side on the GPU, as the reference's
+ * objects do on the CPU (no shared state between two scene objects, include/impl/scene.hpp:569-575). A scene is searched
+ * against a model of the SAME context. */
+typedef std::shared_ptr<detail::context_holder> context_t;
+inline context_t make_context(int device = 0) {
+    detail::tune_allocator_once();
+    return std::make_shared<detail::context_holder>(device);
+}
 
 }  // namespace triplet_match
 

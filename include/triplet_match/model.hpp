@@ -80,7 +80,10 @@ public:
     typedef std::array<uint32_t, voxel_multiplicity> voxel_data_t;
 
     model(typename cloud_t::ConstPtr cloud, discretization_params params, int device = 0)
-        : cloud_(cloud), params_(params), ctx_(detail::default_context(device)) {
+        : model(cloud, params, detail::default_context(device)) {}
+    /* on a context of the caller's (make_context): see common.hpp */
+    model(typename cloud_t::ConstPtr cloud, discretization_params params, context_t context)
+        : cloud_(cloud), params_(params), ctx_(std::move(context)) {
         static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
         if (!cloud_ || cloud_->size() == 0) throw std::runtime_error("model: empty cloud");
         detail::check(tm_model_create(ctx_->ctx, cloud_->points[0].raw(), (uint32_t)cloud_->size(),

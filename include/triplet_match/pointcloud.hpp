@@ -78,13 +78,21 @@ public:
         std::lock_guard<std::mutex> lk(mutex_);
         if (!resolution_fixed_) resolution_ = -1.f;
         diameter_ = -1.f;
-        curv_k_ = 0;
+        {
+            std::lock_guard<std::mutex> lc(curv_mutex_);
+            curv_k_ = 0;
+        }
         tm_cloud_destroy(tree_);
         tree_ = nullptr;
     }
     /* forgets the caches if they were filled for other content than `hash` (= content_hash() of now) */
     void sync(uint64_t hash) {
-        if (curv_k_ != 0 && curv_hash_ != hash) touch();
+        bool stale;
+        {
+            std::lock_guard<std::mutex> lc(curv_mutex_);
+            stale = curv_k_ != 0 && curv_hash_ != hash;
+        }
+        if (stale) touch();
     }
     /* 64-bit hash of the raw surfel bytes (four interleaved multiply-xorshift lanes; ~5 ms per million points):
      * scene<Point> keys its device copy on it, so an in-place edit of the points is never searched stale */
@@ -155,6 +163,7 @@ public:
      * normals (tm_cloud_curvature, GPU); all points are computed on first use and cached per k. A partial cache
      * (store_curvature / prepare_curvature: the rows of the points a mask loop reads) answers for its points. */
     curvature_info_t curvature(uint32_t k, uint32_t idx) const {
+        std::lock_guard<std::mutex> lc(curv_mutex_); /* scenes on several threads may share one cloud object */
         const float* row = nullptr;
         if (curv_k_ == k && curv_sparse_) {
             auto it = std::lower_bound(curv_idx_.begin(), curv_idx_.end(), idx);
@@ -187,6 +196,7 @@ public:
      * all of them (:68-71, :48-49). A later curvature(k, idx) of another point recomputes the whole cloud.
      * `indices` ascending. */
     bool has_curvature(uint32_t k, const std::vector<uint32_t>& indices) const {
+        std::lock_guard<std::mutex> lc(curv_mutex_);
         if (curv_k_ != k) return false;
         if (!curv_sparse_) return curv_.size() == 5 * points.size();
         size_t at = 0; /* both lists ascend: one pass */
@@ -200,6 +210,7 @@ public:
      * scene's device copy of it); kept as (ascending index, row) pairs — a dense array cost 20 MB of stores per million
      * points for 40k rows. `hash` = content_hash() of the content they belong to. */
     void store_curvature(uint32_t k, std::vector<uint32_t> indices, std::vector<float> rows, uint64_t hash) const {
+        std::lock_guard<std::mutex> lc(curv_mutex_);
         curv_idx_ = std::move(indices);
         curv_rows_ = std::move(rows);
         curv_sparse_ = true;
@@ -352,6 +363,7 @@ private:
     mutable std::vector<uint32_t> curv_idx_;  /* ... or the rows of these points only, ascending (partial cache) */
     mutable std::vector<float> curv_rows_;
     mutable bool curv_sparse_ = false;
+    mutable std::mutex curv_mutex_;           /* guards the curvature cache (mutex_ guards the tree and the scalars) */
     mutable uint32_t curv_k_ = 0;
     mutable uint64_t curv_hash_ = 0;
 };

@@ -429,8 +429,9 @@ public:
         double rejection_rate;
     };
 
-    explicit scene(typename cloud_t::Ptr cloud, int device = 0)
-        : cloud_(cloud), ctx_(detail::default_context(device)) {
+    explicit scene(typename cloud_t::Ptr cloud, int device = 0) : scene(cloud, detail::default_context(device)) {}
+    /* on a context of the caller's (make_context; the model it is searched against lives on the same one) */
+    scene(typename cloud_t::Ptr cloud, context_t context) : cloud_(cloud), ctx_(std::move(context)) {
         static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
         if (!cloud_ || cloud_->size() == 0) throw std::runtime_error("scene: empty cloud");
     }

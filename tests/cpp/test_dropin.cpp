@@ -260,6 +260,45 @@ int main(int argc, char** argv) {
         CHECK((size_t)(r0.second - r0.first) == first.size(), "pair_iter_t: random-access distance");
     }
 
+    /* contexts of the caller's (make_context): three threads, each with its own context, model and scene objects over
+     * the same clouds, search at once — the same matches as the search above on the default context, every time; and a
+     * scene of one context against a model of another is refused */
+    {
+        const int T = 3, reps = 4;
+        std::vector<context_t> ctxs;
+        std::vector<std::unique_ptr<model<P>>> models;
+        for (int t = 0; t < T; ++t) {
+            ctxs.push_back(make_context(0));
+            models.emplace_back(new model<P>(mcloud, dp, ctxs.back()));
+            models.back()->init(sp);
+        }
+        std::vector<int> bad(T, 0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                for (int r = 0; r < reps; ++r) {
+                    scene<P> mine(scloud, ctxs[t]); /* a new scene object per repetition: the whole preparation runs */
+                    mine.set_workers(4);
+                    auto got = mine.find_all_parallel(*models[t], 3.0f, 0.5f, 0.9f, sp, 2);
+                    bool same = got.size() == matches.size();
+                    for (size_t k = 0; k < got.size() && same; ++k)
+                        same = got[k].scene_corrs == matches[k].scene_corrs && got[k].model_corrs == matches[k].model_corrs &&
+                               std::memcmp(got[k].transform.m, matches[k].transform.m, 64) == 0;
+                    if (!same) ++bad[t];
+                }
+            });
+        for (auto& x : th) x.join();
+        CHECK(bad[0] + bad[1] + bad[2] == 0, "three contexts searching at once: every search equals the single-context one");
+        bool refused = false;
+        try {
+            scene<P> other(scloud, ctxs[1]);
+            other.find_all_parallel(*models[0], 3.0f, 0.5f, 0.9f, sp, 2);
+        } catch (const std::exception&) {
+            refused = true;
+        }
+        CHECK(refused, "a scene of one context against a model of another is refused");
+    }
+
     /* an in-place edit of the scene cloud between two searches is seen (the reference re-reads cloud_ per call):
      * shift every point; the matches must move with them */
     if (!matches.empty()) {

@@ -1,10 +1,13 @@
 /* e2e_demo.cpp — times the drop-in scene<Point>::find_all_parallel on a fixture written by
  * tests/test_cpp_dropin.py::_fixture (model, scene, resolution, ground-truth poses).
  * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] [repeats of the search on the kept scene]
- *        [new scene objects over the same cloud] [new clouds] */
+ *        [new scene objects over the same cloud] [new clouds] [stream: up to this many host threads] */
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <memory>
+#include <thread>
 #include <unistd.h>
 
 #include "triplet_match/scene.hpp"
@@ -102,6 +105,47 @@ int main(int argc, char** argv) {
             auto t6 = std::chrono::steady_clock::now();
             printf("new cloud %d: %.4f s -> %zu matches (search itself %.2f ms)\n", f, std::chrono::duration<double>(t6 - t5).count(),
                    got.size(), 1e3 * fresh.last_stats().total);
+        }
+    }
+    if (argc > 7) { /* a stream of new clouds worked off by T host threads, each with a context and a model of its own
+                     * (make_context): the threads' kernels run side by side on the GPU and nothing is shared but the
+                     * headers' worker pool — frames per second for T = 1 .. argv[7]. (Threads on the one default context
+                     * serialise on its lock: 54 -> 61 frames/s with two.) */
+        const int max_threads = atoi(argv[7]);
+        const int frames = 32;
+        std::vector<pointcloud<P>::Ptr> clouds;
+        for (int f = 0; f < frames; ++f) {
+            auto c = pointcloud<P>::empty();
+            c->points = scloud->points;
+            c->points[(size_t)(f + 100) * 7919u % c->points.size()].y += 1e-4f;
+            clouds.push_back(c);
+        }
+        std::vector<context_t> ctxs;
+        std::vector<std::unique_ptr<model<P>>> models;
+        for (int t = 0; t < max_threads; ++t) {
+            ctxs.push_back(make_context(0));
+            models.emplace_back(new model<P>(mcloud, dp, ctxs.back()));
+            models.back()->init(sp);
+        }
+        for (int T = 1; T <= max_threads; ++T) {
+            std::atomic<int> next{0}, found{0};
+            auto t7 = std::chrono::steady_clock::now();
+            std::vector<std::thread> pool;
+            for (int t = 0; t < T; ++t)
+                pool.emplace_back([&, t]() {
+                    for (;;) {
+                        const int f = next.fetch_add(1);
+                        if (f >= frames) break;
+                        scene<P> fresh(clouds[f], ctxs[t]);
+                        fresh.set_early_drop(early_drop);
+                        found.fetch_add((int)fresh.find_all_parallel(*models[t], 3.0f, 0.5f, 0.9f, sp, icp).size());
+                    }
+                });
+            for (auto& th : pool) th.join();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t7).count();
+            printf("stream: %d frames on %d thread%s, a context each: %.1f frames/s (%.2f ms per frame), %d matches\n", frames, T,
+                   T > 1 ? "s" : "", frames / dt, 1e3 * dt / frames, found.load());
+            for (auto& c : clouds) c->touch(); /* the next round starts from clouds without cached curvature */
         }
     }
     for (const auto& mt : matches) {

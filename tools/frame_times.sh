@@ -10,4 +10,4 @@ from test_cpp_dropin import _fixture
 _fixture("/tmp/c2.bin", model_n=100000, scene_n=1000000, copies=4)
 PY
 g++ -std=c++17 -O2 -Iinclude tools/e2e_demo.cpp -o /tmp/e2e_demo -Ltriplet_match_amd -ltm_hip -Wl,-rpath,$PWD/triplet_match_amd -pthread || exit 1
-TM_FRAME_VERBOSE=1 /tmp/e2e_demo /tmp/c2.bin 1 10 3 4 4 2>&1 | grep -v "^\[search\]"
+TM_FRAME_VERBOSE=1 /tmp/e2e_demo /tmp/c2.bin 1 10 3 4 4 ${STREAM_THREADS:-3} 2>&1 | grep -v "^\[search\]"
