@@ -52,7 +52,7 @@ def main():
                          "over gloo (RCCL refuses two ranks on one device); not a measurement")
     ap.add_argument("--ed-profile", action="store_true",
                     help="profiling aid: after the setup run only the device-resident early-drop scoring of the batch "
-                         "(three calls) and print its figure; tools/profile_r03.sh counts its fabric bytes")
+                         "(three calls) and print its figure; tools/profile_round4.sh counts its fabric bytes")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="plumbing check without a GPU: the ranks come up over gloo, exchange one synthetic best "
                          "record each and rank 0 prints a line with \"selftest\": true and no value (tests/)")
@@ -305,7 +305,7 @@ def main():
     copy_gbs = measured_copy_bandwidth(torch, local_rank) if rank == 0 else None
     # ONE basis for roofline.frac, on every line of every round from here on: the bytes the L2s request from the
     # fabric for this kernel (TCC_EA0_RDREQ by size + write requests, separate rocprofv3 --pmc passes of this same
-    # command: profiles/r03/traffic.json, quoted only while the kernel sources still hash to what was profiled)
+    # command: profiles/rNN/traffic.json, quoted only while the kernel sources still hash to what was profiled)
     # / this run's kernel time / the 8 TB/s HBM peak. Infinity-Cache hits are inside those counters, so this is
     # "Infinity Cache + HBM": an UPPER bound of the HBM traffic. The formula and the requested-bytes
     # model stay as side fields; neither is ever promoted to `frac`.
@@ -456,28 +456,48 @@ def measured_copy_bandwidth(torch, local_rank):
         return None
 
 
+def _profile_rounds():
+    """profiles/rNN directories, newest first"""
+    try:
+        names = [d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()]
+    except OSError:
+        return []
+    return sorted(names, key=lambda d: -int(d[1:]))
+
+
 def source_hash():
     """SHA-256 over the sources of the scoring kernel: a PMC file is only quoted for the build it profiled."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tm_scene.hip", "tm_score.h", "tm_math.h", "tm_table.h"):
-        h.update(open(os.path.join(ROOT, "triplet_match_amd", "csrc", f), "rb").read())
+    csrc = os.path.join(ROOT, "triplet_match_amd", "csrc")
+    text = open(os.path.join(csrc, "tm_scene.hip"), "rb").read()
+    # the kernels' part of tm_scene.hip (markers in the file); the entry points and host helpers around them can
+    # change without new PMC passes
+    a, b = text.find(b"/* >>> scoring kernels"), text.find(b"/* <<< scoring kernels")
+    h.update(text[a:b] if 0 <= a < b else text)
+    for f in ("tm_score.h", "tm_math.h", "tm_table.h"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
 def measured_traffic(args):
-    """HBM bytes per scoring launch from the committed PMC passes (profiles/r03/traffic.json, written by
+    """HBM bytes per scoring launch from the committed PMC passes (profiles/rNN/traffic.json, written by
     tools/make_traffic_json.py from separate rocprofv3 --pmc runs of this same command). Null when the
     workload differs from the profiled one or the kernel sources changed since."""
-    path = os.path.join(ROOT, "profiles", "r03", "traffic.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
+    t = None
+    for rnd in _profile_rounds():  # the newest round whose PMC passes were taken on these kernel sources
+        try:
+            cand = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+        except (OSError, ValueError):
+            continue
+        if cand.get("source_hash") == source_hash():
+            t = cand
+            t["file"] = "profiles/%s/traffic.json" % rnd
+            break
+    if t is None:
+        log("no profiles/r*/traffic.json was taken on these kernel sources: roofline.traffic = null")
         return None
     w = t.get("workload", {})
-    if t.get("source_hash") != source_hash():
-        log("profiles/r03/traffic.json was taken on other kernel sources: roofline.traffic = null")
-        return None
     if (w.get("model_points") == args.model_points and w.get("scene_points") == args.scene_points
             and w.get("hyp_per_batch") == args.hyp_per_batch and w.get("mode") == args.mode):
         return t
@@ -531,7 +551,9 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tools", "e2e_demo.cpp"), "-o", exe, "-L" + libdir, "-ltm_hip",
                                "-Wl,-rpath," + libdir, "-pthread"])
-        r = subprocess.run([exe, fx, "1", "10"], capture_output=True, text=True, timeout=300)
+        # early drop on, 10 ICP iterations, the search repeated once on the kept scene, two frames with a new cloud, then
+        # a stream of new clouds on 1..4 host threads with a context each
+        r = subprocess.run([exe, fx, "1", "10", "1", "0", "2", "4"], capture_output=True, text=True, timeout=300)
         os.unlink(fx)
         os.unlink(exe)
         import re
@@ -542,8 +564,15 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                 "model_init_s": float(m1.group(1)), "find_all_parallel_s": float(m1.group(2)),
                 "matches": int(m1.group(3)), "planted": int(len(scene["poses_scene_to_model"])),
                 "second_call_s": float(m2.group(1)) if m2 else None,
+                "new_cloud_frame_s": (lambda v: min(v) if v else None)(
+                    [float(x) for x in re.findall(r"new cloud \d+: ([0-9.]+) s", r.stdout)]),
+                "stream_frames_per_s": {int(t): float(f) for t, f in
+                                        re.findall(r"stream: \d+ frames on (\d+) threads?, a context each: ([0-9.]+) frames/s",
+                                                   r.stdout)} or None,
                 "note": "drop-in scene<Point>::find_all_parallel, early drop on, 10 ICP iterations, curvature masks on; "
-                        "second call = the same search again with the prepared scene kept on the device"}
+                        "second call = the same search again with the prepared scene kept on the device; new_cloud_frame_s = "
+                        "new cloud + new scene object + search (upload, curve order, tangent_mask_ on the device); "
+                        "stream_frames_per_s = such frames worked off by 1..4 host threads with a context (stream) each"}
         else:
             log("extras: e2e demo output not understood:\n" + r.stdout[-800:] + r.stderr[-800:])
     except Exception as exc:
@@ -565,7 +594,7 @@ def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres
     tm_score_hypotheses_early_drop_ball_dev: poses in, results out on the device; only the centre indices (4 B per
     hypothesis) go up. Time = HIP events on the library's stream around the call (its two internal read-backs of a
     few words included). Bytes: L2->fabric requests of all its kernels from the committed PMC pass
-    (profiles/r03/early_drop_traffic.json, guarded by a hash of the kernel sources)."""
+    (profiles/rNN/early_drop_traffic.json, guarded by a hash of the kernel sources)."""
     prov = np.zeros((n_hyp, 4), np.uint32)
     ctx.d2h(prov, d_prov)
     centers = np.ascontiguousarray(pairs[prov[:, 0], 0], dtype=np.uint32)
@@ -592,7 +621,15 @@ def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres
         c2, _, d2, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, gm.diameter, dist_thres, accept_prob)
         out["equals_host_buffer_call"] = bool(np.array_equal(c2, cnt) and np.array_equal(d2, dropped))
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03", "early_drop_traffic.json")))
+        t = {}
+        for rnd in _profile_rounds():
+            try:
+                cand = json.load(open(os.path.join(ROOT, "profiles", rnd, "early_drop_traffic.json")))
+            except (OSError, ValueError):
+                continue
+            if cand.get("source_hash") == ed_source_hash():
+                t = cand
+                break
         if t.get("source_hash") == ed_source_hash() and t.get("hypotheses") == int(n_hyp):
             gbs = t["fabric_bytes_per_call"] / (best * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "traffic": t["fabric_bytes_per_call"], "achieved": round(gbs, 1),
@@ -600,7 +637,7 @@ def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres
                                "frac_basis": "measured_l2_fabric_bytes: Infinity Cache + HBM, upper bound of HBM",
                                "infinity_cache_frac": round(gbs / INFINITY_CACHE_RANDOM_GBS, 4),
                                "kernel_busy_ms_under_profiler": t.get("kernel_busy_ms_per_call"),
-                               "note": "bytes by kernel in profiles/r03/early_drop_traffic.json: the continuation "
+                               "note": "bytes by kernel in profiles/rNN/early_drop_traffic.json: the continuation "
                                        "(k_ed_hist_list) streams the neighbourhood of every pending hypothesis once (scene "
                                        "entries, voxel lines, model points and refs of ~100k positions per hypothesis), the "
                                        "first step (k_ed_prefix_group) the voxel side of the first 5 % of every hypothesis"}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the PMC passes of tools/pmc_rdreq.sh into profiles/r03/traffic.json (what bench.py quotes as
+"""Turns the PMC passes of tools/pmc_rdreq.sh into profiles/rNN/traffic.json (what bench.py quotes as
 roofline.traffic).  usage: tools/make_traffic_json.py <pmc outdir> [kernel substring] [out path] [folded outdir]
 <folded outdir> = the pass-1 counters of the same command on the timing-experiments build with TM_ABLATE=7 (voxel
 index folded into 1 MB): the difference of the line counts = the lines the voxel gathers fetch.

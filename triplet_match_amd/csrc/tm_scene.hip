@@ -84,6 +84,9 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
  * per wave iteration with predicated (branch-free) gathers so that four independent
  * voxel -> model-point gather chains are in flight per lane. No atomics: one store per hypothesis.
  * ---------------------------------------------------------------------------------------------- */
+/* >>> scoring kernels: bench.py ties the committed PMC passes (profiles/rNN/traffic.json) to a hash of the text between
+ * this marker and its closing twin, plus tm_score.h / tm_math.h / tm_table.h — a change in here needs new passes
+ * (tools/profile_round4.sh), a change elsewhere in this file does not */
 constexpr int kCullChunk = 1024; /* tiles culled per round; each may leave up to 4 sub-tiles in the 16 KiB list */
 
 struct cull_args {
@@ -952,6 +955,8 @@ static items_kernel_t items_kernel(bool l2, uint32_t group_hyps, bool ball, bool
     }
     return l2 ? k_score_items<true, 4, 32, false, true, false, STATS> : k_score_items<false, 4, 32, false, false, false, STATS>;
 }
+
+/* <<< scoring kernels */
 
 /* sums the per-workgroup stat slots of one scoring launch into that launch's row of device counters
  * (one workgroup, plain stores: nothing for the host to wait for inside a timed loop) */
