@@ -203,3 +203,48 @@ def test_planted_poses_and_best_of_batch(gpu_ctx, full):
         b = p @ Tk[:3, :3].T + Tk[:3, 3]
         errs.append(np.sqrt(((a - b) ** 2).sum(1)).mean())
     assert min(errs) < 2 * DT * full["res"], errs
+
+
+def test_sixteen_million_point_scene(gpu_ctx, full):
+    """A scene sixteen times the configs[1] size (16M points, 768 MB of surfels: sixteen copies of every point in
+    shuffled order) through the size-independent property that copies offer: every count is exactly sixteen times
+    the 1M-point scene's, every fixed-point score sum too (so the normalised scores agree to the last bit), for the
+    grouped kernel and the exhaustive one, the ball-restricted pass and the early-drop rule with nothing dropped;
+    correspondences of the best pose come back sixteen-fold."""
+    S, tmk = full["scene"]["surfels"], full["scene"]["tangent_mask"]
+    K = 16
+    perm = np.random.default_rng(3).permutation(K * N_SCENE)
+    src = (perm % N_SCENE).astype(np.int64)  # big[q] is a copy of point src[q]
+    big = np.ascontiguousarray(S[src])
+    gs16 = capi.Scene(gpu_ctx, big, np.ascontiguousarray(tmk[src]))
+    del big
+    gm = full["gm"]
+    order = np.argsort(-full["counts"].astype(np.int64), kind="stable")
+    sel = np.unique(np.r_[order[:24], np.random.default_rng(4).integers(0, H, 2024)])
+    poses = full["poses"][sel]
+    c16, s16 = gs16.score_hypotheses(gm, poses, DT, mode=capi.SCORE_CULLED)
+    assert np.array_equal(c16, K * full["counts"][sel]) and c16.max() > K * 90_000
+    assert np.array_equal(s16, K * full["scores"][sel])  # sums of 2^-40 fixed-point terms: exact multiples
+    cb, sb = gs16.score_hypotheses(gm, poses[:160], DT, mode=capi.SCORE_BRUTEFORCE)
+    assert np.array_equal(cb, c16[:160]) and np.array_equal(sb, s16[:160])
+    # ball-restricted pass and the early-drop rule (accept_prob 0: nothing drops) around a first point of the big scene:
+    # centre q of the big scene is a copy of point src[q] of the 1M scene
+    prov = full["prov"][sel]
+    first_small = full["pairs"][prov[:, 0], 0].astype(np.int64)
+    where = np.full(N_SCENE, -1, np.int64)
+    where[src[::-1]] = np.arange(K * N_SCENE - 1, -1, -1)  # the first copy of every point
+    centers16 = where[first_small].astype(np.uint32)
+    few = slice(0, 512)
+    cs, ss = full["gs"].score_hypotheses_ball(gm, poses[few], first_small[few].astype(np.uint32), gm.diameter, DT)
+    cbig, sbig = gs16.score_hypotheses_ball(gm, poses[few], centers16[few], gm.diameter, DT)
+    assert np.array_equal(cbig, K * cs) and np.array_equal(sbig, K * ss) and cbig.max() > K * 50_000
+    ce, se, de, _ = gs16.score_hypotheses_early_drop_ball(gm, poses[few], centers16[few], gm.diameter, DT, 0.0)
+    assert (de < 0).all() and np.array_equal(ce, cbig) and np.array_equal(se, sbig)
+    # finish_find for the best pose: sixteen copies of every correspondence, each with its point's model partner
+    sc1, mc1, _ = full["gs"].extract_correspondences(gm, full["poses"][order[0]], DT)
+    sc16, mc16, _ = gs16.extract_correspondences(gm, full["poses"][order[0]], DT)
+    assert len(sc16) == K * len(sc1) and (np.diff(sc16.astype(np.int64)) > 0).all()
+    partner = np.full(N_SCENE, -1, np.int64)
+    partner[sc1] = mc1
+    assert np.array_equal(partner[src[sc16]], mc16.astype(np.int64))
+    gs16.close()
