@@ -9,6 +9,10 @@
 #ifndef TRIPLET_MATCH_TRAITS_HPP_
 #define TRIPLET_MATCH_TRAITS_HPP_
 
+#include <limits>
+#include <random>
+#include <stdexcept>
+#include <cmath>
 #include <tuple>
 #include <utility>
 
@@ -220,16 +224,85 @@ struct plane2_traits : detail::traits_impl<Point, TM_TRAITS_PLANE2, 3> {
     }
 };
 
-/* include/cylinder_traits. init_from_model in the reference is a PCL MSAC cylinder fit
- * (impl/cylinder_traits.hpp:10-26): third-party and out of scope, so the model
- * projector is built from known axis parameters instead. */
+/* include/cylinder_traits. init_from_model in the reference hands the model cloud to PCL's MSAC cylinder fit
+ * (pcl::MEstimatorSampleConsensus over pcl::SampleConsensusModelCylinder, impl/cylinder_traits.hpp:10-26: threshold
+ * 5 x resolution, probability 0.99, no refinement) and builds the frame from the winning coefficients (:28-39). PCL
+ * is not in the reference tree, so its published algorithm is restated here: candidate = the cylinder through two
+ * sampled points with their normals (the closest approach of the two normal lines — the same construction
+ * init_from_samples uses, :53-97, which the reference took from PCL's computeModelCoefficients); distance of a point
+ * = | distance to the axis - radius | (normal weight 0, PCL's default); penalty = sum of min(distance, threshold);
+ * the candidate with the lowest penalty wins; after every improvement the iteration bound becomes
+ * log(1 - 0.99) / log(1 - w^2) with w = its inlier fraction (at most 10,000, MSAC's max_iterations_). What cannot be
+ * restated is PCL's sample sequence (boost RNG, unpinned version): samples are drawn with mt19937 seed 13, like every
+ * other draw of this library — the cylinder found is one PCL could have found, not necessarily the one it would. */
 template <typename Point>
 struct cylinder_traits : detail::traits_impl<Point, TM_TRAITS_CYLINDER, 2> {
     typedef detail::traits_impl<Point, TM_TRAITS_CYLINDER, 2> base;
-    static typename base::handle_t init_from_model(typename base::cloud_t::ConstPtr, const subset_t& = subset_t()) {
-        throw std::logic_error(
-            "cylinder_traits::init_from_model needs PCL's MSAC cylinder fit, which is outside this "
-            "library; use init_from_axis(origin, axis, radius, threshold)");
+    static typename base::handle_t init_from_model(typename base::cloud_t::ConstPtr cloud,
+                                                   const subset_t& subset = subset_t(), uint32_t seed = 13) {
+        if (!cloud || cloud->size() < 2) throw std::runtime_error("cylinder_traits::init_from_model: fewer than two points");
+        std::vector<uint32_t> indices(subset.begin(), subset.end());
+        if (indices.empty()) { /* :13-16 */
+            indices.resize(cloud->size());
+            for (uint32_t i = 0; i < (uint32_t)indices.size(); ++i) indices[i] = i;
+        }
+        const float threshold = 5.f * cloud->resolution(); /* :19 */
+        const size_t n = indices.size();
+        if (n < 2) throw std::runtime_error("cylinder_traits::init_from_model: fewer than two points in the subset");
+        float ms[TM_STATE_FLOATS] = {0};
+        ms[1] = threshold;
+        std::mt19937 rng(seed);
+        double best_penalty = std::numeric_limits<double>::max();
+        float best[TM_STATE_FLOATS] = {0};
+        bool have = false;
+        double k = 1.0;
+        const uint32_t max_iterations = 10000;
+        uint32_t iterations = 0, skipped = 0;
+        while ((double)iterations < k && iterations < max_iterations && skipped < 10u * max_iterations) {
+            const uint32_t a = indices[rng() % n], b = indices[rng() % n];
+            if (a == b) { /* PCL's isSampleGood: two distinct points */
+                ++skipped;
+                continue;
+            }
+            float flat[24], st[TM_STATE_FLOATS] = {0};
+            memcpy(flat, cloud->points[a].raw(), 48);
+            memcpy(flat + 12, cloud->points[b].raw(), 48);
+            if (tm_traits_init_from_samples(TM_TRAITS_CYLINDER, ms, flat, st) || !(st[0] > 0.f) || !std::isfinite(st[0])) {
+                ++skipped; /* degenerate sample (parallel normals through one line, non-finite point) */
+                continue;
+            }
+            /* axis = third row of g2l (column-major 4x4 at st + 5), a point on it = origin */
+            const vec3f_t o(st[2], st[3], st[4]), ax(st[5 + 2], st[5 + 6], st[5 + 10]);
+            double penalty = 0.0;
+            size_t inliers = 0;
+            for (uint32_t i : indices) {
+                const Point& p = cloud->points[i];
+                const vec3f_t d(p.x - o[0], p.y - o[1], p.z - o[2]);
+                const float dist = std::fabs(ax.cross(d).norm() - st[0]);
+                if (dist < threshold) { /* NaN fails: counted at the threshold like any outlier */
+                    penalty += (double)dist;
+                    ++inliers;
+                } else {
+                    penalty += (double)threshold;
+                }
+            }
+            if (penalty < best_penalty) {
+                best_penalty = penalty;
+                memcpy(best, st, sizeof best);
+                have = true;
+                /* the iteration bound from the inlier fraction (sample size 2), clamped as PCL clamps it */
+                const double w = (double)inliers / (double)n;
+                double p_no_outliers = 1.0 - w * w;
+                p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
+                p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+                k = std::log(1.0 - 0.99) / std::log(p_no_outliers);
+            }
+            ++iterations;
+        }
+        if (!have) throw std::runtime_error("cylinder_traits::init_from_model: no cylinder through any sampled pair");
+        /* :28-39: frame from the axis via unitOrthogonal, as init_from_axis builds it */
+        return init_from_axis(vec3f_t(best[2], best[3], best[4]), vec3f_t(best[5 + 2], best[5 + 6], best[5 + 10]), best[0],
+                              threshold);
     }
     /* threshold = 5 * resolution in the reference (:19) */
     static typename base::handle_t init_from_axis(const vec3f_t& origin, const vec3f_t& axis_dir, float radius,

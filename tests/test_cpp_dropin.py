@@ -75,6 +75,66 @@ def test_worker_pool():
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
 
 
+def test_cylinder_init_from_model_fits_the_cylinder(tmp_path):
+    """cylinder_traits::init_from_model = PCL's MSAC cylinder fit restated (reference include/impl/cylinder_traits.hpp:
+    5-50; PCL itself is not in the reference tree): on a noisy cylinder with 15 % outliers and wrong normals among the
+    inliers, the fitted axis, radius and origin are the planted ones — judged here with numpy, not with the library's
+    own distance function — for several seeds, for a subset, and the frame round-trips."""
+    exe = _compile("test_cylinder_fit")
+    rng = np.random.default_rng(11)
+    n, r, res = 6000, 0.35, 0.01
+    axis = np.array([0.2, 0.5, 0.84])
+    axis /= np.linalg.norm(axis)
+    c0 = np.array([1.0, 2.0, 3.0])
+    e1 = np.cross(axis, [1.0, 0.0, 0.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(axis, e1)
+    ang, h = rng.uniform(0, 2 * np.pi, n), rng.uniform(-1.0, 1.0, n)
+    radial = np.cos(ang)[:, None] * e1 + np.sin(ang)[:, None] * e2
+    pts = c0 + h[:, None] * axis + (r + rng.normal(0, 0.002, n))[:, None] * radial
+    nrm = radial + rng.normal(0, 0.02, (n, 3))
+    n_out = int(0.15 * n)
+    pts[:n_out] = c0 + rng.uniform(-1.2, 1.2, (n_out, 3))
+    nrm[:n_out] = rng.normal(size=(n_out, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    S = np.zeros((n, 12), np.float32)
+    S[:, 0:3], S[:, 3], S[:, 4:7] = pts, 1.0, nrm
+    perm = rng.permutation(n)
+    S = S[perm]
+    inlier = perm >= n_out
+    for seed, subset in ((13, None), (1, None), (99, None), (13, np.nonzero(inlier)[0][::2].astype(np.uint32))):
+        fin, fout = str(tmp_path / "cyl.bin"), str(tmp_path / "state.bin")
+        with open(fin, "wb") as f:
+            f.write(np.uint32(n).tobytes())
+            f.write(S.tobytes())
+            f.write(np.float32(res).tobytes())
+            f.write(np.uint32(0 if subset is None else len(subset)).tobytes())
+            if subset is not None:
+                f.write(subset.tobytes())
+        rr = subprocess.run([exe, fin, fout, str(seed)], capture_output=True, text=True, timeout=120)
+        assert rr.returncode == 0, rr.stdout + rr.stderr
+        st = np.fromfile(fout, np.float32).astype(np.float64)
+        radius, threshold, origin, ax = st[0], st[1], st[2:5], st[5:8]
+        assert abs(threshold - 5 * res) < 1e-7  # :19
+        assert abs(np.linalg.norm(ax) - 1) < 1e-5
+        assert abs(abs(ax @ axis) - 1) < 2e-4, (seed, ax)                      # direction within ~1 degree
+        assert abs(radius - r) < 0.5 * threshold, (seed, radius)   # the stop rule ends after a handful of draws at 85 % inliers
+        d0 = origin - c0
+        assert np.linalg.norm(d0 - (d0 @ axis) * axis) < 0.5 * threshold, seed  # the origin lies on the planted axis
+        # (a two-point model, not a least-squares one: MSAC picks the best SAMPLED cylinder, :21-24 has no refinement)
+        q = S[inlier, 0:3].astype(np.float64) - origin
+        dist = np.abs(np.linalg.norm(np.cross(q, ax), axis=1) - radius)
+        assert (dist < threshold).mean() > 0.995, seed                          # the planted surface is inside the band
+    # two points cannot be drawn from a cloud of one
+    with open(fin, "wb") as f:
+        f.write(np.uint32(1).tobytes())
+        f.write(S[:1].tobytes())
+        f.write(np.float32(res).tobytes())
+        f.write(np.uint32(0).tobytes())
+    rr = subprocess.run([exe, fin, fout, "13"], capture_output=True, text=True, timeout=60)
+    assert rr.returncode == 4 and "fewer than two points" in rr.stdout
+
+
 def test_host_orchestration_over_oracle_backend(tmp_path):
     exe = _compile("test_search", _oracle_link())
     fx = _fixture(str(tmp_path / "case.bin"))

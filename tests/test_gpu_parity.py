@@ -1177,6 +1177,20 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
         with gpu_ctx.option("item_sort", shift):
             cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
         assert np.array_equal(cg, cb) and np.array_equal(sg, sb), shift
+    # the other instantiations and hand-out forms of the item kernel: 64-bit addresses for its gathers (what a voxel table
+    # beyond 4 GiB takes), a fixed item share per wave, no continuation in other XCDs' items, short runs per XCD, a small
+    # persistent grid — same integers every way
+    for opts in ({"score_off32": 0}, {"item_static": 1}, {"item_nosteal": 1}, {"item_run": 0}, {"item_run": 3, "item_sort": 4},
+                 {"score_item_wgs": 8}, {"score_off32": 0, "group_hyps": 32}):
+        old = {k: gpu_ctx.get_option(k) for k in opts}
+        for k, v in opts.items():
+            gpu_ctx.set_option(k, v)
+        try:
+            cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
+        finally:
+            for k, v in old.items():
+                gpu_ctx.set_option(k, v)
+        assert np.array_equal(cg, cb) and np.array_equal(sg, sb), opts
     # the per-hypothesis kernel of round 1 (still used for subset scoring) agrees as well
     with gpu_ctx.option("score_grouped", 0):
         cg, sg = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_CULLED)
