@@ -85,6 +85,7 @@ public:
     model(typename cloud_t::ConstPtr cloud, discretization_params params, context_t context)
         : cloud_(cloud), params_(params), ctx_(std::move(context)) {
         static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
+        if (!ctx_) throw std::invalid_argument("model: null context");
         if (!cloud_ || cloud_->size() == 0) throw std::runtime_error("model: empty cloud");
         detail::check(tm_model_create(ctx_->ctx, cloud_->points[0].raw(), (uint32_t)cloud_->size(),
                                       cloud_->resolution(), params_.distance_step_count, params_.angle_step,

@@ -433,6 +433,7 @@ public:
     /* on a context of the caller's (make_context; the model it is searched against lives on the same one) */
     scene(typename cloud_t::Ptr cloud, context_t context) : cloud_(cloud), ctx_(std::move(context)) {
         static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
+        if (!ctx_) throw std::invalid_argument("scene: null context");
         if (!cloud_ || cloud_->size() == 0) throw std::runtime_error("scene: empty cloud");
     }
     virtual ~scene() { tm_scene_destroy(h_); }

@@ -346,3 +346,145 @@ def test_early_drop_bound_against_the_literal_expression_on_a_grid():
         tried = int(rng.integers(1, S + 1))
         corrs = int(rng.integers(0, tried + 1))
         assert capi.early_drop_upper(tried, S, corrs) == tmo.early_drop_upper_literal(tried, S, corrs), (tried, S, corrs)
+
+
+def _project_numpy(model, resolution, voxels, extents, to_voxel, scene, tangent_mask, mask, pose16, dist_thres):
+    """project_ of the reference (include/impl/scene.hpp:411-510, full pass) written a second time, in numpy, line by
+    line from the reference text — not from the oracle's C++: float32 element-wise arithmetic in the association of
+    SURVEY Q1 (a 4x4 times (x, y, z, 1) row = ((m0 x + m4 y) + m8 z) + m12), the voxel look-up of impl/model.hpp:180-192
+    (int cast = truncation toward zero), the fp64 score sum. Returns (scene_corrs, model_corrs, score)."""
+    f32 = np.float32
+    T = np.asarray(pose16, f32).reshape(4, 4).T  # column-major storage -> T[row, col]
+    P = scene[:, 0:3].astype(f32)
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+
+    def row(r):  # :439-440: pos = T * p
+        return ((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]
+    px, py, pz = row(0), row(1), row(2)
+    V = np.asarray(to_voxel, f32).reshape(4, 4).T  # impl/model.hpp:181: to_voxel * pos (a scale and a translation)
+    with np.errstate(invalid="ignore", over="ignore"):
+        vx, vy, vz = V[0, 0] * px + V[0, 3], V[1, 1] * py + V[1, 3], V[2, 2] * pz + V[2, 3]
+        fin = np.isfinite(vx) & np.isfinite(vy) & np.isfinite(vz)
+        i = np.where(fin, np.trunc(np.where(fin, vx, 0)), -1).astype(np.int64)  # :182: cast<int>
+        j = np.where(fin, np.trunc(np.where(fin, vy, 0)), -1).astype(np.int64)
+        k = np.where(fin, np.trunc(np.where(fin, vz, 0)), -1).astype(np.int64)
+    ex, ey, ez = (int(e) for e in extents)
+    inside = (i >= 0) & (i < ex) & (j >= 0) & (j < ey) & (k >= 0) & (k < ez)  # :184-189
+    live = inside & (np.asarray(mask) == 0)  # :434
+    cand = np.nonzero(live)[0]
+    m = voxels[(k[cand] * ey + j[cand]) * ex + i[cand]].astype(np.int64)  # :190: voxel_data_[k * ex * ey + j * ex + i]
+    M = model[:, 0:3].astype(f32)
+    dx, dy, dz = px[cand] - M[m, 0], py[cand] - M[m, 1], pz[cand] - M[m, 2]
+    dist = np.sqrt((dx * dx + dy * dy) + dz * dz)  # :463 norm()
+    thres = f32(dist_thres) * f32(resolution)      # :413
+    keep = ~(dist > thres)                         # :464
+    cand, m = cand[keep], m[keep]
+    mt = model[m, 9:12].astype(f32)
+    m_is_t = np.sqrt((mt[:, 0] * mt[:, 0] + mt[:, 1] * mt[:, 1]) + mt[:, 2] * mt[:, 2]) > f32(0.7)  # :469-470
+    s_is_t = np.asarray(tangent_mask)[cand] != 0   # :441
+    keep = m_is_t == s_is_t                        # :472-478
+    cand, m, s_is_t = cand[keep], m[keep], s_is_t[keep]
+    sv = np.where(s_is_t[:, None], scene[cand, 9:12], scene[cand, 4:7]).astype(f32)   # tangent or normal of p
+    mv = np.where(s_is_t[:, None], model[m, 9:12], model[m, 4:7]).astype(f32)         # ... and of P_m
+    rx = (T[0, 0] * sv[:, 0] + T[0, 1] * sv[:, 1]) + T[0, 2] * sv[:, 2]               # R * v, no translation
+    ry = (T[1, 0] * sv[:, 0] + T[1, 1] * sv[:, 1]) + T[1, 2] * sv[:, 2]
+    rz = (T[2, 0] * sv[:, 0] + T[2, 1] * sv[:, 1]) + T[2, 2] * sv[:, 2]
+    term = np.abs((rx * mv[:, 0] + ry * mv[:, 1]) + rz * mv[:, 2])                   # :484
+    score = float(np.sum(term.astype(np.float64))) / float(len(model))                # :486, :509
+    return cand.astype(np.uint32), m.astype(np.uint32), score
+
+
+def test_project_against_a_numpy_restatement(oracle_small, small_case):
+    """The oracle's project_ against the reference text written a second time in another language: correspondence
+    lists equal entry for entry, scores to the last few bits of the fp64 sum — for the planted poses, perturbed ones,
+    random ones, with mask_ set and with non-finite points in the scene."""
+    m, res = oracle_small["model"], small_case["resolution"]
+    model = small_case["model"]
+    S = small_case["scene"]["surfels"].copy()
+    S[17, 0] = np.nan
+    S[4242, 1] = np.inf
+    tmk = small_case["scene"]["tangent_mask"]
+    s = tmo.Scene(S, tmk)
+    ext, tv = m.grid()
+    vox = m.voxels()
+    rng = np.random.default_rng(12)
+    mask = (rng.random(len(S)) < 0.3).astype(np.int32)
+    poses = [synth.pose_colmajor(T) for T in small_case["scene"]["poses_scene_to_model"]]
+    for base in small_case["scene"]["poses_scene_to_model"]:
+        for _ in range(3):
+            T = np.array(base, np.float64)
+            T[:3, 3] += rng.normal(0, 0.5 * res, 3)
+            poses.append(synth.pose_colmajor(T))
+    for _ in range(4):
+        T = np.eye(4)
+        T[:3, :3] = synth.random_rotation(rng)
+        T[:3, 3] = rng.normal(size=3)
+        poses.append(synth.pose_colmajor(T))
+    hits = 0
+    for use_mask in (False, True):
+        s.set_mask(mask if use_mask else None)
+        for dt in (3.0, 0.5):
+            for pose in poses:
+                sc, mc, score, saved = s.project(m, pose, 0.5, dt)
+                nsc, nmc, nscore = _project_numpy(model, res, vox, ext, tv, S, tmk, mask if use_mask else np.zeros(len(S), np.int32),
+                                                  pose, dt)
+                assert np.array_equal(sc, nsc) and np.array_equal(mc, nmc), (use_mask, dt)
+                assert abs(score - nscore) <= 1e-12 * max(1.0, abs(score)) and saved == 0
+                hits += int(len(sc) > 500)
+    assert hits >= 12
+
+
+def test_pair_table_against_a_numpy_restatement(oracle_small, small_case):
+    """The pair table (reference include/impl/model.hpp:100-149 with feature.hpp:16-46,50-88,91-114 and
+    src/discretize.cpp:20-30) written a second time in numpy from the reference text: the same filters, the same
+    bounds pass (incl. valid_bounds' min + 1.f * (max - min) in float32), the same keys with the same multiplicities.
+    numpy's arctan2 stands in for atan2f (the census of tests/golden/atan2_census.json: a handful of 1.4e7 keys move):
+    at most two entries may sit in a neighbouring angle bin."""
+    f32 = np.float32
+    m = oracle_small["model"]
+    model, subset = small_case["model"], np.asarray(small_case["subset"], np.int64)
+    P, Tg = model[:, 0:3].astype(f32), model[:, 9:12].astype(f32)
+    diam = f32(m.diameter)
+    lower, upper = diam * f32(0.2), diam * f32(1.0)
+    I, J = np.meshgrid(subset, subset, indexing="ij")  # i-major, j-minor (:100)
+    I, J = I.ravel(), J.ravel()
+    ne = I != J
+    I, J = I[ne], J[ne]
+    d = P[J] - P[I]
+    dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dn = d / dist[:, None]                                                      # :108 d1 /= dist1
+        dott = (dn[:, 0] * Tg[I, 0] + dn[:, 1] * Tg[I, 1]) + dn[:, 2] * Tg[I, 2]
+        keep = ~((dist < lower) | (dist > upper)) & ~((f32(1.0) - np.abs(dott)) < f32(0.01))  # :109-110
+    I, J, d, dist = I[keep], J[keep], d[keep], dist[keep]
+
+    def angle(a, b):  # feature.hpp:5-8
+        cx = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
+        cy = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
+        cz = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+        cn = np.sqrt((cx * cx + cy * cy) + cz * cz)
+        dt = np.abs((a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2])
+        return np.arctan2(cn, dt).astype(f32)
+    f0, f1, f2 = dist, angle(d, Tg[I]), angle(d, Tg[J])
+    bmin0, bmax0 = f0.min(), f0.max()                                               # :115 extend
+    diag0 = bmax0 - bmin0
+    nmin0, nmax0 = bmin0 + f32(0.0) * diag0, bmin0 + f32(1.0) * diag0               # valid_bounds(…, 0.0f, 1.f), :122
+    got_min, got_max = m.feature_bounds()
+    assert got_min[0] == nmin0 and got_max[0] == nmax0
+    pi = f32(np.pi)
+    ok = ~((f0 < nmin0) | (f0 > nmax0)) & (f1 >= 0) & (f1 <= pi) & (f2 >= 0) & (f2 <= pi)  # valid(), feature.hpp:50-88
+    rng0 = nmax0 - nmin0                                                            # bounds.diagonal()[0] of the NEW bounds
+    steps = np.uint32(np.float32(20.0))                                             # float -> uint32_t parameter (SURVEY Q3)
+    nval = (f0 - nmin0) / rng0
+    k0 = np.where(nval < 0, 0, np.where(nval >= 1, steps - 1, (nval * f32(steps)).astype(np.uint32))).astype(np.uint32)
+    step = f32(10.0) * f32(np.pi) / f32(180.0)
+    k1, k2 = (f1 / step).astype(np.uint32), (f2 / step).astype(np.uint32)
+    keys = np.stack([k0, k1, k2, k0], 1)[ok]
+    want = {}
+    for k in map(tuple, keys.tolist()):
+        want[k] = want.get(k, 0) + 1
+    okeys, ocounts = m.table_keys()
+    got = {tuple(int(x) for x in k): int(c) for k, c in zip(okeys, ocounts)}
+    assert sum(got.values()) == sum(want.values()) == int(ok.sum()) == m.pair_count() and len(keys) > 1000
+    moved = sum(abs(got.get(k, 0) - want.get(k, 0)) for k in set(got) | set(want))
+    assert moved <= 4, moved  # an entry that changes bin counts twice
