@@ -488,3 +488,120 @@ def test_pair_table_against_a_numpy_restatement(oracle_small, small_case):
     assert sum(got.values()) == sum(want.values()) == int(ok.sum()) == m.pair_count() and len(keys) > 1000
     moved = sum(abs(got.get(k, 0) - want.get(k, 0)) for k in set(got) | set(want))
     assert moved <= 4, moved  # an entry that changes bin counts twice
+
+
+def _point_outcomes_numpy(model, resolution, voxels, extents, to_voxel, scene, tangent_mask, pose16, dist_thres):
+    """per scene point, from the reference text (as _project_numpy): inside the voxel grid?, correspondence?, its model
+    partner, its score term |ref . ref_n| as float32"""
+    f32 = np.float32
+    T = np.asarray(pose16, f32).reshape(4, 4).T
+    P = scene[:, 0:3].astype(f32)
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    px = ((T[0, 0] * x + T[0, 1] * y) + T[0, 2] * z) + T[0, 3]
+    py = ((T[1, 0] * x + T[1, 1] * y) + T[1, 2] * z) + T[1, 3]
+    pz = ((T[2, 0] * x + T[2, 1] * y) + T[2, 2] * z) + T[2, 3]
+    V = np.asarray(to_voxel, f32).reshape(4, 4).T
+    with np.errstate(invalid="ignore", over="ignore"):
+        v = [V[0, 0] * px + V[0, 3], V[1, 1] * py + V[1, 3], V[2, 2] * pz + V[2, 3]]
+        fin = np.isfinite(v[0]) & np.isfinite(v[1]) & np.isfinite(v[2])
+        ijk = [np.where(fin, np.trunc(np.where(fin, c, 0)), -1).astype(np.int64) for c in v]
+    ex, ey, ez = (int(e) for e in extents)
+    inside = (ijk[0] >= 0) & (ijk[0] < ex) & (ijk[1] >= 0) & (ijk[1] < ey) & (ijk[2] >= 0) & (ijk[2] < ez)
+    lin = np.where(inside, (ijk[2] * ey + ijk[1]) * ex + ijk[0], 0)
+    m = voxels[lin].astype(np.int64)
+    M = model[:, 0:3].astype(f32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        dx, dy, dz = px - M[m, 0], py - M[m, 1], pz - M[m, 2]
+        dist = np.sqrt((dx * dx + dy * dy) + dz * dz)
+    close = inside & ~(dist > f32(dist_thres) * f32(resolution))
+    mt = model[m, 9:12].astype(f32)
+    m_is_t = np.sqrt((mt[:, 0] * mt[:, 0] + mt[:, 1] * mt[:, 1]) + mt[:, 2] * mt[:, 2]) > f32(0.7)
+    s_is_t = np.asarray(tangent_mask) != 0
+    corr = close & (m_is_t == s_is_t)
+    sv = np.where(s_is_t[:, None], scene[:, 9:12], scene[:, 4:7]).astype(f32)
+    mv = np.where(s_is_t[:, None], model[m, 9:12], model[m, 4:7]).astype(f32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        rx = (T[0, 0] * sv[:, 0] + T[0, 1] * sv[:, 1]) + T[0, 2] * sv[:, 2]
+        ry = (T[1, 0] * sv[:, 0] + T[1, 1] * sv[:, 1]) + T[1, 2] * sv[:, 2]
+        rz = (T[2, 0] * sv[:, 0] + T[2, 1] * sv[:, 1]) + T[2, 2] * sv[:, 2]
+        term = np.abs((rx * mv[:, 0] + ry * mv[:, 1]) + rz * mv[:, 2])
+    return inside, corr, m, term
+
+
+def _project_early_drop_python(subset, mask, inside, corr, partner, term, accept_prob, n_model):
+    """the loop of include/impl/scene.hpp:421-509 with early_out = true, statement by statement, over per-point outcomes
+    computed beforehand: the test sits at the END of the body, so masked points and points outside the grid (`continue`,
+    :434,:458) never run it; the bound is the literal expression with its negative operands, the casts wrapping as they
+    do on x86-64. Returns (scene_corrs, model_corrs, score, saved)."""
+    import math
+    S = len(subset)
+    tests = [int(np.float32(np.float32(np.float32(0.05) * np.float32(i + 1)) * np.float32(S))) for i in range(int(np.float32(1.0) / np.float32(0.05)) - 2)]
+    sc, mc = [], []
+    tried, next_test, score = 0, 0, 0.0
+    thresh = np.float32(accept_prob) * np.float32(n_model)  # float * size_t -> float (:500)
+    for idx in subset:
+        tried += 1
+        if mask[idx]:
+            continue
+        if not inside[idx]:
+            continue
+        if corr[idx]:
+            score += float(np.float64(term[idx]))
+            sc.append(int(idx))
+            mc.append(int(partner[idx]))
+        if next_test < len(tests) and tried >= tests[next_test]:
+            N = -2.0 - tried
+            x = -2.0 - S
+            n = -1.0 - len(mc)
+            tmp = math.sqrt((x * n * (N - x) * (N - n)) / (N - 1.0))
+            inner = int((x * n + tmp) / N) % (1 << 32)      # static_cast<uint32_t>(negative double): wraps
+            upper = int(-1.0 - inner) % (1 << 32)           # ... and the double result into the uint32_t `upper`
+            if np.float32(upper) < thresh:                  # uint32_t < float
+                return sc, mc, score, S - tried
+            next_test += 1
+    return sc, mc, score / n_model, 0
+
+
+def test_project_with_early_drop_against_a_python_restatement(oracle_small, small_case):
+    """The early-drop rule of project_ (include/impl/scene.hpp:421-509) against the loop written a second time in Python
+    over numpy's per-point outcomes: correspondences, partial or normalised score and `saved` for neighbourhood subsets of
+    several sizes (down to a handful of points, where checkpoints coincide), good, nearly good and wrong poses, several
+    accept_prob, with mask_ set."""
+    m, res = oracle_small["model"], small_case["resolution"]
+    model, sc_ = small_case["model"], small_case["scene"]
+    S, tmk = sc_["surfels"], sc_["tangent_mask"]
+    s = oracle_small["scene"]
+    ext, tv = m.grid()
+    vox = m.voxels()
+    rng = np.random.default_rng(21)
+    mask = (rng.random(len(S)) < 0.2).astype(np.int32)
+    poses = []
+    for base in sc_["poses_scene_to_model"]:
+        poses.append(synth.pose_colmajor(base))
+        for shift in (0.5, 2.0, 6.0, 40.0):
+            T = np.array(base, np.float64)
+            T[:3, 3] += rng.normal(0, shift * res, 3)
+            poses.append(synth.pose_colmajor(T))
+    firsts = [int(np.nonzero(sc_["instance_id"] == k)[0][5]) for k in (0, 1)]
+    subsets = []
+    for c in firsts:
+        for r in (m.diameter, 0.4 * m.diameter, 6 * res, 0.0):
+            subsets.append(s.radius_subset(c, r))
+    dropped = full = 0
+    try:
+        for use_mask in (False, True):
+            s.set_mask(mask if use_mask else None)
+            mk = mask if use_mask else np.zeros(len(S), np.int32)
+            for pose in poses:
+                inside, corr, partner, term = _point_outcomes_numpy(model, res, vox, ext, tv, S, tmk, pose, 3.0)
+                for sub in subsets:
+                    for accept in (0.5, 0.1, 0.9):
+                        want = _project_early_drop_python(sub, mk, inside, corr, partner, term, accept, len(model))
+                        got = s.project(m, pose, accept, 3.0, subset=sub, early_out=True)
+                        assert list(got[0]) == want[0] and list(got[1]) == want[1], (use_mask, len(sub), accept)
+                        assert got[3] == want[3] and abs(got[2] - want[2]) <= 1e-12 * max(1.0, abs(want[2]))
+                        dropped += int(want[3] > 0)
+                        full += int(want[3] == 0 and len(want[0]) > 50)
+    finally:
+        s.set_mask(None)
+    assert dropped > 50 and full > 20
