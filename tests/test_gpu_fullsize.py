@@ -82,6 +82,11 @@ def test_voxel_grid_full_size(gpu_ctx, full):
     assert np.array_equal(vox, vb)
     del vb
     gb.close()
+    with gpu_ctx.option("voxel_packet", 0):  # ... and the per-voxel descent == the packet descent (the default)
+        gp = capi.Model(gpu_ctx, full["model"], full["res"])
+        gp.build_voxels()
+        assert np.array_equal(vox, gp.voxels())
+        gp.close()
     # sampled voxels: the stored point is a nearest neighbour of the voxel centre (fp64, all points)
     rng = np.random.default_rng(3)
     T = np.asarray(to_voxel, np.float64).reshape(4, 4).T  # column-major -> matrix

@@ -117,6 +117,20 @@ def test_voxel_grid_with_ties_and_degenerate_axis(gpu_ctx):
     assert np.array_equal(g.grid()[0], o.grid()[0])
     vg, vo = g.voxels(), o.voxels()
     assert np.array_equal(vg, vo) and vg.max() < n // 2
+    # the model's arrays, order and tree built on the host (round 1-3) instead of on the device: same table; the same
+    # with a few non-finite points in the cloud and with clouds of one to nine points (a single leaf, no tree at all)
+    s2 = s.copy()
+    s2[[3, 77, 399], 0] = np.nan
+    s2[5, 2] = np.inf
+    for cloud in (s, s2, s[:1], s[:2], s[:9], s2[:6]):
+        ref = tmo.Model(cloud, res)
+        ref.build_voxels(threads=4, brute=True)
+        for host_build in (0, 1):
+            with gpu_ctx.option("model_host_build", host_build):
+                gm = capi.Model(gpu_ctx, cloud, res)
+                gm.build_voxels()
+                assert np.array_equal(gm.voxels(), ref.voxels()), (len(cloud), host_build)
+                gm.close()
 
 
 def test_pair_table_bit_exact(gpu_small, oracle_small, small_case):
@@ -641,6 +655,24 @@ def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
         b.build_voxels()
         vb = b.voxels()
     assert va.size > 4_000_000 and np.array_equal(va, vb)
+    with gpu_ctx.option("model_host_build", 1):  # arrays, curve order and a median kd-tree from the host
+        h = capi.Model(gpu_ctx, model, res)
+        h.build_voxels()
+        assert np.array_equal(va, h.voxels())
+        sub_t = np.nonzero(np.linalg.norm(model[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+        a.build_pairs(sub_t)
+        h.build_pairs(sub_t)
+        ka, kh = a.table(), h.table()
+        assert all(np.array_equal(x, y) for x, y in zip(ka, kh)) and len(ka[0]) > 10  # same order -> same table
+        h.close()
+    with gpu_ctx.option("voxel_packet", 0):  # every voxel on its own stack instead of a brick's 64 as one packet
+        c = capi.Model(gpu_ctx, model, res)
+        c.build_voxels()
+        assert np.array_equal(va, c.voxels())
+        sc = capi.Scene(gpu_ctx, model[:256], np.zeros(256, np.int32))
+        assert np.array_equal(sc.score_hypotheses(c, np.eye(4, dtype=np.float32).reshape(1, 16), DT)[0],
+                              sc.score_hypotheses(a, np.eye(4, dtype=np.float32).reshape(1, 16), DT)[0])  # brick minima too
+        c.close()
     assert not np.isin(va, np.arange(15000, 15500)).any()  # duplicates never win over their originals
     poses = np.eye(4, dtype=np.float32).reshape(1, 16)
     s = capi.Scene(gpu_ctx, model, (np.linalg.norm(model[:, 9:12], axis=1) > 0.7).astype(np.int32))
@@ -784,11 +816,21 @@ def test_cloud_resolution_bit_exact(gpu_ctx):
     model, _ = synth.synth_model(6000, seed=5)
     model[100:110, 0:3] = model[200:210, 0:3]
     model[50, 0] = np.nan
-    rg, dg = gpu_ctx.cloud_resolution(model)
     ro, do = tmo.cloud_resolution(model)
-    assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
-    assert np.float32(rg).view(np.uint32) == np.float32(ro).view(np.uint32)
-    assert (dg[100:110] == 0).all() and abs(rg - synth.resolution(model[np.isfinite(model[:, 0])])) < 1e-4
+    for host_trees in (0, 1):  # order + tree built on the device (default) / median kd-tree built on host threads
+        with gpu_ctx.option("model_host_build", host_trees):
+            rg, dg = gpu_ctx.cloud_resolution(model)
+            assert np.array_equal(dg.view(np.uint32), do.view(np.uint32)), host_trees
+            assert np.float32(rg).view(np.uint32) == np.float32(ro).view(np.uint32)
+            assert (dg[100:110] == 0).all() and abs(rg - synth.resolution(model[np.isfinite(model[:, 0])])) < 1e-4
+            for tiny in (model[:2], model[48:52], model[:9]):  # a single leaf
+                rt, dt_ = gpu_ctx.cloud_resolution(tiny)
+                rto, dto = tmo.cloud_resolution(tiny)
+                assert np.float32(rt).view(np.uint32) == np.float32(rto).view(np.uint32), (host_trees, len(tiny))
+                assert np.array_equal(dt_.view(np.uint32), dto.view(np.uint32))
+            # fewer than two finite points: the reference indexes past its one neighbour (undefined,
+            # include/impl/pointcloud.hpp:73-78); here the resolution is 0
+            assert gpu_ctx.cloud_resolution(model[:1])[0] == 0.0 and gpu_ctx.cloud_resolution(model[50:52])[0] == 0.0
 
 
 def test_cloud_curvature_bit_exact(gpu_ctx):
@@ -796,9 +838,18 @@ def test_cloud_curvature_bit_exact(gpu_ctx):
     model, _ = synth.synth_model(3000, seed=6)
     model[10:14, 0:3] = model[20:24, 0:3]  # duplicates: ties in the neighbour order
     model[77, 1] = np.inf
-    cg = gpu_ctx.cloud_curvature(model, 30)
     co = tmo.cloud_curvature(model, 30)
+    with gpu_ctx.option("model_host_build", 1):  # the median kd-tree built on host threads (rounds 1-3)
+        ch = gpu_ctx.cloud_curvature(model, 30)
+        sub = np.array([77, 5, 2999, 10, 11, 12, 13, 20], np.uint32)
+        assert np.array_equal(gpu_ctx.cloud_curvature_subset(model, sub, 30).view(np.uint32), co[sub].view(np.uint32))
+    assert np.array_equal(ch.view(np.uint32), co.view(np.uint32))
+    cg = gpu_ctx.cloud_curvature(model, 30)  # default: curve order and tree made on the device
     assert np.array_equal(cg.view(np.uint32), co.view(np.uint32))
+    assert np.array_equal(gpu_ctx.cloud_curvature_subset(model, sub, 30).view(np.uint32), co[sub].view(np.uint32))
+    for n_tiny in (1, 2, 9, 40):  # fewer points than k, a single leaf
+        assert np.array_equal(gpu_ctx.cloud_curvature(model[:n_tiny], 30).view(np.uint32),
+                              tmo.cloud_curvature(model[:n_tiny], 30).view(np.uint32)), n_tiny
     # edge-like points (normals of two faces among the neighbours) have pc_min / pc_max < 0.2
     with np.errstate(invalid="ignore", divide="ignore"):
         ratio = cg[:, 3] / cg[:, 4]

@@ -117,6 +117,8 @@ struct options {
                                  the grid's bricks lies beyond the threshold (auto), 2 always */
     int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
+    int voxel_packet = 1;     /* 0: kd descent per voxel on per-thread stacks instead of one packet per brick */
+    int model_host_build = 0; /* 1: tm_model_create sorts the cloud and builds a median kd-tree on the host (cross-check) */
     int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
     int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
     int ed_prefix_list = 1;   /* 0: the first step of the early-drop rule walks the neighbourhood list (scan order)
@@ -392,6 +394,9 @@ bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
 int scene_upload(tm_scene* s, const float* surfels = nullptr);
 int scene_build(tm_scene* s, bool resort);
+/* tm_scene_build.hip: sorted curve keys + order of a raw device cloud (d_bounds: room for a tmx::scene_bounds, 64 bytes) */
+int curve_order(tm_ctx* c, const float* d_cloud, uint32_t n, bool hilbert, void* d_bounds,
+                dbuf<unsigned long long>& keys_out, dbuf<uint32_t>& order_out);
 /* ascending indices of the points with tangent_mask set (s->d_tangent_idx, s->n_tangent), built once per scene */
 int scene_tangent_index(tm_scene* s);
 /* the scene's pinned staging buffer (s->h_pinned) with room for at least `need` bytes; grown with a quarter of head

@@ -195,13 +195,104 @@ __global__ __launch_bounds__(256) void k_voxel_nn_kd(const float4* __restrict__ 
     if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = bmin;
 }
 
+/* The same search with the 64 voxels of a brick walking the tree TOGETHER (a packet): one stack of node ids per wave
+ * (256 bytes of LDS instead of 48 KB of per-thread stacks per workgroup), node and leaf loads at one address for the
+ * whole wave, and a subtree is entered when ANY lane's box distance does not exceed that lane's best — which is when the
+ * per-thread walk would have made the wave execute it anyway, under divergence. A lane that did not ask for a subtree
+ * still tests its points: that can only find what its own rule would accept (d2 < best, or d2 == best at a lower
+ * original index), so every lane ends with the same (distance, index) as on its own. The order of the two children
+ * follows lane 21 (a voxel in the middle of the brick); any order is correct. */
+constexpr int kKdPacketStack = 64;
+__global__ __launch_bounds__(256) void k_voxel_nn_packet(const float4* __restrict__ kd_lo,
+                                                         const float4* __restrict__ kd_hi,
+                                                         const float4* __restrict__ pts,
+                                                         const uint32_t* __restrict__ new2orig, grid_t g,
+                                                         uint64_t voxel_slots, int bx, int by,
+                                                         uint32_t* __restrict__ voxels,
+                                                         uint32_t* __restrict__ brick_min_bits) {
+    __shared__ uint32_t st_node[4][kKdPacketStack];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t brick = (uint32_t)(slot >> 6), loc = (uint32_t)(slot & 63);
+    uint32_t bi, bj, bk;
+    brick_coords(brick, (uint32_t)bx, (uint32_t)by, bi, bj, bk);
+    const uint32_t i = (bi << 2) + (loc & 3u), j = (bj << 2) + ((loc >> 2) & 3u), k = (bk << 2) + (loc >> 4);
+    const bool live = slot < voxel_slots && i < (uint32_t)g.ex && j < (uint32_t)g.ey && k < (uint32_t)g.ez;
+    const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
+    float q[3];
+    q[0] = isx * (float)i + (-(g.tx * isx));
+    q[1] = isy * (float)j + (-(g.ty * isy));
+    q[2] = isz * (float)k + (-(g.tz * isz));
+    float best = __builtin_inff();
+    uint32_t besti = 0xFFFFFFFFu, besto = 0xFFFFFFFFu;
+    if (__ballot(live)) { /* wave-uniform: a brick with no voxel in the grid has nothing to find */
+        int sp = 1;
+        if ((threadIdx.x & 63u) == 0u) st_node[wave][0] = 0u;
+        while (sp > 0) {
+            --sp;
+            uint32_t node = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_node[wave][sp]);
+            /* does any lane still need this subtree? (bests have shrunk since it was pushed) */
+            if (!__ballot(live && !(box_d2(q, kd_lo[node], kd_hi[node]) > best))) continue;
+            for (;;) {
+                const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
+                if (a & 0x80000000u) { /* leaf: points [begin, end), the same ones for every lane */
+                    for (uint32_t p = a & 0x7FFFFFFFu; p < b; ++p) {
+                        const float4 P = pts[p];
+                        const float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (d2 <= best) {
+                            const uint32_t ni = __float_as_uint(P.w);
+                            const uint32_t o = new2orig[ni];
+                            if (d2 < best || o < besto) {
+                                best = d2;
+                                besti = ni;
+                                besto = o;
+                            }
+                        }
+                    }
+                    break;
+                }
+                const float dl = box_d2(q, kd_lo[a], kd_hi[a]);
+                const float dr = box_d2(q, kd_lo[b], kd_hi[b]);
+                const bool any_l = __ballot(live && !(dl > best)) != 0ull;
+                const bool any_r = __ballot(live && !(dr > best)) != 0ull;
+                if (!any_l && !any_r) break;
+                /* nearer child first as the brick's middle voxel sees it */
+                const float ml = __shfl(dl, 21), mr = __shfl(dr, 21);
+                const bool left_first = ml <= mr;
+                uint32_t first = left_first ? a : b, second = left_first ? b : a;
+                const bool any_first = left_first ? any_l : any_r, any_second = left_first ? any_r : any_l;
+                if (any_first && any_second) {
+                    if (sp < kKdPacketStack) {
+                        if ((threadIdx.x & 63u) == 0u) st_node[wave][sp] = second;
+                        ++sp;
+                    }
+                    node = first;
+                } else {
+                    node = any_first ? first : second;
+                }
+                node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            }
+        }
+    }
+    if (slot < voxel_slots) voxels[slot] = live ? besti : 0u;
+    uint32_t bmin = live ? __float_as_uint(best) : 0x7F7F7F7Fu;
+    for (int off = 32; off > 0; off >>= 1) bmin = min(bmin, (uint32_t)__shfl_down((int)bmin, off));
+    if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = bmin;
+}
+
 /* second-smallest squared distance from each point to the cloud (the point itself included, as
- * nearestKSearch(pnt, 2) does): same box-pruned kd descent, bound = current second best */
+ * nearestKSearch(pnt, 2) does): same box-pruned kd descent, bound = current second best. STACK > 32 (the device-built
+ * tree, deeper than a median kd-tree): node ids only on the stack, the box distance is taken again at the pop.
+ * BYW: the queries are the tree's own points in its order (a wave walks neighbouring paths) and row = the original
+ * index in their w; otherwise row = query number. */
+template <int STACK = kKdStack, bool BYW = false>
 __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, const float4* __restrict__ kd_hi,
                                               const float4* __restrict__ pts, const float4* __restrict__ queries,
                                               uint32_t n, float* __restrict__ out) {
-    __shared__ uint32_t st_node[kKdStack][256];
-    __shared__ float st_bound[kKdStack][256];
+    constexpr bool kBounds = STACK <= 32;
+    __shared__ uint32_t st_node[STACK][256];
+    __shared__ float st_bound[kBounds ? STACK : 1][256];
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const float4 Q = queries[t];
@@ -210,11 +301,11 @@ __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, 
     if (Q.x == Q.x) {
         int sp = 1;
         st_node[0][threadIdx.x] = 0u;
-        st_bound[0][threadIdx.x] = 0.f;
+        if (kBounds) st_bound[0][threadIdx.x] = 0.f;
         while (sp > 0) {
             --sp;
             uint32_t node = st_node[sp][threadIdx.x];
-            if (st_bound[sp][threadIdx.x] > b2) continue;
+            if (kBounds ? st_bound[sp][threadIdx.x] > b2 : box_d2(q, kd_lo[node], kd_hi[node]) > b2) continue;
             for (;;) {
                 const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
                 if (a & 0x80000000u) {
@@ -235,9 +326,9 @@ __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, 
                 float dr = box_d2(q, kd_lo[b], kd_hi[b]);
                 uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
                 float dn = fminf(dl, dr), df = fmaxf(dl, dr);
-                if (!(df > b2) && sp < kKdStack) {
+                if (!(df > b2) && sp < STACK) {
                     st_node[sp][threadIdx.x] = farc;
-                    st_bound[sp][threadIdx.x] = df;
+                    if (kBounds) st_bound[sp][threadIdx.x] = df;
                     ++sp;
                 }
                 if (dn > b2) break;
@@ -245,7 +336,12 @@ __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, 
             }
         }
     }
-    out[t] = (Q.x == Q.x) ? sqrtf(b2) : 0.f; /* non-finite points are not part of the tree */
+    const float r = (Q.x == Q.x) ? sqrtf(b2) : 0.f; /* non-finite points are not part of the tree */
+    if (BYW) {
+        if (Q.x == Q.x) out[__float_as_uint(Q.w)] = r;
+    } else {
+        out[t] = r;
+    }
 }
 
 /* k nearest neighbours (self included) + principal curvatures, one thread per point. The neighbour list
@@ -831,6 +927,13 @@ static int setup_grid(tm_model* m) {
 
 using namespace tmx;
 
+namespace tmx {
+static int model_arrays_on_device(tm_model* m, const float* surfels); /* defined with the tree builder below */
+static int cloud_curvature_on_device(tm_ctx* c, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
+                                     uint32_t n_idx, float* curv5);
+static int cloud_nn_distances_on_device(tm_ctx* c, const float* surfels, uint32_t n, float* dist, uint32_t* n_fin);
+}
+
 extern "C" {
 
 int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolution,
@@ -847,6 +950,25 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
     m->distance_step_count = distance_step_count;
     m->angle_step = angle_step;
     m->h_cloud.assign(surfels, surfels + (size_t)n * 12);
+    /* Round 4: the arrays, their curve order and the tree are built on the device from the raw cloud (the scene's
+     * kernels: curve keys, radix sort, linear BVH over the sorted keys) — 22 ms of host sorting, median splits and
+     * array shuffling per 100k points became 2. The order is the one the host code below produces (same keys, stable
+     * sort). The tree is deeper than a median kd-tree, which only the packet walk of the voxel build tolerates, so
+     * voxel_packet = 0 (and model_host_build = 1, the cross-check) keep the host build. */
+    if (ctx->opt.voxel_packet && !ctx->opt.model_host_build) {
+        int rc = model_arrays_on_device(m, surfels);
+        if (rc == TM_OK) rc = setup_grid(m);
+        if (rc) {
+            tm_model_destroy(m);
+            return rc;
+        }
+        for (int d = 0; d < 4; ++d) {
+            m->bmin[d] = std::numeric_limits<float>::max();
+            m->bmax[d] = std::numeric_limits<float>::lowest();
+        }
+        *out = m;
+        return TM_OK;
+    }
     /* internal order = Hilbert curve over the finite bounding box (non-finite points last); neighbours in
      * space are neighbours in the arrays, so the scoring kernel's gathers of model points share lines.
      * TM_MODEL_MORTON=1 selects the plain Morton order (timing comparisons). */
@@ -974,6 +1096,23 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
     *resolution = 0.f;
     if (n < 2) return TM_OK;
     TM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->opt.model_host_build) {
+        /* round 4: curve order, tree and the 2-NN walk on the device (no kd-tree built on host threads: 3.4 ms per 100k
+         * points, 38 ms per million); the running mean stays here, in f32 and in point order (include/common:104-115) */
+        std::vector<float> dist(n);
+        uint32_t n_fin = 0;
+        TM_FORWARD(cloud_nn_distances_on_device(ctx, surfels, n, dist.data(), &n_fin));
+        if (n_fin < 2) return TM_OK;
+        float accum = 0.f;
+        uint32_t i = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!fin3(surfels + (size_t)k * 12)) continue;
+            accum = accum + (dist[k] - accum) / (float)(++i);
+        }
+        *resolution = accum;
+        if (nn_dist) memcpy(nn_dist, dist.data(), (size_t)n * 4);
+        return TM_OK;
+    }
     std::vector<float4> pos(n);
     const float nanv = std::numeric_limits<float>::quiet_NaN();
     for (uint32_t i = 0; i < n; ++i) {
@@ -1003,7 +1142,7 @@ int tm_cloud_resolution(tm_ctx* ctx, const float* surfels, uint32_t n, float* re
     if (e == hipSuccess) e = hipMemcpyAsync(d_pts.p, kd_pts.data(), kd_pts.size() * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_q.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_knn2, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_lo.p, d_hi.p, d_pts.p, d_q.p, n,
+        hipLaunchKernelGGL((k_knn2<kKdStack, false>), dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_lo.p, d_hi.p, d_pts.p, d_q.p, n,
                            d_out.p);
         e = hipGetLastError();
     }
@@ -1044,6 +1183,8 @@ int tm_cloud_curvature_subset(tm_ctx* ctx, const float* surfels, uint32_t n, uin
         for (uint32_t q = 0; q < n_idx; ++q)
             TM_REQUIRE(indices[q] < n, TM_ERR_INVALID, "tm_cloud_curvature_subset: index out of range");
     TM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->opt.model_host_build) /* round 4: the cloud goes up raw; order, tree and queries are made there */
+        return cloud_curvature_on_device(ctx, surfels, n, k, indices, indices ? n_idx : 0u, curv5);
     const bool dbg = ctx->opt.debug_times != 0; /* where the call's time goes, on stderr */
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -1218,6 +1359,123 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const float4* __restrict__ p
         hi[id] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(b));
     }
 }
+/* queues the build of the tree over pts[0, n_fin) (in the order of their sorted keys): lo / hi = 2 * n_fin nodes at
+ * most, q0 / q1 = n_fin work items each, cnt = 3 + kLbvhMaxDepth + 3 words (nodes, |q0|, |q1|, level starts; cnt[0]
+ * ends up as the node count) */
+static void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4* d_pts, uint32_t n_fin, float4* d_lo,
+                       float4* d_hi, uint4* d_q0, uint4* d_q1, uint32_t* d_cnt) {
+    uint32_t* level_start = d_cnt + 3;
+    hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(1), 0, c->stream, n_fin, d_q0, d_cnt, level_start);
+    const uint32_t grid = std::min<uint32_t>(1024u, (n_fin + 255u) / 256u);
+    for (uint32_t d = 0; d <= (uint32_t)kLbvhMaxDepth; ++d) { /* level d's nodes -> level d + 1's */
+        const uint32_t in = d & 1u;
+        hipLaunchKernelGGL(k_lbvh_level, dim3(grid), dim3(256), 0, c->stream, d_keys, in ? d_q1 : d_q0, d_cnt + 1 + in,
+                           in ? d_q0 : d_q1, d_cnt + 1 + (in ^ 1u), d_cnt, d_lo, d_hi);
+        hipLaunchKernelGGL(k_lbvh_mark, dim3(1), dim3(1), 0, c->stream, d_cnt, in, level_start + d + 2);
+    }
+    for (uint32_t d = (uint32_t)kLbvhMaxDepth + 2u; d-- > 0;) /* nodes of level d: [level_start[d], level_start[d + 1]) */
+        hipLaunchKernelGGL(k_lbvh_boxes, dim3(grid), dim3(256), 0, c->stream, d_pts, level_start + d, d_lo, d_hi);
+}
+
+/* the model's arrays in curve order from its raw cloud on the device (what tm_model_create used to assemble on the
+ * host): slot k holds original point order[k]; pos.w = ref.w = (|tangent| > 0.7) (reference include/impl/scene.hpp:
+ * 469-470), ref = tangent or normal, a non-finite point has pos.x = NaN; kd_pts[k] = (xyz, k) for the finite prefix */
+__global__ __launch_bounds__(256) void k_model_gather(const float* __restrict__ cloud, const uint32_t* __restrict__ order,
+                                                      uint32_t n, float4* __restrict__ pos, float4* __restrict__ ref,
+                                                      float4* __restrict__ tan4, float4* __restrict__ vpos,
+                                                      float* __restrict__ pos3, uint32_t* __restrict__ new2orig,
+                                                      float4* __restrict__ kd_pts, uint32_t* __restrict__ n_fin) {
+    __shared__ uint32_t s_n[4];
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    bool fin = false;
+    if (k < n) {
+        const uint32_t i = order[k];
+        const float4* sp = reinterpret_cast<const float4*>(cloud) + (size_t)i * 3;
+        const float4 a = sp[0], b = sp[1], cc = sp[2];
+        fin = isfinite(a.x) && isfinite(a.y) && isfinite(a.z);
+        const f3 t = make3(cc.y, cc.z, cc.w);
+        const bool is_t = len(t) > 0.7f;
+        const float px = fin ? a.x : __builtin_nanf("");
+        pos[k] = make_float4(px, a.y, a.z, is_t ? 1.f : 0.f);
+        ref[k] = is_t ? make_float4(cc.y, cc.z, cc.w, 1.f) : make_float4(b.x, b.y, b.z, 0.f);
+        tan4[k] = make_float4(cc.y, cc.z, cc.w, 0.f);
+        vpos[k] = make_float4(px, a.y, a.z, __uint_as_float(i));
+        pos3[3 * (size_t)k] = px;
+        pos3[3 * (size_t)k + 1] = a.y;
+        pos3[3 * (size_t)k + 2] = a.z;
+        new2orig[k] = i;
+        /* non-finite points sort last (k_scene_morton), so the finite ones are a prefix of the order */
+        kd_pts[k] = fin ? make_float4(a.x, a.y, a.z, __uint_as_float(k)) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+    }
+    const unsigned long long bl = __ballot(fin);
+    if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = (uint32_t)__popcll(bl);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+        if (t) atomicAdd(n_fin, t);
+    }
+}
+
+static int model_arrays_on_device(tm_model* m, const float* surfels) {
+    tm_ctx* c = m->ctx;
+    const uint32_t n = m->n;
+    dbuf<float> d_cloud;
+    dbuf<unsigned long long> d_keys;
+    dbuf<uint32_t> d_order, d_cnt;
+    dbuf<unsigned char> d_bounds;
+    dbuf<uint4> d_q;
+    auto cleanup = [&]() {
+        d_cloud.release();
+        d_keys.release();
+        d_order.release();
+        d_cnt.release();
+        d_bounds.release();
+        d_q.release();
+    };
+    int rc;
+    if ((rc = d_cloud.alloc((size_t)n * 12)) || (rc = d_bounds.alloc(64)) || (rc = d_cnt.alloc(3 + kLbvhMaxDepth + 3 + 1)) ||
+        (rc = d_q.alloc(2 * (size_t)n)) || (rc = m->pos.alloc(n)) || (rc = m->ref.alloc(n)) || (rc = m->tan4.alloc(n)) ||
+        (rc = m->vpos.alloc(n)) || (rc = m->new2orig.alloc(n)) || (rc = m->pos3.alloc((size_t)n * 3)) ||
+        (rc = m->kd_lo.alloc(2 * (size_t)n)) || (rc = m->kd_hi.alloc(2 * (size_t)n)) || (rc = m->kd_pts.alloc(n))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_cloud.p, surfels, (size_t)n * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = curve_order(c, d_cloud.p, n, !c->opt.model_morton, d_bounds.p, d_keys, d_order);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+    }
+    uint32_t* d_nfin = d_cnt.p + 3 + kLbvhMaxDepth + 3;
+    uint32_t n_fin = 0, n_nodes = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(d_nfin, 0, 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_model_gather, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud.p, d_order.p, n, m->pos.p,
+                           m->ref.p, m->tan4.p, m->vpos.p, m->pos3.p, m->new2orig.p, m->kd_pts.p, d_nfin);
+        e = hipMemcpyAsync(&n_fin, d_nfin, 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    m->h_new2orig.resize(n);
+    if (e == hipSuccess) e = hipMemcpyAsync(m->h_new2orig.data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n_fin > 0) {
+        lbvh_build(c, d_keys.p, m->kd_pts.p, n_fin, m->kd_lo.p, m->kd_hi.p, d_q.p, d_q.p + n, d_cnt.p);
+        e = hipMemcpyAsync(&n_nodes, d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_model_create: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    m->h_orig2new.resize(n);
+    for (uint32_t k = 0; k < n; ++k) m->h_orig2new[m->h_new2orig[k]] = k;
+    m->kd_n_nodes = n_nodes;
+    m->kd_n_pts = n_fin;
+    return TM_OK;
+}
+
 /* the finite points of a scene in its curve order (xyz, original index) — mask_ does not matter here — and how many */
 __global__ __launch_bounds__(256) void k_kd_scene_points(const float* __restrict__ cloud, const uint32_t* __restrict__ order,
                                                          uint32_t n, float4* __restrict__ pts, uint32_t* __restrict__ n_fin) {
@@ -1264,10 +1522,18 @@ struct scene_curv_work {
 
 /* kNN-k curvature of the scene points idx[0..n_idx) (host indices, or device indices when idx_on_device) on a linear
  * BVH built over the scene's curve order; rows stay on the device in w.d_out. The caller releases w.arena. */
+static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_order, const unsigned long long* d_keys,
+                         uint32_t n, uint32_t k, const uint32_t* idx, bool idx_on_device, uint32_t n_idx, scene_curv_work& w);
 static int scene_curvature_run(tm_scene* s, uint32_t k, const uint32_t* idx, bool idx_on_device, uint32_t n_idx,
                                scene_curv_work& w) {
-    tm_ctx* c = s->ctx;
-    const uint32_t n = s->n;
+    return curvature_run(s->ctx, s->d_cloud.p, s->d_order.p, s->d_keys.p, s->n, k, idx, idx_on_device, n_idx, w);
+}
+/* the same over any raw cloud on the device with its curve order (tmx::curve_order). idx == null: every point, rows
+ * by original index (n rows), the queries taken in the tree's order */
+static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_order, const unsigned long long* d_keys,
+                         uint32_t n, uint32_t k, const uint32_t* idx, bool idx_on_device, uint32_t n_idx, scene_curv_work& w) {
+    const bool all = idx == nullptr;
+    if (all) n_idx = n;
     const bool dbg = c->opt.debug_times != 0; /* where the call's time goes, on stderr */
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -1300,37 +1566,29 @@ static int scene_curvature_run(tm_scene* s, uint32_t k, const uint32_t* idx, boo
     w.d_out = d_out.p;
     uint32_t n_fin = 0;
     hipError_t e = hipMemsetAsync(d_idx.p + n_idx, 0, 4, c->stream);
-    if (e == hipSuccess)
+    if (e == hipSuccess && !all)
         e = hipMemcpyAsync(d_idx.p, idx, (size_t)n_idx * 4, idx_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                            c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, (size_t)n_idx * 20, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_kd_scene_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, s->d_cloud.p, s->d_order.p, n,
+        hipLaunchKernelGGL(k_kd_scene_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_order, n,
                            d_pts.p, d_idx.p + n_idx);
-        hipLaunchKernelGGL(k_kd_scene_normals, dim3((n + 255) / 256), dim3(256), 0, c->stream, s->d_cloud.p, n, d_nrm.p);
-        hipLaunchKernelGGL(k_kd_scene_queries, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, s->d_cloud.p, d_idx.p, n_idx,
-                           d_q.p);
+        hipLaunchKernelGGL(k_kd_scene_normals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, n, d_nrm.p);
+        if (!all)
+            hipLaunchKernelGGL(k_kd_scene_queries, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_idx.p, n_idx,
+                               d_q.p);
         e = hipMemcpyAsync(&n_fin, d_idx.p + n_idx, 4, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     lap("alloc + points, normals, queries");
     if (e == hipSuccess && n_fin > 0) {
-        /* d_cnt: nodes, |q0|, |q1|, then kLbvhMaxDepth + 3 level starts */
-        uint32_t* level_start = d_cnt.p + 3;
-        hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(1), 0, c->stream, n_fin, d_q0.p, d_cnt.p, level_start);
-        const uint32_t grid = std::min<uint32_t>(1024u, (n_fin + 255u) / 256u);
-        for (uint32_t d = 0; d <= (uint32_t)kLbvhMaxDepth; ++d) { /* level d's nodes -> level d + 1's */
-            const uint32_t in = d & 1u;
-            hipLaunchKernelGGL(k_lbvh_level, dim3(grid), dim3(256), 0, c->stream, s->d_keys.p, in ? d_q1.p : d_q0.p,
-                               d_cnt.p + 1 + in, in ? d_q0.p : d_q1.p, d_cnt.p + 1 + (in ^ 1u), d_cnt.p, d_lo.p, d_hi.p);
-            hipLaunchKernelGGL(k_lbvh_mark, dim3(1), dim3(1), 0, c->stream, d_cnt.p, in, level_start + d + 2);
-        }
-        for (uint32_t d = (uint32_t)kLbvhMaxDepth + 2u; d-- > 0;) /* nodes of level d: [level_start[d], level_start[d + 1]) */
-            hipLaunchKernelGGL(k_lbvh_boxes, dim3(grid), dim3(256), 0, c->stream, d_pts.p, level_start + d, d_lo.p, d_hi.p);
+        lbvh_build(c, d_keys, d_pts.p, n_fin, d_lo.p, d_hi.p, d_q0.p, d_q1.p, d_cnt.p);
         lap("tree");
         const uint32_t kk = std::min(k, n_fin);
-        hipLaunchKernelGGL(k_curvature<kLbvhStack>, dim3((n_idx + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0,
-                           c->stream, d_lo.p, d_hi.p, d_pts.p, d_nrm.p, n_fin, kk, d_out.p, d_q.p, n_idx);
+        const uint32_t n_threads = all ? n_fin : n_idx;
+        hipLaunchKernelGGL(k_curvature<kLbvhStack>, dim3((n_threads + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0,
+                           c->stream, d_lo.p, d_hi.p, d_pts.p, d_nrm.p, n_fin, kk, d_out.p, all ? (const float4*)nullptr : d_q.p,
+                           n_idx);
         e = hipGetLastError();
         lap("kernel");
     }
@@ -1338,6 +1596,110 @@ static int scene_curvature_run(tm_scene* s, uint32_t k, const uint32_t* idx, boo
         set_error("scene curvature: %s", hipGetErrorString(e));
         return TM_ERR_HIP;
     }
+    return TM_OK;
+}
+
+/* a raw host cloud on the device with its curve order: what the cloud-level calls (curvature, resolution) need before
+ * they can use the scene's tree builder */
+struct device_cloud {
+    dbuf<float> cloud;
+    dbuf<unsigned long long> keys;
+    dbuf<uint32_t> order;
+    dbuf<unsigned char> bounds;
+    void release() {
+        cloud.release();
+        keys.release();
+        order.release();
+        bounds.release();
+    }
+};
+static int device_cloud_make(tm_ctx* c, const float* surfels, uint32_t n, device_cloud& dc) {
+    int rc;
+    if ((rc = dc.cloud.alloc((size_t)n * 12)) || (rc = dc.bounds.alloc(64))) return rc;
+    TM_HIP_CHECK(hipMemcpyAsync(dc.cloud.p, surfels, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    return curve_order(c, dc.cloud.p, n, true, dc.bounds.p, dc.keys, dc.order);
+}
+
+static int cloud_curvature_on_device(tm_ctx* c, const float* surfels, uint32_t n, uint32_t k, const uint32_t* indices,
+                                     uint32_t n_idx, float* curv5) {
+    const uint32_t n_rows = indices ? n_idx : n;
+    device_cloud dc;
+    scene_curv_work w;
+    int rc = device_cloud_make(c, surfels, n, dc);
+    if (rc == TM_OK) rc = curvature_run(c, dc.cloud.p, dc.order.p, dc.keys.p, n, k, indices, false, n_idx, w);
+    hipError_t e = hipSuccess;
+    if (rc == TM_OK) {
+        e = hipMemcpyAsync(curv5, w.d_out, (size_t)n_rows * 20, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    w.arena.release();
+    dc.release();
+    if (rc != TM_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("tm_cloud_curvature: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
+/* distance of every point to its nearest OTHER point of the cloud (the second entry of nearestKSearch(pnt, 2)), rows
+ * by original index, 0 for non-finite points; *n_fin = finite points */
+static int cloud_nn_distances_on_device(tm_ctx* c, const float* surfels, uint32_t n, float* dist, uint32_t* n_fin_out) {
+    device_cloud dc;
+    dbuf<unsigned char> arena;
+    auto cleanup = [&]() {
+        arena.release();
+        dc.release();
+    };
+    int rc = device_cloud_make(c, surfels, n, dc);
+    if (rc != TM_OK) {
+        cleanup();
+        return rc;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_pts = take((size_t)n * 16), o_lo = take(2 * (size_t)n * 16), o_hi = take(2 * (size_t)n * 16),
+                 o_q0 = take((size_t)n * 16), o_q1 = take((size_t)n * 16), o_cnt = take((3 + kLbvhMaxDepth + 3 + 1) * 4),
+                 o_out = take((size_t)n * 4);
+    if ((rc = arena.alloc(off))) {
+        cleanup();
+        return rc;
+    }
+    float4* d_pts = reinterpret_cast<float4*>(arena.p + o_pts);
+    float4* d_lo = reinterpret_cast<float4*>(arena.p + o_lo);
+    float4* d_hi = reinterpret_cast<float4*>(arena.p + o_hi);
+    uint4* d_q0 = reinterpret_cast<uint4*>(arena.p + o_q0);
+    uint4* d_q1 = reinterpret_cast<uint4*>(arena.p + o_q1);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(arena.p + o_cnt);
+    uint32_t* d_nfin = d_cnt + 3 + kLbvhMaxDepth + 3;
+    float* d_out = reinterpret_cast<float*>(arena.p + o_out);
+    uint32_t n_fin = 0;
+    hipError_t e = hipMemsetAsync(d_nfin, 0, 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_kd_scene_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, dc.cloud.p, dc.order.p, n, d_pts,
+                           d_nfin);
+        e = hipMemcpyAsync(&n_fin, d_nfin, 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n_fin >= 2) {
+        lbvh_build(c, dc.keys.p, d_pts, n_fin, d_lo, d_hi, d_q0, d_q1, d_cnt);
+        hipLaunchKernelGGL((k_knn2<kLbvhStack, true>), dim3((n_fin + 255) / 256), dim3(256), 0, c->stream, d_lo, d_hi, d_pts,
+                           d_pts, n_fin, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("tm_cloud_resolution: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    *n_fin_out = n_fin;
     return TM_OK;
 }
 
@@ -1575,9 +1937,11 @@ int tm_model_build_voxels(tm_model* m) {
     } else {
         uint64_t kd_blocks = (m->voxel_slots + 255) / 256;
         TM_REQUIRE(kd_blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
-        hipLaunchKernelGGL(k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_lo.p, m->kd_hi.p,
-                           m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1],
-                           m->voxels.p, m->brick_min_bits.p);
+        /* a brick's 64 voxels as one packet (default), or every voxel on its own stack (voxel_packet = 0: the
+         * cross-check; identical tables) */
+        hipLaunchKernelGGL(c->opt.voxel_packet ? k_voxel_nn_packet : k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0,
+                           c->stream, m->kd_lo.p, m->kd_hi.p, m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots,
+                           m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);
     }
     TM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_brick_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream,

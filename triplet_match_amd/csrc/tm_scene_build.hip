@@ -392,6 +392,55 @@ int scene_upload(tm_scene* s, const float* surfels) {
     return TM_OK;
 }
 
+/* Curve keys of a raw cloud (48-byte surfels on the device) and the order they put the points in: keys_out[k] =
+ * 63-bit Hilbert (or Morton) key of the k-th point along the curve, ascending; order_out[k] = its original index;
+ * equal keys keep their index order (stable radix sort), non-finite points come last (key ~0). *bnd receives the
+ * bounding box of the finite points, the largest |coordinate| and a zeroed live counter. Used for scenes and, since
+ * round 4, for models (tm_model_create). Queued on the context's stream; synchronises once, after the sort. */
+int curve_order(tm_ctx* c, const float* d_cloud, uint32_t n, bool hilbert, void* d_bounds,
+                dbuf<unsigned long long>& keys_out, dbuf<uint32_t>& order_out) {
+    scene_bounds* bnd = reinterpret_cast<scene_bounds*>(d_bounds);
+    const dim3 blk(256), grid_n((n + 255) / 256);
+    scene_bounds init;
+    for (int d = 0; d < 3; ++d) {
+        init.lo[d] = ~0u;
+        init.hi[d] = 0u;
+    }
+    init.cmax = 0u;
+    init.live = 0u;
+    TM_HIP_CHECK(hipMemcpyAsync(bnd, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scene_bounds, dim3(std::min<uint32_t>(512u, (n + 255) / 256)), blk, 0, c->stream, d_cloud, n, bnd);
+    dbuf<unsigned long long> k_in;
+    dbuf<uint32_t> v_in;
+    auto cleanup = [&]() {
+        k_in.release();
+        v_in.release();
+    };
+    int rc;
+    if ((rc = k_in.alloc(n)) || (rc = keys_out.ensure(n)) || (rc = v_in.alloc(n)) || (rc = order_out.ensure(n))) {
+        cleanup();
+        return rc;
+    }
+    hipLaunchKernelGGL(k_scene_morton, grid_n, blk, 0, c->stream, d_cloud, n, bnd, hilbert ? 1 : 0, k_in.p, v_in.p);
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, k_in.p, keys_out.p, v_in.p, order_out.p, (size_t)n, 0, 64,
+                                             c->stream);
+    if (e == hipSuccess && (rc = scratch_ensure(c, tmp))) {
+        cleanup();
+        return rc;
+    }
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(c->scratch.p, tmp, k_in.p, keys_out.p, v_in.p, order_out.p, (size_t)n, 0, 64,
+                                      c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error("curve_order: sort failed: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    return TM_OK;
+}
+
 /* (re)derives every device array of the scene from d_cloud / d_tmask / d_mask. `resort` = the cloud
  * changed (new scene); false = only mask_ changed. */
 int scene_build(tm_scene* s, bool resort) {
@@ -416,46 +465,7 @@ int scene_build(tm_scene* s, bool resort) {
     hipLaunchKernelGGL(k_scene_original, grid_n, blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p, s->d_mask.p, n,
                        s->opos.p, s->otan.p, s->oref.p);
     if (resort) {
-        scene_bounds init;
-        for (int d = 0; d < 3; ++d) {
-            init.lo[d] = ~0u;
-            init.hi[d] = 0u;
-        }
-        init.cmax = 0u;
-        init.live = 0u;
-        TM_HIP_CHECK(hipMemcpyAsync(bnd, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_scene_bounds, dim3(std::min<uint32_t>(512u, (n + 255) / 256)), blk, 0, c->stream,
-                           s->d_cloud.p, n, bnd);
-        dbuf<unsigned long long> k_in;
-        dbuf<unsigned long long>& k_out = s->d_keys; /* kept: the sorted keys are the skeleton of a tree over the points */
-        dbuf<uint32_t> v_in;
-        auto cleanup = [&]() {
-            k_in.release();
-            v_in.release();
-        };
-        int rc;
-        if ((rc = k_in.alloc(n)) || (rc = k_out.ensure(n)) || (rc = v_in.alloc(n))) {
-            cleanup();
-            return rc;
-        }
-        hipLaunchKernelGGL(k_scene_morton, grid_n, blk, 0, c->stream, s->d_cloud.p, n, bnd,
-                           c->opt.scene_morton ? 0 : 1, k_in.p, v_in.p);
-        size_t tmp = 0;
-        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, k_in.p, k_out.p, v_in.p, s->d_order.p, (size_t)n, 0,
-                                                 64, c->stream);
-        if (e == hipSuccess && (rc = scratch_ensure(c, tmp))) {
-            cleanup();
-            return rc;
-        }
-        if (e == hipSuccess)
-            e = rocprim::radix_sort_pairs(c->scratch.p, tmp, k_in.p, k_out.p, v_in.p, s->d_order.p, (size_t)n, 0,
-                                          64, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        cleanup();
-        if (e != hipSuccess) {
-            set_error("scene_build: Morton sort failed: %s", hipGetErrorString(e));
-            return TM_ERR_HIP;
-        }
+        TM_FORWARD(curve_order(c, s->d_cloud.p, n, !c->opt.scene_morton, bnd, s->d_keys, s->d_order));
     } else {
         TM_HIP_CHECK(hipMemsetAsync(&bnd->live, 0, 4, c->stream));
     }
