@@ -358,7 +358,8 @@ __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __rest
                                                             uint32_t n /* finite points = entries of pts */,
                                                             uint32_t k, float* __restrict__ curv5 /* zeroed */,
                                                             const float4* __restrict__ queries = nullptr,
-                                                            uint32_t n_queries = 0) {
+                                                            uint32_t n_queries = 0,
+                                                            const uint32_t* __restrict__ row_of = nullptr) {
     __shared__ uint32_t st_node[STACK][kCurvThreads];
     /* a deep stack (the device-built tree, kLbvhStack) keeps the node only — with the bounds it would not fit the 64 KB
      * of static LDS next to the neighbour lists — and takes the box distance again when it pops */
@@ -376,7 +377,9 @@ __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __rest
     const float4 Q = queries ? queries[t] : pts[t];
     if (!(Q.x == Q.x)) return; /* a non-finite query point keeps its zero row */
     const uint32_t self = __float_as_uint(Q.w);
-    float* out = curv5 + (size_t)(queries ? t : self) * 5;
+    /* row_of: the queries were put in the tree's order (so that a wave walks neighbouring paths whatever order the
+     * caller listed them in); row_of[t] = the row the caller expects query t in */
+    float* out = curv5 + (size_t)(queries ? (row_of ? row_of[t] : t) : self) * 5;
     float q[3] = {Q.x, Q.y, Q.z};
     uint32_t have = 0;
     int sp = 1;
@@ -1513,6 +1516,32 @@ __global__ __launch_bounds__(256) void k_kd_scene_queries(const float* __restric
     q[t] = fin ? make_float4(a.x, a.y, a.z, __uint_as_float(i)) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
 }
 
+/* slot_of[original index] = position in the curve order */
+__global__ __launch_bounds__(256) void k_slot_of(const uint32_t* __restrict__ order, uint32_t n, uint32_t* __restrict__ slot_of) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) slot_of[order[k]] = k;
+}
+/* sort keys of a query list: the curve position of every listed point, value = its place in the list */
+__global__ __launch_bounds__(256) void k_query_keys(const uint32_t* __restrict__ idx, uint32_t n_idx,
+                                                    const uint32_t* __restrict__ slot_of, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_idx) return;
+    keys[t] = slot_of[idx[t]];
+    vals[t] = t;
+}
+/* queries in curve order: q[t] = point idx[row_of[t]] */
+__global__ __launch_bounds__(256) void k_kd_scene_queries_sorted(const float* __restrict__ cloud, const uint32_t* __restrict__ indices,
+                                                                 const uint32_t* __restrict__ row_of, uint32_t n_idx,
+                                                                 float4* __restrict__ q) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_idx) return;
+    const uint32_t i = indices[row_of[t]];
+    const float4 a = reinterpret_cast<const float4*>(cloud)[(size_t)i * 3];
+    const bool fin = isfinite(a.x) && isfinite(a.y) && isfinite(a.z);
+    q[t] = fin ? make_float4(a.x, a.y, a.z, __uint_as_float(i)) : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+}
+
 /* the work arrays of one curvature call on a scene's device copy; d_out = n_idx rows of 5 floats, valid until the
  * arena is released */
 struct scene_curv_work {
@@ -1554,6 +1583,19 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
                  o_idx = take(((size_t)n_idx + 1) * 4), o_out = take((size_t)n_idx * 20), o_lo = take(2 * (size_t)n * 16),
                  o_hi = take(2 * (size_t)n * 16), o_q0 = take((size_t)n * 16), o_q1 = take((size_t)n * 16),
                  o_cnt = take((3 + kLbvhMaxDepth + 3) * 4);
+    /* subset mode: the queries are walked in the tree's order (a caller's list — ascending original index — is in no
+     * spatial order when the cloud is not: every lane of a wave would go its own way) */
+    const bool reorder = !all && n_idx >= 256u;
+    const size_t o_slot = reorder ? take((size_t)n * 4) : 0, o_qk = reorder ? take((size_t)n_idx * 4) : 0,
+                 o_qv = reorder ? take((size_t)n_idx * 4) : 0, o_qk2 = reorder ? take((size_t)n_idx * 4) : 0,
+                 o_row = reorder ? take((size_t)n_idx * 4) : 0;
+    size_t sort_tmp = 0;
+    if (reorder) {
+        if (rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                      (uint32_t*)nullptr, (size_t)n_idx, 0, 32, c->stream) != hipSuccess)
+            sort_tmp = 0;
+        TM_FORWARD(scratch_ensure(c, sort_tmp));
+    }
     dbuf<unsigned char>& arena = w.arena;
     int rc;
     if ((rc = arena.alloc(off))) return rc;
@@ -1574,10 +1616,24 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
         hipLaunchKernelGGL(k_kd_scene_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_order, n,
                            d_pts.p, d_idx.p + n_idx);
         hipLaunchKernelGGL(k_kd_scene_normals, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, n, d_nrm.p);
-        if (!all)
+        if (reorder) {
+            uint32_t* d_slot = reinterpret_cast<uint32_t*>(arena.p + o_slot);
+            uint32_t* d_qk = reinterpret_cast<uint32_t*>(arena.p + o_qk);
+            uint32_t* d_qv = reinterpret_cast<uint32_t*>(arena.p + o_qv);
+            uint32_t* d_qk2 = reinterpret_cast<uint32_t*>(arena.p + o_qk2);
+            uint32_t* d_row = reinterpret_cast<uint32_t*>(arena.p + o_row);
+            hipLaunchKernelGGL(k_slot_of, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_order, n, d_slot);
+            hipLaunchKernelGGL(k_query_keys, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, d_idx.p, n_idx, d_slot, d_qk,
+                               d_qv);
+            e = rocprim::radix_sort_pairs(c->scratch.p, sort_tmp, d_qk, d_qk2, d_qv, d_row, (size_t)n_idx, 0, 32, c->stream);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(k_kd_scene_queries_sorted, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, d_cloud,
+                                   d_idx.p, d_row, n_idx, d_q.p);
+        } else if (!all) {
             hipLaunchKernelGGL(k_kd_scene_queries, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_idx.p, n_idx,
                                d_q.p);
-        e = hipMemcpyAsync(&n_fin, d_idx.p + n_idx, 4, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_fin, d_idx.p + n_idx, 4, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     lap("alloc + points, normals, queries");
@@ -1588,7 +1644,7 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
         const uint32_t n_threads = all ? n_fin : n_idx;
         hipLaunchKernelGGL(k_curvature<kLbvhStack>, dim3((n_threads + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0,
                            c->stream, d_lo.p, d_hi.p, d_pts.p, d_nrm.p, n_fin, kk, d_out.p, all ? (const float4*)nullptr : d_q.p,
-                           n_idx);
+                           n_idx, reorder ? reinterpret_cast<const uint32_t*>(arena.p + o_row) : (const uint32_t*)nullptr);
         e = hipGetLastError();
         lap("kernel");
     }
