@@ -583,7 +583,8 @@ __global__ void k_metric_codes(const uint32_t* __restrict__ bits, int per_column
  * a7 — pair enumeration. Ordered pairs (a,b) of subset positions, a-major (reference :100).
  * Thread = one `a`; the b side streams through LDS in chunks.
  * ---------------------------------------------------------------------------------------------- */
-constexpr int kPairChunk = 1024;
+constexpr int kPairRecBuf = 512; /* records a wave stages in LDS before it appends them (4 KB per wave) */
+constexpr int kPairChunk = 256; /* second points staged per workgroup: n_t = 4k gives 16 x 16 workgroups (64 with 1024) */
 
 struct pair_params {
     float lower, upper;      /* diameter * {min,max}_diameter_factor (unsquared, reference :101-102) */
@@ -655,35 +656,68 @@ __global__ __launch_bounds__(256) void k_pairs(const float4* __restrict__ pos,
     float mn[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
     float mx[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
     uint32_t nvalid = 0;
+    /* EMIT: the records of a wave are staged in LDS and go out kPairRecBuf - 64 or more at a time behind ONE returning
+     * atomic on the record counter (1.4e7 records: one atomic each was 2 of this pass's 3 ms, one per wave and turn
+     * still 2.6e5 same-address atomics); their order does not matter, the sort follows */
+    __shared__ unsigned long long s_rec[EMIT ? 4 : 1][EMIT ? kPairRecBuf : 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t fill = 0; /* uniform over the live lanes of the wave */
+    auto flush = [&]() {
+        if (!EMIT || fill == 0u) return;
+        const unsigned long long act = __ballot(1);
+        const int leader = __ffsll((long long)act) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)fill);
+        base = __shfl(base, leader);
+        /* the wave's LIVE lanes share the copy (the last wave of the subset is partly idle: striding by 64 would leave
+         * the idle lanes' share unwritten) */
+        const uint32_t n_act = (uint32_t)__popcll(act), my = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+        for (uint32_t r = my; r < fill; r += n_act)
+            if (base + r < cap) sort_keys[base + r] = s_rec[wave][r];
+        fill = 0u;
+    };
     if (live) {
         for (int s = 0; s < cnt; ++s) {
             float4 P = sp[s];
             uint32_t ib = __float_as_uint(P.w);
-            if (ib == ia) continue; /* reference :104 compares the point indices */
             f3 pj = make3(P.x, P.y, P.z);
-            if (!pair_filter(pi, ti, pj, pp.lower, pp.upper)) continue;
-            float4 T = st[s];
-            feat4 f = pair_feature(pi, ti, pj, make3(T.x, T.y, T.z));
+            /* reference :104 compares the point indices */
+            const bool ok = ib != ia && pair_filter(pi, ti, pj, pp.lower, pp.upper);
+            feat4 f = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                float4 T = st[s];
+                f = pair_feature(pi, ti, pj, make3(T.x, T.y, T.z));
+            }
             if (!EMIT) {
-                mn[0] = fminf(mn[0], f.f0);
-                mx[0] = fmaxf(mx[0], f.f0);
-                mn[1] = fminf(mn[1], f.f1);
-                mx[1] = fmaxf(mx[1], f.f1);
-                mn[2] = fminf(mn[2], f.f2);
-                mx[2] = fmaxf(mx[2], f.f2);
-                mn[3] = fminf(mn[3], f.f3);
-                mx[3] = fmaxf(mx[3], f.f3);
-                ++nvalid;
+                if (ok) {
+                    mn[0] = fminf(mn[0], f.f0);
+                    mx[0] = fmaxf(mx[0], f.f0);
+                    mn[1] = fminf(mn[1], f.f1);
+                    mx[1] = fmaxf(mx[1], f.f1);
+                    mn[2] = fminf(mn[2], f.f2);
+                    mx[2] = fmaxf(mx[2], f.f2);
+                    mn[3] = fminf(mn[3], f.f3);
+                    mx[3] = fmaxf(mx[3], f.f3);
+                    ++nvalid;
+                }
             } else {
-                if (!feature_valid(f, pp.lo0, pp.hi0)) continue;
-                key4 k = feature_key(f, pp.lo0, pp.hi0, pp.steps, pp.angle_step);
-                uint32_t packed = (k.k0 * pp.r1 + k.k1) * pp.r2 + k.k2;
-                uint32_t rank = a * pp.n_t + (b0 + (uint32_t)s);
-                unsigned long long slot = atomicAdd(counter, 1ull);
-                if (slot < cap)
-                    sort_keys[slot] = ((unsigned long long)packed << 32) | (0xFFFFFFFFu - rank);
+                const bool emit = ok && feature_valid(f, pp.lo0, pp.hi0);
+                unsigned long long rec = 0ull;
+                if (emit) {
+                    key4 k = feature_key(f, pp.lo0, pp.hi0, pp.steps, pp.angle_step);
+                    uint32_t packed = (k.k0 * pp.r1 + k.k1) * pp.r2 + k.k2;
+                    uint32_t rank = a * pp.n_t + (b0 + (uint32_t)s);
+                    rec = ((unsigned long long)packed << 32) | (0xFFFFFFFFu - rank);
+                }
+                const unsigned long long em = __ballot(emit); /* every live lane of the wave is here: same trip count */
+                if (em) {
+                    if (emit) s_rec[wave][fill + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = rec;
+                    fill += (uint32_t)__popcll(em);
+                    if (fill > (uint32_t)kPairRecBuf - 64u) flush();
+                }
             }
         }
+        flush();
     }
     if (!EMIT) {
         /* wave reduce, then one atomic per wave and bound */
