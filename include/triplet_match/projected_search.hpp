@@ -63,10 +63,14 @@ public:
      * Points whose project() is nullopt are dropped; original_index() maps back. */
     projected_model(typename cloud_t::ConstPtr cloud, const_handle_t handle, discretization_params params,
                     int device = 0)
+        : projected_model(cloud, handle, params, detail::default_context(device)) {}
+    /* on a context of the caller's (make_context): the scene it is searched in lives on the same one */
+    projected_model(typename cloud_t::ConstPtr cloud, const_handle_t handle, discretization_params params,
+                    context_t ctx)
         : cloud_(cloud), handle_(handle) {
         static_assert(sizeof(Point) == 48, "Point must be the 48-byte surfel layout");
+        if (!ctx) throw std::invalid_argument("projected_model: null context");
         if (!cloud_ || cloud_->size() == 0 || !handle_) throw std::runtime_error("projected_model: empty cloud or projector");
-        auto ctx = detail::default_context(device);
         const uint32_t n = (uint32_t)cloud_->size();
         float st[TM_STATE_FLOATS] = {0};
         handle_->pack(st);
@@ -84,7 +88,7 @@ public:
             kept_.push_back(i);
         }
         if (uvw_cloud_->size() < 2) throw std::runtime_error("projected_model: the projector rejects the model cloud");
-        model_.reset(new model<Point>(uvw_cloud_, params, device));
+        model_.reset(new model<Point>(uvw_cloud_, params, ctx));
         model_->disable_curvature_filter(); /* the tangents were mapped into uvw space: |tangent| > 0.7 only */
         detail::check(tm_model_set_metric(model_->handle(), Traits::kind, handle_->radius), "tm_model_set_metric");
     }

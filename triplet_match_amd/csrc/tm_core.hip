@@ -50,9 +50,9 @@ extern "C" {
 
 const char* tm_last_error(void) { return g_error.c_str(); }
 #ifdef TM_TIMING_EXPERIMENTS
-const char* tm_version(void) { return "triplet_match_amd 0.3 (gfx950) +timing-experiments: NOT a product build"; }
+const char* tm_version(void) { return "triplet_match_amd 0.4 (gfx950) +timing-experiments: NOT a product build"; }
 #else
-const char* tm_version(void) { return "triplet_match_amd 0.3 (gfx950)"; }
+const char* tm_version(void) { return "triplet_match_amd 0.4 (gfx950)"; }
 #endif
 
 }  // extern "C"
