@@ -1,7 +1,7 @@
 /* e2e_demo.cpp — times the drop-in scene<Point>::find_all_parallel on a fixture written by
  * tests/test_cpp_dropin.py::_fixture (model, scene, resolution, ground-truth poses).
  * usage: e2e_demo <fixture.bin> [early_drop 0|1] [max_icp_iterations] [repeats of the search on the kept scene]
- *        [new scene objects over the same cloud] [new clouds] [stream: up to this many host threads] */
+ *        [new scene objects over the same cloud] [new clouds] [stream: up to this many host threads] [starting at] */
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -127,7 +127,9 @@ int main(int argc, char** argv) {
             models.emplace_back(new model<P>(mcloud, dp, ctxs.back()));
             models.back()->init(sp);
         }
-        for (int T = 1; T <= max_threads; ++T) {
+        const int first_threads = argc > 8 ? std::max(1, atoi(argv[8])) : 1;
+        for (int T = first_threads; T <= max_threads; ++T) {
+            usleep(300000); /* a gap the kernel trace can be cut at (tools/trace_summary.py --segments) */
             std::atomic<int> next{0}, found{0};
             auto t7 = std::chrono::steady_clock::now();
             std::vector<std::thread> pool;

@@ -41,4 +41,16 @@ if "--segments" in sys.argv:
     for k, sg in enumerate(segs):
         b = sum(e - s for s, e, _ in sg)
         sp = sg[-1][1] - sg[0][0]
-        print("segment %d: span %.1f ms, busy %.1f ms (%.2f of the span), %d dispatches" % (k, sp / 1e6, b / 1e6, b / max(sp, 1), len(sg)))
+        # kernels of several streams overlap: the time at least one kernel runs (union of the intervals)
+        u, cur_s, cur_e = 0, None, None
+        for s_, e_, _ in sorted(sg):
+            if cur_e is None or s_ > cur_e:
+                if cur_e is not None:
+                    u += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        if cur_e is not None:
+            u += cur_e - cur_s
+        print("segment %d: span %.1f ms, busy %.1f ms (%.2f of the span), at least one kernel running %.1f ms (%.2f), %d dispatches"
+              % (k, sp / 1e6, b / 1e6, b / max(sp, 1), u / 1e6, u / max(sp, 1), len(sg)))
