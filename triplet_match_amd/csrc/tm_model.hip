@@ -1374,6 +1374,11 @@ __global__ void k_lbvh_mark(uint32_t* __restrict__ counters, uint32_t consumed, 
     *level_end = counters[0];
     counters[1 + consumed] = 0u;
 }
+/* level_start[from + 1 .. to] = level_start[from] (the levels a shortened build never reached are empty) */
+__global__ void k_lbvh_fill_starts(uint32_t* __restrict__ level_start, uint32_t from, uint32_t to) {
+    const uint32_t v = level_start[from];
+    for (uint32_t d = from + 1u + threadIdx.x; d <= to; d += blockDim.x) level_start[d] = v;
+}
 __global__ __launch_bounds__(256) void k_lbvh_boxes(const float4* __restrict__ pts, const uint32_t* __restrict__ level_start,
                                                     float4* __restrict__ lo, float4* __restrict__ hi) {
     const uint32_t n0 = level_start[0], n1 = level_start[1];
@@ -1404,13 +1409,36 @@ static void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4
     uint32_t* level_start = d_cnt + 3;
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(1), 0, c->stream, n_fin, d_q0, d_cnt, level_start);
     const uint32_t grid = std::min<uint32_t>(1024u, (n_fin + 255u) / 256u);
-    for (uint32_t d = 0; d <= (uint32_t)kLbvhMaxDepth; ++d) { /* level d's nodes -> level d + 1's */
-        const uint32_t in = d & 1u;
-        hipLaunchKernelGGL(k_lbvh_level, dim3(grid), dim3(256), 0, c->stream, d_keys, in ? d_q1 : d_q0, d_cnt + 1 + in,
-                           in ? d_q0 : d_q1, d_cnt + 1 + (in ^ 1u), d_cnt, d_lo, d_hi);
-        hipLaunchKernelGGL(k_lbvh_mark, dim3(1), dim3(1), 0, c->stream, d_cnt, in, level_start + d + 2);
+    /* The tree of a million points is 27-30 levels deep, the cap is 46: the levels are queued in blocks, and after a
+     * block the next queue's length comes back (8 bytes, one wait) — an empty queue ends the build instead of ~50 more
+     * launches that find nothing to do (3 launches per level, ~5 us each on the host side). The first block covers what
+     * a balanced tree of this size needs plus a margin. */
+    uint32_t depth = 0; /* levels queued so far */
+    uint32_t block = 4u;
+    for (uint32_t m = n_fin / 8u; m > 0u; m >>= 1) ++block; /* log2(n / 8) + 4 */
+    bool done = false;
+    while (!done && depth <= (uint32_t)kLbvhMaxDepth) {
+        const uint32_t upto = std::min<uint32_t>(depth + block, (uint32_t)kLbvhMaxDepth + 1u);
+        for (uint32_t d = depth; d < upto; ++d) { /* level d's nodes -> level d + 1's */
+            const uint32_t in = d & 1u;
+            hipLaunchKernelGGL(k_lbvh_level, dim3(grid), dim3(256), 0, c->stream, d_keys, in ? d_q1 : d_q0, d_cnt + 1 + in,
+                               in ? d_q0 : d_q1, d_cnt + 1 + (in ^ 1u), d_cnt, d_lo, d_hi);
+            hipLaunchKernelGGL(k_lbvh_mark, dim3(1), dim3(1), 0, c->stream, d_cnt, in, level_start + d + 2);
+        }
+        depth = upto;
+        if (depth > (uint32_t)kLbvhMaxDepth) break;
+        uint32_t next_len = 1u; /* the queue level `depth` will read */
+        if (hipMemcpyAsync(&next_len, d_cnt + 1 + (depth & 1u), 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            next_len = 1u; /* could not look: keep going to the cap, as before */
+        done = next_len == 0u;
+        block = 6u;
     }
-    for (uint32_t d = (uint32_t)kLbvhMaxDepth + 2u; d-- > 0;) /* nodes of level d: [level_start[d], level_start[d + 1]) */
+    /* levels beyond `depth` were never numbered: their starts equal the last one (empty ranges for the box passes) */
+    if (depth <= (uint32_t)kLbvhMaxDepth)
+        hipLaunchKernelGGL(k_lbvh_fill_starts, dim3(1), dim3(64), 0, c->stream, level_start, depth + 1u,
+                           (uint32_t)kLbvhMaxDepth + 2u);
+    for (uint32_t d = std::min<uint32_t>(depth + 1u, (uint32_t)kLbvhMaxDepth + 2u); d-- > 0;) /* nodes of level d: [level_start[d], level_start[d + 1]) */
         hipLaunchKernelGGL(k_lbvh_boxes, dim3(grid), dim3(256), 0, c->stream, d_pts, level_start + d, d_lo, d_hi);
 }
 
