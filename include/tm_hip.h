@@ -252,6 +252,11 @@ int tm_model_voxel_query(const tm_model* model, const float pos4[4], uint32_t* i
  * tm_scene_tangent_points) fetch a host mirror from there on first use. */
 int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t* tangent_mask,
                     tm_scene** scene);
+/* The same for a cloud that is already on the context's device (a sensor pipeline's output): d_surfels = n x 12
+ * floats, d_tangent_mask = n x int32 or null; both are copied device to device on the context's stream — the caller's
+ * own work on them must be complete — and nothing crosses PCIe but the 4 n bytes of the mask for the host helpers. */
+int tm_scene_create_dev(tm_ctx* ctx, const float* d_surfels, uint32_t n, const int32_t* d_tangent_mask,
+                        tm_scene** scene);
 int tm_scene_destroy(tm_scene* scene);
 /* mask_ (include/impl/scene.hpp:41,87-90); NULL clears */
 int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);

@@ -1514,3 +1514,64 @@ def test_concurrent_calls_on_one_context(gpu_small, small_case):
     for t in range(4):
         assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1])
         assert vox[t] == want_vox
+
+
+def test_block_cache_of_a_context(small_case):
+    """The context's cache of released device blocks (tm_ctx_pool_stats, option pool_mib): scenes created and destroyed in
+    a loop are served from the cache after the first round, the cache never exceeds its budget, a smaller budget trims
+    at once, 0 switches it off — and the results do not depend on any of it."""
+    S, tmk = small_case["scene"]["surfels"], small_case["scene"]["tangent_mask"]
+    ctx = capi.Context(0)
+    gm = capi.Model(ctx, small_case["model"], small_case["resolution"])
+    gm.build_voxels()
+    poses = random_poses_near_truth(small_case, 40, seed=77)
+
+    def one_round():
+        s = capi.Scene(ctx, S, tmk)
+        out = s.score_hypotheses(gm, poses, DT)
+        s.close()
+        return out
+    want = one_round()
+    cached0, reused0, alloc0 = ctx.pool_stats()
+    assert cached0 > 0 and ctx.get_option("pool_mib") == 1024
+    for _ in range(3):
+        got = one_round()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    cached1, reused1, alloc1 = ctx.pool_stats()
+    assert reused1 - reused0 >= 3 * 10       # a scene is some forty blocks; they come out of the cache ...
+    assert alloc1 - alloc0 <= 2              # ... not from hipMalloc
+    assert cached1 <= 1024 << 20
+    ctx.set_option("pool_mib", 1)            # a smaller budget takes effect at once
+    assert ctx.pool_stats()[0] <= 1 << 20
+    ctx.set_option("pool_mib", 0)            # off: nothing is kept, every block goes back to the device
+    got = one_round()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert ctx.pool_stats()[0] == 0
+    gm.close()
+
+
+def test_scene_from_device_buffers(gpu_ctx, gpu_small, small_case):
+    """tm_scene_create_dev: a cloud (and tangent_mask_) already on the device make the same scene as the host call —
+    scores, generated hypotheses, the host mirror and the device-built tangent mask."""
+    S, tmk = small_case["scene"]["surfels"], small_case["scene"]["tangent_mask"]
+    gm, ref = gpu_small["model"], gpu_small["scene"]
+    d_s, d_t = gpu_ctx.alloc(S.nbytes), gpu_ctx.alloc(tmk.nbytes)
+    gpu_ctx.h2d(d_s, S)
+    gpu_ctx.h2d(d_t, np.ascontiguousarray(tmk, np.int32))
+    gpu_ctx.synchronize()
+    dev = capi.Scene.from_device(gpu_ctx, d_s, len(S), d_t)
+    poses = random_poses_near_truth(small_case, 30, seed=9)
+    a, b = dev.score_hypotheses(gm, poses, DT), ref.score_hypotheses(gm, poses, DT)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[0].max() > 100
+    cloud, mask = dev.download()
+    assert np.array_equal(cloud.view(np.uint32), S.view(np.uint32)) and np.array_equal(mask, tmk)
+    ta, tb = dev.tangent_points(), ref.tangent_points()
+    assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1].view(np.uint32), tb[1].view(np.uint32))
+    # without a mask: none yet; the device-side tangent_mask_ follows
+    bare = capi.Scene.from_device(gpu_ctx, d_s, len(S))
+    twin = capi.Scene(gpu_ctx, S, np.zeros(len(S), np.int32))
+    m1, c1, r1 = bare.auto_tangent_mask(30)
+    m2, c2, r2 = twin.auto_tangent_mask(30)
+    assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    gpu_ctx.free(d_s)
+    gpu_ctx.free(d_t)

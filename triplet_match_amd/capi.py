@@ -102,6 +102,7 @@ SIGNATURES = {
     "tm_model_query_key": (C.c_int, [vp, u32p, u32p, C.c_uint32, u32p]),
     "tm_model_voxel_query": (C.c_int, [vp, f32p, u32p, C.POINTER(C.c_int)]),
     "tm_scene_create": (C.c_int, [vp, f32p, C.c_uint32, i32p, C.POINTER(vp)]),
+    "tm_scene_create_dev": (C.c_int, [vp, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(vp)]),
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
@@ -731,6 +732,16 @@ class Scene:
         h = vp()
         _check(lib().tm_scene_create(ctx.h, p, self.n, ptm, C.byref(h)))
         self.h = h
+
+    @classmethod
+    def from_device(cls, ctx, d_surfels, n, d_tangent_mask=None):
+        """tm_scene_create_dev: the cloud (and optionally tangent_mask_) are device buffers of ctx (ctx.alloc)"""
+        self = cls.__new__(cls)
+        self.ctx, self.n = ctx, int(n)
+        h = vp()
+        _check(lib().tm_scene_create_dev(ctx.h, d_surfels, self.n, d_tangent_mask, C.byref(h)))
+        self.h = h
+        return self
 
     def close(self):
         if getattr(self, "h", None):

@@ -1794,6 +1794,37 @@ int tm_scene_create(tm_ctx* ctx, const float* surfels, uint32_t n, const int32_t
     return TM_OK;
 }
 
+int tm_scene_create_dev(tm_ctx* ctx, const float* d_surfels, uint32_t n, const int32_t* d_tangent_mask, tm_scene** out) {
+    TM_GUARD(ctx);
+    TM_REQUIRE(ctx && d_surfels && out, TM_ERR_INVALID, "tm_scene_create_dev: null argument");
+    TM_REQUIRE(n > 0, TM_ERR_INVALID, "tm_scene_create_dev: empty cloud");
+    TM_HIP_CHECK(hipSetDevice(ctx->device));
+    tm_scene* s = new tm_scene();
+    s->ctx = ctx;
+    s->n = n;
+    s->h_tmask.assign(n, 0);
+    s->h_mask.assign(n, 0);
+    int rc = scene_upload(s, nullptr); /* allocates d_cloud / d_tmask / d_mask and uploads the (zero) masks */
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(s->d_cloud.p, d_surfels, (size_t)n * 48, hipMemcpyDeviceToDevice, ctx->stream);
+    if (!rc && e == hipSuccess && d_tangent_mask) {
+        e = hipMemcpyAsync(s->d_tmask.p, d_tangent_mask, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) /* the host-side helpers read tangent_mask_ from their mirror */
+            e = hipMemcpyAsync(s->h_tmask.data(), d_tangent_mask, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (!rc && e != hipSuccess) {
+        set_error("tm_scene_create_dev: %s", hipGetErrorString(e));
+        rc = TM_ERR_HIP;
+    }
+    if (!rc) rc = scene_build(s, true);
+    if (rc) {
+        tm_scene_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return TM_OK;
+}
+
 int tm_scene_destroy(tm_scene* s) {
     if (!s) return TM_OK;
     if (!ctx_alive(s->ctx)) { /* context already gone: the device memory went with it */
