@@ -1002,22 +1002,55 @@ __global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uin
     if (t < n) out[t] = ((double)fx[t] * inv_scale) / model_size; /* reference :509 */
 }
 
-/* finish_find for one pose: per original index the matched model index or 0xFFFFFFFF */
-__global__ __launch_bounds__(256) void k_extract(score_args a, uint32_t n_pad,
-                                                 uint32_t* __restrict__ match_of_orig) {
+/* finish_find for several poses side by side (blockIdx.y = pose k): per original index the matched model index or
+ * 0xFFFFFFFF, the matches of pose k in match_of_orig + k * n,
+ * count and fixed-point score sum in count_fx[2 k] / [2 k + 1] */
+__global__ __launch_bounds__(256) void k_extract_batch(score_args a, uint32_t n_pad, uint32_t n,
+                                                       uint32_t* __restrict__ match_of_orig,
+                                                       unsigned long long* __restrict__ count_fx) {
     uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_pad) return;
     float4 v = a.spos[s];
     if (!(v.x == v.x)) return;
-    const pose12 T = load_pose(a.poses);
+    const uint32_t k = blockIdx.y;
+    const pose12 T = load_pose(a.poses + 16 * (size_t)k);
     long long fx = 0;
     uint32_t pass = 0, m = 0xFFFFFFFFu;
     uint32_t hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
     if (hit) {
-        match_of_orig[__float_as_uint(v.w)] = m;
-        atomicAdd(&a.scores_fx[0], (unsigned long long)fx);
-        atomicAdd(&a.counts[0], 1u);
+        match_of_orig[(size_t)k * n + __float_as_uint(v.w)] = m;
+        atomicAdd(&count_fx[2 * (size_t)k + 1], (unsigned long long)fx);
+        atomicAdd(&count_fx[2 * (size_t)k], 1ull);
     }
+}
+/* ordered compaction of those matches: ascending scene index = the reference's scan order (finish_find walks 0..n-1,
+ * include/impl/scene.hpp:100-106). Per pose: matches per 64 original indices (row k of wave_count, n_waves + 1 entries each,
+ * the last one zero) */
+__global__ __launch_bounds__(256) void k_extract_count_batch(const uint32_t* __restrict__ match_of_orig, uint32_t n,
+                                                             uint32_t n_waves, uint32_t* __restrict__ wave_count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const bool hit = i < n && match_of_orig[(size_t)k * n + i] != 0xFFFFFFFFu;
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) wave_count[(size_t)k * (n_waves + 1u) + (i >> 6)] = (uint32_t)__popcll(b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wave_count[(size_t)k * (n_waves + 1u) + n_waves] = 0u; /* the row's spare entry */
+}
+/* ... and the ordered lists: wave_offset = exclusive scan over ALL rows of wave_count, so a pose's entries start at
+ * its row's first offset */
+__global__ __launch_bounds__(256) void k_extract_scatter_batch(const uint32_t* __restrict__ match_of_orig, uint32_t n,
+                                                               uint32_t n_waves, const uint32_t* __restrict__ wave_offset,
+                                                               const uint32_t* __restrict__ new2orig,
+                                                               uint32_t* __restrict__ corr /* rows of 2 n: scene, model */) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    const uint32_t mt = i < n ? match_of_orig[(size_t)k * n + i] : 0xFFFFFFFFu;
+    const bool hit = mt != 0xFFFFFFFFu;
+    const unsigned long long b = __ballot(hit);
+    if (!hit) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    const uint32_t* row = wave_offset + (size_t)k * (n_waves + 1u);
+    const uint32_t dst = row[i >> 6] - row[0] + rank;
+    corr[2 * (size_t)n * k + dst] = i;
+    corr[2 * (size_t)n * k + n + dst] = new2orig[mt];
 }
 
 /* finish_find + cross-covariance sums for ICP. Grid-stride over the sorted scene points; the 15
@@ -1143,33 +1176,6 @@ __global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* 
         __syncthreads();
         if (threadIdx.x == 0) icp_step(sums, pose, st, max_iterations, first != 0);
     }
-}
-
-/* ordered compaction of k_extract's per-point matches: ascending scene index = the reference's scan
- * order (finish_find walks 0..n-1, include/impl/scene.hpp:100-106). One wave per 64 original indices. */
-__global__ __launch_bounds__(256) void k_extract_count(const uint32_t* __restrict__ match_of_orig, uint32_t n,
-                                                       uint32_t* __restrict__ wave_count) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool hit = i < n && match_of_orig[i] != 0xFFFFFFFFu;
-    const unsigned long long b = __ballot(hit);
-    if ((threadIdx.x & 63) == 0) wave_count[i >> 6] = (uint32_t)__popcll(b);
-}
-
-__global__ __launch_bounds__(256) void k_extract_scatter(const uint32_t* __restrict__ match_of_orig, uint32_t n,
-                                                         const uint32_t* __restrict__ wave_offset,
-                                                         const uint32_t* __restrict__ new2orig,
-                                                         uint32_t* __restrict__ scene_corrs,
-                                                         uint32_t* __restrict__ model_corrs) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t mt = i < n ? match_of_orig[i] : 0xFFFFFFFFu;
-    const bool hit = mt != 0xFFFFFFFFu;
-    const unsigned long long b = __ballot(hit);
-    if (!hit) return;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t rank = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-    const uint32_t dst = wave_offset[i >> 6] + rank;
-    scene_corrs[dst] = i;
-    model_corrs[dst] = new2orig[mt];
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -2171,17 +2177,19 @@ int tm_score_hypotheses_ball(tm_scene* s, tm_model* m, const float* poses16, uin
     return TM_OK;
 }
 
-/* finish_find for the pose at d_pose, everything left on the device: count -> d_count_fx[0] (as u64), fixed-point
- * score sum -> d_count_fx[1], correspondences (ascending scene index) -> d_scene_corrs / d_model_corrs. Queued on
- * the context's stream; no synchronisation. */
-static int extract_on_device(tm_scene* s, tm_model* m, const float* d_pose, float dist_thres,
-                             unsigned long long* d_count_fx, uint32_t* d_scene_corrs, uint32_t* d_model_corrs) {
+/* finish_find for n poses in ONE set of launches (the poses side by side in the grid's y): per pose k count and score
+ * sum -> d_count_fx[2 k], [2 k + 1]; correspondences (ascending scene index) -> d_corr + 2 * s->n * k (scene indices,
+ * then model indices at + s->n). Ten dispatches per pose became seven per call: a search extracts a dozen poses. */
+static int extract_batch_on_device(tm_scene* s, tm_model* m, const float* d_poses, uint32_t n, float dist_thres,
+                                   unsigned long long* d_count_fx, uint32_t* d_corr) {
     tm_ctx* c = s->ctx;
-    TM_FORWARD(s->w_counts.ensure(1));
-    TM_FORWARD(s->w_u32a.ensure(s->n));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_counts.p, 0, 4, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(d_count_fx, 0, 16, c->stream));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_u32a.p, 0xFF, (size_t)s->n * 4, c->stream));
+    const uint32_t n_blocks = (s->n + 255) / 256, n_waves = n_blocks * 4;
+    const size_t rows = (size_t)n * (n_waves + 1u);
+    TM_FORWARD(s->w_u32a.ensure((size_t)s->n * n));
+    TM_FORWARD(s->w_u32b.ensure(rows + 1));
+    TM_FORWARD(s->w_u32c.ensure(rows + 1));
+    TM_HIP_CHECK(hipMemsetAsync(d_count_fx, 0, (size_t)n * 16, c->stream));
+    TM_HIP_CHECK(hipMemsetAsync(s->w_u32a.p, 0xFF, (size_t)s->n * n * 4, c->stream));
     score_args a;
     a.spos = s->spos.p;
     a.spos3 = s->spos3.p;
@@ -2191,12 +2199,12 @@ static int extract_on_device(tm_scene* s, tm_model* m, const float* d_pose, floa
     a.mref = m->ref.p;
     a.vox = m->voxels.p;
     a.active = nullptr;
-    a.poses = d_pose;
-    a.counts = s->w_counts.p;
-    a.scores_fx = d_count_fx + 1;
+    a.poses = d_poses;
+    a.counts = nullptr;
+    a.scores_fx = nullptr;
     a.g = m->grid;
     a.d2max = sq_threshold(dist_thres * m->resolution);
-    a.n_hyp = 1;
+    a.n_hyp = n;
     a.hyp_per_block = 1;
     a.ablate = 0;
     a.kind = m->metric_kind;
@@ -2208,25 +2216,19 @@ static int extract_on_device(tm_scene* s, tm_model* m, const float* d_pose, floa
     a.bx = m->bdim[0];
     a.by = m->bdim[1];
     a.code_max = 255u;
-    hipLaunchKernelGGL(k_extract, dim3(s->n_sorted / 256), dim3(256), 0, c->stream, a, s->n_sorted,
-                       s->w_u32a.p);
-    TM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_extract_batch, dim3(s->n_sorted / 256, n), dim3(256), 0, c->stream, a, s->n_sorted, s->n, s->w_u32a.p,
+                       d_count_fx);
     /* ordered compaction on the device: only the correspondences travel back */
-    const uint32_t n_blocks = (s->n + 255) / 256, n_waves = n_blocks * 4;
-    TM_FORWARD(s->w_u32b.ensure((size_t)n_waves + 1));
-    TM_FORWARD(s->w_u32c.ensure((size_t)n_waves + 1));
-    TM_HIP_CHECK(hipMemsetAsync(s->w_u32b.p + n_waves, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_extract_count, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32b.p);
+    hipLaunchKernelGGL(k_extract_count_batch, dim3(n_blocks, n), dim3(256), 0, c->stream, s->w_u32a.p, s->n, n_waves,
+                       s->w_u32b.p);
+    TM_HIP_CHECK(hipGetLastError());
     size_t tmp = 0;
-    TM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp, s->w_u32b.p, s->w_u32c.p, 0u, (size_t)n_waves + 1,
-                                         rocprim::plus<uint32_t>(), c->stream));
+    TM_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp, s->w_u32b.p, s->w_u32c.p, 0u, rows, rocprim::plus<uint32_t>(), c->stream));
     TM_FORWARD(scratch_ensure(c, tmp));
-    TM_HIP_CHECK(rocprim::exclusive_scan(c->scratch.p, tmp, s->w_u32b.p, s->w_u32c.p, 0u, (size_t)n_waves + 1,
-                                         rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(k_extract_scatter, dim3(n_blocks), dim3(256), 0, c->stream, s->w_u32a.p, s->n, s->w_u32c.p,
-                       m->new2orig.p, d_scene_corrs, d_model_corrs);
-    /* the count rides with the score sum: one 16-byte read-back per pose */
-    TM_HIP_CHECK(hipMemcpyAsync(d_count_fx, s->w_u32c.p + n_waves, 4, hipMemcpyDeviceToDevice, c->stream));
+    TM_HIP_CHECK(rocprim::exclusive_scan(c->scratch.p, tmp, s->w_u32b.p, s->w_u32c.p, 0u, rows, rocprim::plus<uint32_t>(),
+                                         c->stream));
+    hipLaunchKernelGGL(k_extract_scatter_batch, dim3(n_blocks, n), dim3(256), 0, c->stream, s->w_u32a.p, s->n, n_waves,
+                       s->w_u32c.p, m->new2orig.p, d_corr);
     TM_HIP_CHECK(hipGetLastError());
     return TM_OK;
 }
@@ -2250,9 +2252,7 @@ int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* pose
     TM_FORWARD(s->w_scores_fx.ensure((size_t)n * 2));
     TM_FORWARD(s->w_corr.ensure(2 * (size_t)s->n * n));
     TM_HIP_CHECK(hipMemcpyAsync(s->w_poses.p, poses16, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
-    for (uint32_t k = 0; k < n; ++k)
-        TM_FORWARD(extract_on_device(s, m, s->w_poses.p + (size_t)k * 16, dist_thres, s->w_scores_fx.p + 2 * (size_t)k,
-                                     s->w_corr.p + 2 * (size_t)s->n * k, s->w_corr.p + 2 * (size_t)s->n * k + s->n));
+    TM_FORWARD(extract_batch_on_device(s, m, s->w_poses.p, n, dist_thres, s->w_scores_fx.p, s->w_corr.p));
     std::vector<unsigned long long> h((size_t)n * 2);
     TM_HIP_CHECK(hipMemcpyAsync(h.data(), s->w_scores_fx.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
