@@ -1075,7 +1075,7 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
                 {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1}, {"ed_prefix_list": 0},
                 {"ed_wave_rows": 3, "search_segment": 300}, {"ed_hist": 0}, {"ed_hist": 0, "ed_wave_rows": 0}, {"ed_prefix_group": 0}, {"ed_prefix_group": 0, "ed_hist": 0}, {"ed_ball_list": 0}, {"ed_prefix_group": 5},
-                {"ed_hist": 0, "search_segment": 300}):
+                {"ed_hist": 0, "search_segment": 300}, {"search_step_check": 0}, {"search_step_check": 0, "search_segment": 300}):
         old_env = {k: gs.ctx.get_option(k) for k in env}
         for k, v in env.items():
             gs.ctx.set_option(k, v)
@@ -1109,6 +1109,10 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
                 seq = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
             for got, want_ in zip(many, seq):
                 assert got[:5] == want_[:5] and (got[0] < 0 or np.array_equal(got[5], want_[5]))
+            with gs.ctx.option("search_step_check", 0):  # every step queued, no look at the stop words in between
+                for got, want_ in zip(many, gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient,
+                                                              min_diameter_factor=0.2)):
+                    assert got[:5] == want_[:5] and (got[0] < 0 or np.array_equal(got[5], want_[5]))
             with gs.ctx.option("search_segment", 300):  # several steps per batch, batches of unequal length
                 short = gs.search_batches(gm, pairs, offs, diam, DT, 0.5, early_drop, sufficient, min_diameter_factor=0.2)
                 with gs.ctx.option("ed_wave_rows", 1):  # the continuation one pending hypothesis per batch first

@@ -194,6 +194,7 @@ static const opt_entry kOptions[] = {
     {"ed_unfused", &options::ed_unfused, 0, 1},
     {"search_segment", &options::search_segment, -1, 1 << 24},
     {"search_per_range", &options::search_per_range, 0, 1},
+    {"search_step_check", &options::search_step_check, 0, 1},
     {"ed_wave_rows", &options::ed_wave_rows, 0, 1 << 19},
     {"ed_prefix_list", &options::ed_prefix_list, 0, 1},
     {"score_off32", &options::score_off32, 0, 1},

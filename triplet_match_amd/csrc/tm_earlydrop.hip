@@ -2204,6 +2204,19 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
                 chk.step = k;
                 TM_HIP_CHECK(launch_ed_fused(s, c, (uint32_t)pend_cap, fused_lds, a, cu, o, accept_thresh, d_tests.p, rows_cap,
                                              n_ranges, d_n_steps + k, &chk));
+                /* Every batch that has its sufficient hypothesis makes the kernels of its later steps leave at once —
+                 * but a step is still ten launches. After the first step (the one that usually settles a round with
+                 * matches in it) and after every third one the batches' stop words come back (4 bytes each, one wait):
+                 * when all are set the remaining steps are not queued at all. */
+                if (c->opt.search_step_check && k + 1 < steps && (k == 0 || k % 3 == 0)) {
+                    std::vector<uint32_t> h_found(n_ranges);
+                    TM_HIP_CHECK(hipMemcpyAsync(h_found.data(), d_found, (size_t)n_ranges * 4, hipMemcpyDeviceToHost, c->stream));
+                    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    bool all = true;
+                    for (uint32_t b = 0; b < n_ranges && all; ++b)
+                        all = h_found[b] != 0xFFFFFFFFu || range_starts[b + 1] - range_starts[b] <= (k + 1) * segment;
+                    if (all) break;
+                }
             }
             a.rng_starts = nullptr;
         } else
@@ -2385,10 +2398,14 @@ __global__ void k_batch_slots(const uint4* __restrict__ prov, uint32_t n_hyp, co
  * else scores holds the full-pass scores. */
 __global__ void __launch_bounds__(1024)
 k_first_sufficient(const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ fx,
-                   const double* __restrict__ scores, const int32_t* __restrict__ dropped, uint32_t n_hyp,
-                   float sufficient, double n_model, const float* __restrict__ poses, tm_batch_result* out,
-                   const uint32_t* __restrict__ found = nullptr, uint32_t h0 = 0) {
-    /* the batch is hypotheses [h0, h0 + n_hyp) of the arrays; the record's index counts from h0 */
+                   const double* __restrict__ scores, const int32_t* __restrict__ dropped,
+                   const uint32_t* __restrict__ starts, float sufficient, double n_model, const float* __restrict__ poses,
+                   tm_batch_result* out, const uint32_t* __restrict__ found = nullptr) {
+    /* workgroup b = batch b = hypotheses [starts[b], starts[b + 1]) of the arrays; the record's index counts from the
+     * batch's first hypothesis (one launch for the batches of a round: seven launches per round before) */
+    const uint32_t h0 = starts[blockIdx.x], n_hyp = starts[blockIdx.x + 1] - h0;
+    out += blockIdx.x;
+    if (found) found += blockIdx.x;
     __shared__ uint32_t s_first;
     if (threadIdx.x == 0) s_first = found ? *found : 0xFFFFFFFFu; /* found: the segments have already looked */
     __syncthreads();
@@ -2510,10 +2527,9 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
         const uint32_t segment = s->ctx->opt.search_segment >= 0 ? (uint32_t)s->ctx->opt.search_segment : 2048u;
         TM_FORWARD(ed_ball_core(s, m, s->w_poses.p, n_hyp, uniq.data(), (uint32_t)uniq.size(), radius, dist_thres,
                                 accept_prob, segment, sufficient, d_found, starts.data(), n_batches, d_starts));
-        for (uint32_t b = 0; b < n_batches; ++b)
-            hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
-                               (const double*)nullptr, s->ed_dropped.p, starts[b + 1] - starts[b], sufficient, (double)m->n,
-                               s->w_poses.p, s->sb_result.p + b, (const uint32_t*)(d_found + b), starts[b]);
+        hipLaunchKernelGGL(k_first_sufficient, dim3(n_batches), dim3(1024), 0, c->stream, s->w_counts.p, s->w_scores_fx.p,
+                           (const double*)nullptr, s->ed_dropped.p, (const uint32_t*)d_starts, sufficient, (double)m->n,
+                           s->w_poses.p, s->sb_result.p, (const uint32_t*)d_found);
     } else {
         /* full pass: centre of a hypothesis = first point of its pair */
         TM_FORWARD(s->w_counts.ensure(n_hyp));
@@ -2523,11 +2539,10 @@ extern "C" int tm_search_batches(tm_scene* s, tm_model* m, const uint32_t* ij_pa
         TM_HIP_CHECK(hipGetLastError());
         TM_FORWARD(tm_score_hypotheses_ball_dev(s, m, s->w_poses.p, n_hyp, s->sb_centres.p, radius, dist_thres,
                                                 s->w_counts.p, s->w_scores.p));
-        for (uint32_t b = 0; b < n_batches; ++b)
-            hipLaunchKernelGGL(k_first_sufficient, dim3(1), dim3(1024), 0, c->stream, s->w_counts.p,
-                               (const unsigned long long*)nullptr, s->w_scores.p, (const int32_t*)nullptr,
-                               starts[b + 1] - starts[b], sufficient, (double)m->n, s->w_poses.p, s->sb_result.p + b,
-                               (const uint32_t*)nullptr, starts[b]);
+        hipLaunchKernelGGL(k_first_sufficient, dim3(n_batches), dim3(1024), 0, c->stream, s->w_counts.p,
+                           (const unsigned long long*)nullptr, s->w_scores.p, (const int32_t*)nullptr,
+                           (const uint32_t*)d_starts, sufficient, (double)m->n, s->w_poses.p, s->sb_result.p,
+                           (const uint32_t*)nullptr);
     }
     TM_HIP_CHECK(hipGetLastError());
     TM_HIP_CHECK(hipMemcpyAsync(out, s->sb_result.p, sizeof(*out) * n_batches, hipMemcpyDeviceToHost, c->stream));

@@ -133,6 +133,8 @@ struct options {
     int ed_hist = 1;          /* 0: the wide continuation keeps bit rows in global memory (k_ed_bits_wide / k_ed_walk /
                                  k_ed_score_rows) instead of the interval reductions of k_ed_hist_wide */
     int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
+    int search_step_check = 1; /* 0: every segment step of a merged round is queued; 1: the batches' stop words are read
+                                  back after the first step and every third one, and a settled round queues no more */
     int pool_mib = 1024;      /* released device blocks the context keeps for reuse, in MiB (0: hipFree at once) */
 };
 
