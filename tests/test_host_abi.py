@@ -196,3 +196,27 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in deps
     syms = subprocess.check_output(["nm", "-D", lib]).decode()
     assert "tmo_" not in syms
+
+
+def test_committed_pmc_passes_belong_to_these_kernel_sources():
+    """bench.py quotes roofline.traffic from the newest profiles/rNN/traffic.json whose hash matches the scoring kernels'
+    sources (the marked region of csrc/tm_scene.hip + tm_score.h / tm_math.h / tm_table.h); without a match the line's
+    `frac` is null. This fails when the kernels were edited after the last PMC passes: run tools/profile_round4.sh on a
+    GPU box (stages `pmc folded ed`) and commit the refreshed profiles/ files."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    text = open(os.path.join(root, "triplet_match_amd", "csrc", "tm_scene.hip"), "rb").read()
+    assert text.count(b"/* >>> scoring kernels") == 1 and text.count(b"/* <<< scoring kernels") == 1
+    have = []
+    for rnd in bench._profile_rounds():
+        p = os.path.join(root, "profiles", rnd, "traffic.json")
+        if os.path.exists(p):
+            have.append(json.load(open(p)).get("source_hash"))
+    assert bench.source_hash() in have, "scoring kernels changed since the committed PMC passes"
+    ed = [json.load(open(os.path.join(root, "profiles", rnd, "early_drop_traffic.json"))).get("source_hash")
+          for rnd in bench._profile_rounds() if os.path.exists(os.path.join(root, "profiles", rnd, "early_drop_traffic.json"))]
+    assert bench.ed_source_hash() in ed, "early-drop kernels changed since the committed PMC pass"
