@@ -1306,7 +1306,16 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
         s.set_mask(None)
 
 
-def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case):
+@pytest.fixture(params=[0, 1], ids=["tree_on_device", "tree_on_host"])
+def cloud_tree_route(request, gpu_ctx):
+    """tm_cloud's tree built on the device (curve order + linear BVH, the default) or on the host (median kd-tree)"""
+    old = gpu_ctx.get_option("model_host_build")
+    gpu_ctx.set_option("model_host_build", request.param)
+    yield request.param
+    gpu_ctx.set_option("model_host_build", old)
+
+
+def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case, cloud_tree_route):
     """tm_cloud (the neighbour accessors of pointcloud<Point>, include/pointcloud:38-63): kNN (kd-tree route k <= 32,
     one-pass route k > 32) and radius search against the oracle's exhaustive scan — indices and squared distances
     bit for bit, order (d2, index) — and, independently of both, against scipy's cKDTree (same neighbour SETS up to

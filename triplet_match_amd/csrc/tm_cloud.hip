@@ -32,6 +32,7 @@ struct tm_cloud {
     tmx::dbuf<float4> kd_lo, kd_hi; /* node boxes + links (see kd_node_builder) */
     tmx::dbuf<float4> kd_pts;       /* leaf-ordered (xyz, bits of the cloud index) */
     std::vector<uint32_t> h_idx_of_pos; /* cloud index of the tree's p-th point */
+    bool deep_tree = false;         /* built on the device (linear BVH): the kNN kernel takes its deep-stack form */
     tmx::dbuf<float> w_d2;          /* per tree point: squared distance to the current query */
     tmx::dbuf<uint32_t> w_sel;      /* compacted positions + count */
     tmx::dbuf<float> w_q;           /* query batch */
@@ -106,14 +107,18 @@ __device__ __forceinline__ float cloud_box_d2(const float q[3], float4 lo, float
 /* k nearest tree points of every query, list sorted by (d2, cloud index). A subtree is skipped only when its
  * box distance EXCEEDS the current k-th distance (rounding is monotone, so the box bound never exceeds a
  * contained point's computed d2): equal-distance candidates with a lower index are always seen. */
+template <int STACK>
 __global__ __launch_bounds__(kCloudThreads) void k_cloud_knn(const float4* __restrict__ kd_lo,
                                                              const float4* __restrict__ kd_hi,
                                                              const float4* __restrict__ pts,
                                                              const float* __restrict__ queries, uint32_t nq, uint32_t k,
                                                              int32_t* __restrict__ out_idx, float* __restrict__ out_d2,
                                                              uint32_t* __restrict__ out_count) {
-    __shared__ uint32_t st_node[kCloudStack][kCloudThreads];
-    __shared__ float st_bound[kCloudStack][kCloudThreads];
+    /* STACK > 32: the device-built tree (deeper than a median kd-tree): node ids only, the box distance is taken
+     * again at the pop (with the bounds the stack would not fit next to the neighbour lists) */
+    constexpr bool kBounds = STACK <= 32;
+    __shared__ uint32_t st_node[STACK][kCloudThreads];
+    __shared__ float st_bound[kBounds ? STACK : 1][kCloudThreads];
     __shared__ float nb_d2[kCloudK][kCloudThreads];
     __shared__ uint32_t nb_idx[kCloudK][kCloudThreads];
     const uint32_t t = blockIdx.x * kCloudThreads + threadIdx.x;
@@ -125,11 +130,11 @@ __global__ __launch_bounds__(kCloudThreads) void k_cloud_knn(const float4* __res
     if (fabsf(q[0]) < inf && fabsf(q[1]) < inf && fabsf(q[2]) < inf) { /* a non-finite query has no neighbours */
         int sp = 1;
         st_node[0][tx] = 0u;
-        st_bound[0][tx] = 0.f;
+        if (kBounds) st_bound[0][tx] = 0.f;
         while (sp > 0) {
             --sp;
             uint32_t node = st_node[sp][tx];
-            if (have == k && st_bound[sp][tx] > nb_d2[k - 1][tx]) continue;
+            if (have == k && (kBounds ? st_bound[sp][tx] : cloud_box_d2(q, kd_lo[node], kd_hi[node])) > nb_d2[k - 1][tx]) continue;
             for (;;) {
                 const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
                 if (a & 0x80000000u) {
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(kCloudThreads) void k_cloud_knn(const float4* __res
                 const uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
                 const float dn = fminf(dl, dr), df = fmaxf(dl, dr);
                 const float worst = have == k ? nb_d2[k - 1][tx] : __builtin_inff();
-                if (!(df > worst) && sp < kCloudStack) {
+                if (!(df > worst) && sp < STACK) {
                     st_node[sp][tx] = farc;
-                    st_bound[sp][tx] = df;
+                    if (kBounds) st_bound[sp][tx] = df;
                     ++sp;
                 }
                 if (dn > worst) break;
@@ -178,6 +183,17 @@ __global__ __launch_bounds__(kCloudThreads) void k_cloud_knn(const float4* __res
         out_d2[(size_t)t * k + j] = j < have ? nb_d2[j][tx] : __builtin_inff();
     }
     out_count[t] = have;
+}
+
+/* a tree over a subset: the points' w = row of the subset list -> the cloud's own index */
+__global__ __launch_bounds__(256) void k_cloud_remap_w(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ subset) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float4 P = pts[t];
+    if (P.x == P.x) {
+        P.w = __uint_as_float(subset[__float_as_uint(P.w)]);
+        pts[t] = P;
+    }
 }
 
 /* squared distance of every tree point to one query (coalesced 16-B reads, 4-B writes) */
@@ -264,6 +280,77 @@ int tm_cloud_create(tm_ctx* ctx, const float* surfels, uint32_t n, const uint32_
     c->ctx = ctx;
     c->n = n;
     if (n) c->h_cloud.assign(surfels, surfels + (size_t)n * 12);
+    if (!ctx->opt.model_host_build && n) {
+        /* round 4: the tree is built on the device like every other tree of the library — the (subset of the) cloud goes
+         * up raw, tmx::curve_order sorts it along the Hilbert curve, tmx::lbvh_build links the boxes; the host build
+         * below (a recursive median split on one thread, ~1 s per million points) stays as the cross-check
+         * (model_host_build = 1). The neighbour order of the queries does not depend on the tree: (d2, cloud index). */
+        const uint32_t n_in = n_subset ? n_subset : n;
+        std::vector<float> rows;
+        if (n_subset) { /* set_indices(subset): the tree holds these points only */
+            rows.resize((size_t)n_subset * 12);
+            for (uint32_t k = 0; k < n_subset; ++k) memcpy(&rows[(size_t)k * 12], surfels + (size_t)subset[k] * 12, 48);
+        }
+        dbuf<float> d_cloud;
+        dbuf<unsigned long long> d_keys;
+        dbuf<uint32_t> d_order, d_cnt, d_sub;
+        dbuf<unsigned char> d_bounds;
+        dbuf<uint4> d_q;
+        auto cleanup = [&]() {
+            d_cloud.release();
+            d_keys.release();
+            d_order.release();
+            d_cnt.release();
+            d_sub.release();
+            d_bounds.release();
+            d_q.release();
+        };
+        int rc;
+        if ((rc = d_cloud.alloc((size_t)n_in * 12)) || (rc = d_bounds.alloc(64)) || (rc = d_cnt.alloc(3 + kLbvhMaxDepth + 3 + 1)) ||
+            (rc = d_q.alloc(2 * (size_t)n_in)) || (rc = c->kd_lo.alloc(2 * (size_t)n_in)) || (rc = c->kd_hi.alloc(2 * (size_t)n_in)) ||
+            (rc = c->kd_pts.alloc(n_in)) || (n_subset && (rc = d_sub.alloc(n_subset)))) {
+            cleanup();
+            tm_cloud_destroy(c);
+            return rc;
+        }
+        uint32_t* d_nfin = d_cnt.p + 3 + kLbvhMaxDepth + 3;
+        uint32_t n_fin = 0;
+        hipError_t e = hipMemcpyAsync(d_cloud.p, n_subset ? rows.data() : surfels, (size_t)n_in * 48, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && n_subset)
+            e = hipMemcpyAsync(d_sub.p, subset, (size_t)n_subset * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_nfin, 0, 4, ctx->stream);
+        if (e == hipSuccess) {
+            rc = curve_order(ctx, d_cloud.p, n_in, true, d_bounds.p, d_keys, d_order);
+            if (rc) {
+                cleanup();
+                tm_cloud_destroy(c);
+                return rc;
+            }
+            curve_points(ctx, d_cloud.p, d_order.p, n_in, c->kd_pts.p, d_nfin);
+            if (n_subset) /* w = row of the subset list -> the cloud's own index */
+                hipLaunchKernelGGL(k_cloud_remap_w, dim3((n_in + 255) / 256), dim3(256), 0, ctx->stream, c->kd_pts.p, n_in, d_sub.p);
+            e = hipMemcpyAsync(&n_fin, d_nfin, 4, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && n_fin > 0) {
+            lbvh_build(ctx, d_keys.p, c->kd_pts.p, n_fin, c->kd_lo.p, c->kd_hi.p, d_q.p, d_q.p + n_in, d_cnt.p);
+            std::vector<float4> h_pts(n_fin);
+            e = hipMemcpyAsync(h_pts.data(), c->kd_pts.p, (size_t)n_fin * 16, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            c->h_idx_of_pos.resize(n_fin);
+            for (uint32_t k = 0; k < n_fin; ++k) memcpy(&c->h_idx_of_pos[k], &h_pts[k].w, 4);
+        }
+        cleanup();
+        if (e != hipSuccess) {
+            set_error("tm_cloud_create: %s", hipGetErrorString(e));
+            tm_cloud_destroy(c);
+            return TM_ERR_HIP;
+        }
+        c->n_kd = n_fin;
+        c->deep_tree = true;
+        *out = c;
+        return TM_OK;
+    }
     std::vector<float4> pos(n);
     for (uint32_t i = 0; i < n; ++i) {
         const float* s = surfels + (size_t)i * 12;
@@ -360,9 +447,10 @@ int tm_cloud_knn(tm_cloud* c, const float* queries_xyz, uint32_t n_queries, uint
         TM_FORWARD(c->w_out_d2.ensure((size_t)n_queries * k));
         TM_FORWARD(c->w_cnt.ensure(n_queries));
         TM_HIP_CHECK(hipMemcpyAsync(c->w_q.p, queries_xyz, (size_t)n_queries * 12, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_cloud_knn, dim3((n_queries + kCloudThreads - 1) / kCloudThreads), dim3(kCloudThreads), 0,
-                           ctx->stream, c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, c->w_q.p, n_queries, k, c->w_idx.p,
-                           c->w_out_d2.p, c->w_cnt.p);
+        hipLaunchKernelGGL(c->deep_tree ? k_cloud_knn<kLbvhStack> : k_cloud_knn<kCloudStack>,
+                           dim3((n_queries + kCloudThreads - 1) / kCloudThreads), dim3(kCloudThreads), 0, ctx->stream,
+                           c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, c->w_q.p, n_queries, k, c->w_idx.p, c->w_out_d2.p,
+                           c->w_cnt.p);
         TM_HIP_CHECK(hipGetLastError());
         TM_HIP_CHECK(hipMemcpyAsync(indices, c->w_idx.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
         TM_HIP_CHECK(hipMemcpyAsync(sq_dists, c->w_out_d2.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));

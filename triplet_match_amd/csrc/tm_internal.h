@@ -396,6 +396,14 @@ bool ctx_alive(tm_ctx* ctx);
 /* tm_scene_build.hip: upload h_cloud / h_tmask / h_mask; derive every device array of the scene */
 int scene_upload(tm_scene* s, const float* surfels = nullptr);
 int scene_build(tm_scene* s, bool resort);
+/* tm_model.hip: the linear BVH over points sorted by their curve keys (node format of the kd-tree kernels: lo.w / hi.w =
+ * children, or leaf range begin | 0x80000000 / end). Deeper than a median kd-tree: a consumer needs a stack of
+ * kLbvhStack entries. lo / hi: 2 * n_fin nodes, q0 / q1: n_fin work items each, cnt: 3 + kLbvhMaxDepth + 3 words
+ * (cnt[0] = node count afterwards). Queued on the context's stream (with a few 4-byte read-backs in between). */
+constexpr int kLbvhStack = 48, kLbvhMaxDepth = kLbvhStack - 2;
+void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4* d_pts, uint32_t n_fin, float4* d_lo,
+                float4* d_hi, uint4* d_q0, uint4* d_q1, uint32_t* d_cnt);
+void curve_points(tm_ctx* c, const float* d_cloud, const uint32_t* d_order, uint32_t n, float4* d_pts, uint32_t* d_n_fin);
 /* tm_scene_build.hip: sorted curve keys + order of a raw device cloud (d_bounds: room for a tmx::scene_bounds, 64 bytes) */
 int curve_order(tm_ctx* c, const float* d_cloud, uint32_t n, bool hilbert, void* d_bounds,
                 dbuf<unsigned long long>& keys_out, dbuf<uint32_t>& order_out);

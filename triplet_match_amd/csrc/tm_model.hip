@@ -1328,7 +1328,6 @@ namespace tmx {
  * launch per level. ~140 tiny launches, no host synchronisation; the host build of a 1M-point kd-tree was 38 ms plus
  * 30 ms of array shuffling and uploads. The depth is not bounded by log2(n): the consumer needs a stack of
  * kLbvhMaxDepth + 2 (k_curvature<kLbvhStack>). */
-constexpr int kLbvhStack = 48, kLbvhMaxDepth = kLbvhStack - 2;
 __global__ void k_lbvh_init(uint32_t n, uint4* __restrict__ q0, uint32_t* __restrict__ counters /* nodes, |q0|, |q1| */,
                             uint32_t* __restrict__ level_start) {
     q0[0] = make_uint4(0u, 0u, n, 0u);
@@ -1404,8 +1403,8 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(const float4* __restrict__ p
 /* queues the build of the tree over pts[0, n_fin) (in the order of their sorted keys): lo / hi = 2 * n_fin nodes at
  * most, q0 / q1 = n_fin work items each, cnt = 3 + kLbvhMaxDepth + 3 words (nodes, |q0|, |q1|, level starts; cnt[0]
  * ends up as the node count) */
-static void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4* d_pts, uint32_t n_fin, float4* d_lo,
-                       float4* d_hi, uint4* d_q0, uint4* d_q1, uint32_t* d_cnt) {
+void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4* d_pts, uint32_t n_fin, float4* d_lo,
+                float4* d_hi, uint4* d_q0, uint4* d_q1, uint32_t* d_cnt) {
     uint32_t* level_start = d_cnt + 3;
     hipLaunchKernelGGL(k_lbvh_init, dim3(1), dim3(1), 0, c->stream, n_fin, d_q0, d_cnt, level_start);
     const uint32_t grid = std::min<uint32_t>(1024u, (n_fin + 255u) / 256u);
@@ -1561,6 +1560,11 @@ __global__ __launch_bounds__(256) void k_kd_scene_points(const float* __restrict
         const uint32_t t = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
         if (t) atomicAdd(n_fin, t);
     }
+}
+/* queues: pts[k] = (xyz, original index) of the k-th point along the curve (NaN x for the non-finite tail), *d_n_fin +=
+ * the number of finite points (zero it first) */
+void curve_points(tm_ctx* c, const float* d_cloud, const uint32_t* d_order, uint32_t n, float4* d_pts, uint32_t* d_n_fin) {
+    hipLaunchKernelGGL(k_kd_scene_points, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_cloud, d_order, n, d_pts, d_n_fin);
 }
 __global__ __launch_bounds__(256) void k_kd_scene_normals(const float* __restrict__ cloud, uint32_t n, float4* __restrict__ nrm) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
