@@ -253,3 +253,24 @@ def test_sixteen_million_point_scene(gpu_ctx, full):
     partner[sc1] = mc1
     assert np.array_equal(partner[src[sc16]], mc16.astype(np.int64))
     gs16.close()
+
+
+def test_curvature_lists_by_lane_groups_equal_per_thread_lists_full_size(gpu_ctx, full):
+    """the curvature pass at the configs[1] scene size: the k-nearest lists built by eight lanes per query (default)
+    == one thread per query (curv_groups = 0), bit for bit — for the tangent candidates of the 1M-point scene (a sparse
+    query list on the scene's tree), for all points of a 300k-point cloud (the queries are the tree's own points), for
+    k = 32 (every list register in use) and k = 1; a sample of rows against the oracle's exhaustive neighbour scan"""
+    S, tmk = full["scene"]["surfels"], full["scene"]["tangent_mask"]
+    idx = np.nonzero(tmk)[0].astype(np.uint32)
+    assert len(idx) > 10_000
+    rows = {}
+    for groups in (1, 0):
+        with gpu_ctx.option("curv_groups", groups):
+            rows[groups] = (full["gs"].curvature_subset(idx, 30), gpu_ctx.cloud_curvature(S[:300_000], 30),
+                            full["gs"].curvature_subset(idx[:5000], 32), full["gs"].curvature_subset(idx[:5000], 1))
+    for a, b in zip(rows[1], rows[0]):
+        assert np.array_equal(bits(a), bits(b))
+    assert (rows[1][0][:, 4] > 0).any()
+    sample = np.random.default_rng(8).choice(20_000, 300, replace=False).astype(np.uint32)
+    want = tmo.cloud_curvature(S[:20_000], 30)[sample]
+    assert np.array_equal(bits(gpu_ctx.cloud_curvature_subset(S[:20_000], sample, 30)), bits(want))

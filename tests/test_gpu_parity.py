@@ -833,7 +833,17 @@ def test_cloud_resolution_bit_exact(gpu_ctx):
             assert gpu_ctx.cloud_resolution(model[:1])[0] == 0.0 and gpu_ctx.cloud_resolution(model[50:52])[0] == 0.0
 
 
-def test_cloud_curvature_bit_exact(gpu_ctx):
+@pytest.fixture(params=[1, 0], ids=["eight_lanes_per_query", "thread_per_query"])
+def curv_walk(request, gpu_ctx):
+    """the curvature pass's k-nearest lists: eight lanes per query with the list in registers (default) or one thread
+    per query with the list in LDS (curv_groups = 0) — the same lists either way"""
+    old = gpu_ctx.get_option("curv_groups")
+    gpu_ctx.set_option("curv_groups", request.param)
+    yield request.param
+    gpu_ctx.set_option("curv_groups", old)
+
+
+def test_cloud_curvature_bit_exact(gpu_ctx, curv_walk):
     """cloud->curvature(30, i): kNN-30 + projected-normal covariance + Jacobi eigenvalues, GPU vs oracle."""
     model, _ = synth.synth_model(3000, seed=6)
     model[10:14, 0:3] = model[20:24, 0:3]  # duplicates: ties in the neighbour order
@@ -1380,7 +1390,7 @@ def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case, clo
     assert (cnt == 5).all() and (idx[:, 5:] == -1).all() and np.isinf(d2[:, 5:]).all()
 
 
-def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx):
+def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx, curv_walk):
     """tm_cloud_curvature / tm_cloud_resolution (kd-tree kNN kernel, own Jacobi) against the float64 scipy cKDTree +
     numpy.linalg.eigh vectors of tests/golden/curvature_20k.npz — an answer that passes through none of our code"""
     import os
@@ -1397,7 +1407,7 @@ def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx):
     assert (np.abs(d2[:, -1] - g["kth_d2"][:2000]) <= 2e-6 * g["kth_d2"][:2000] + 1e-12).all()
 
 
-def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case):
+def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case, curv_walk):
     """tm_cloud_curvature_subset (the points that pass the tangent test only) == those rows of tm_cloud_curvature,
     bit for bit; non-finite listed points keep zero rows"""
     cloud = small_case["scene"]["surfels"][:8000].copy()
@@ -1409,7 +1419,7 @@ def test_curvature_subset_equals_rows_of_the_full_call(gpu_ctx, small_case):
     assert len(idx) > 100
 
 
-def test_scene_curvature_and_late_tangent_mask(gpu_ctx, oracle_small, small_case):
+def test_scene_curvature_and_late_tangent_mask(gpu_ctx, oracle_small, small_case, curv_walk):
     """tm_scene_curvature_subset (tree built on the device over the scene's curve order) == tm_cloud_curvature_subset
     (host-built kd-tree) == the oracle, bit for bit, with a mask set and non-finite points in the cloud; a scene
     created with an empty tangent mask and given tangent_mask_ afterwards (tm_scene_set_tangent_mask) == a scene

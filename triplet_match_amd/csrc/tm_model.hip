@@ -350,6 +350,46 @@ __global__ __launch_bounds__(256) void k_knn2(const float4* __restrict__ kd_lo, 
 constexpr int kCurvK = 32;      /* capacity of the neighbour list (k <= 32) */
 constexpr int kCurvThreads = 128;
 
+/* principal curvatures from a finished neighbour list, idx_at(j) = original index of the j-th nearest (reference
+ * include/impl/pointcloud.hpp:5-43) */
+template <class IdxAt>
+__device__ __forceinline__ void curvature_of_list(const float4* __restrict__ nrm, uint32_t self, uint32_t have,
+                                                  IdxAt idx_at, float* __restrict__ out) {
+    const float4 N0 = nrm[self];
+    const float n0[3] = {N0.x, N0.y, N0.z};
+    float M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = (r == c ? 1.f : 0.f) - n0[r] * n0[c];
+    float cen[3] = {0.f, 0.f, 0.f};
+    for (uint32_t j = 0; j < have; ++j) {
+        const float4 Nj = nrm[idx_at(j)];
+        for (int r = 0; r < 3; ++r) {
+            float pr = (M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z;
+            cen[r] = cen[r] + (pr - cen[r]) / (float)(j + 1);
+        }
+    }
+    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; /* 00 01 02 11 12 22 */
+    for (uint32_t j = 0; j < have; ++j) {
+        const float4 Nj = nrm[idx_at(j)];
+        float d[3];
+        for (int r = 0; r < 3; ++r) d[r] = ((M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z) - cen[r];
+        cov[0] += d[0] * d[0];
+        cov[1] += d[0] * d[1];
+        cov[2] += d[0] * d[2];
+        cov[3] += d[1] * d[1];
+        cov[4] += d[1] * d[2];
+        cov[5] += d[2] * d[2];
+    }
+    float ev[3], vmax[3];
+    jacobi_eigen3(cov, ev, vmax);
+    const float area_inv = 1.0f / (float)have;
+    out[0] = vmax[0];
+    out[1] = vmax[1];
+    out[2] = vmax[2];
+    out[3] = ev[1] * area_inv;
+    out[4] = ev[2] * area_inv;
+}
+
 template <int STACK = kKdStack>
 __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __restrict__ kd_lo,
                                                             const float4* __restrict__ kd_hi,
@@ -432,40 +472,135 @@ __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __rest
             node = nearc;
         }
     }
-    /* principal curvatures (reference include/impl/pointcloud.hpp:5-43) */
-    const float4 N0 = nrm[self];
-    const float n0[3] = {N0.x, N0.y, N0.z};
-    float M[3][3];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) M[r][c] = (r == c ? 1.f : 0.f) - n0[r] * n0[c];
-    float cen[3] = {0.f, 0.f, 0.f};
-    for (uint32_t j = 0; j < have; ++j) {
-        const float4 Nj = nrm[nb_idx[j][tx]];
-        for (int r = 0; r < 3; ++r) {
-            float pr = (M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z;
-            cen[r] = cen[r] + (pr - cen[r]) / (float)(j + 1);
+    curvature_of_list(nrm, self, have, [&](uint32_t j) { return nb_idx[j][tx]; }, out);
+}
+
+/* ---- the same neighbour lists with EIGHT lanes per query (default, curv_groups = 1) ----
+ * One thread per query leaves a wave executing 64 different tree walks one after the other, each step with one useful
+ * lane, and a few ten thousand queries (the tangent candidates of a 1M-point scene) are a few hundred waves: the kernel
+ * lasts as long as one wave's 64 walks. Here a query belongs to a group of 8 lanes: a leaf of the device-built tree
+ * holds at most 8 points — one per lane —, the sorted list of 32 (d2, original index) entries lives in REGISTERS, four
+ * consecutive entries per lane, and an insertion is one parallel step (every lane counts its entries below the
+ * candidate; the lane where the count ends puts the candidate there and hands its last entry on, the lanes after it
+ * shift by one — three 8-lane shuffles, no loop, no LDS). A wave walks 8 trees instead of 64, eight times as many waves
+ * share the chip, and a step costs less. The (node, box distance) stack is per group in LDS. The walk's rules are
+ * k_curvature's: a subtree is skipped when its box distance EXCEEDS the k-th distance, candidates are ordered by
+ * (d2, original index) — so the lists, and the curvatures computed from them (k_curvature_lists, one thread per
+ * query), are the same bit for bit. Unused list entries are (inf, 0xFFFFFFFF): "list not full" is "k-th distance =
+ * inf", under which nothing is skipped and every point is accepted. */
+constexpr int kListRow = 32; /* entries per query in the list buffer: 8 lanes x 4 registers = kCurvK */
+static_assert(kListRow == kCurvK, "the group's registers hold the whole neighbour list");
+
+__device__ __forceinline__ bool nb_less(float a, uint32_t ai, float b, uint32_t bi) { return a < b || (a == b && ai < bi); }
+
+template <int STACK>
+__global__ __launch_bounds__(256) void k_knn_lists(const float4* __restrict__ kd_lo, const float4* __restrict__ kd_hi,
+                                                   const float4* __restrict__ pts /* xyz, orig idx */,
+                                                   uint32_t k /* 1..32, <= number of points */,
+                                                   const float4* __restrict__ queries /* (xyz, orig idx), NaN x = skip */,
+                                                   uint32_t n_queries, uint32_t* __restrict__ lists /* n_queries x 32 */) {
+    __shared__ uint32_t st_node[STACK][32];
+    __shared__ float st_bound[STACK][32];
+    const uint32_t l = threadIdx.x & 7u, grp = threadIdx.x >> 3;
+    const uint32_t qi = blockIdx.x * 32u + grp;
+    if (qi >= n_queries) return; /* whole groups leave: the shuffles below stay inside a group */
+    const float4 Q = queries[qi];
+    if (!(Q.x == Q.x)) return;
+    const float q[3] = {Q.x, Q.y, Q.z};
+    float d[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    uint32_t ix[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    float wd = __builtin_inff(); /* the k-th entry: lane (k - 1) / 4, register (k - 1) % 4 */
+    uint32_t wi = 0xFFFFFFFFu;
+    const int k_lane = (int)((k - 1u) >> 2), k_reg = (int)((k - 1u) & 3u);
+    const uint32_t group_shift = threadIdx.x & 56u; /* the group's first lane within the wave */
+    int sp = 1;
+    if (l == 0u) {
+        st_node[0][grp] = 0u;
+        st_bound[0][grp] = 0.f;
+    }
+    while (sp > 0) {
+        --sp;
+        uint32_t node = st_node[sp][grp];
+        if (st_bound[sp][grp] > wd) continue;
+        for (;;) {
+            const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
+            if (a & 0x80000000u) {
+                for (uint32_t p0 = a & 0x7FFFFFFFu; p0 < b; p0 += 8u) { /* a leaf at the depth limit can hold more than 8 */
+                    const uint32_t p = p0 + l;
+                    const float4 P = pts[p < b ? p : p0];
+                    const float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    const uint32_t idx = __float_as_uint(P.w);
+                    const bool cand = p < b && nb_less(d2, idx, wd, wi);
+                    uint32_t m = (uint32_t)(__ballot(cand) >> group_shift) & 0xFFu;
+                    while (m) {
+                        const int j = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const float v = __shfl(d2, j, 8);
+                        const uint32_t vi = (uint32_t)__shfl((int)idx, j, 8);
+                        if (!nb_less(v, vi, wd, wi)) continue; /* the k-th entry has moved since the ballot */
+                        const int c = (int)nb_less(d[0], ix[0], v, vi) + (int)nb_less(d[1], ix[1], v, vi) +
+                                      (int)nb_less(d[2], ix[2], v, vi) + (int)nb_less(d[3], ix[3], v, vi);
+                        int pc = __shfl_up(c, 1, 8);
+                        const float pd = __shfl_up(d[3], 1, 8);
+                        const uint32_t pi = (uint32_t)__shfl_up((int)ix[3], 1, 8);
+                        if (l == 0u) pc = 4;
+                        if (c < 4) {
+                            /* pc == 4: the sorted position is in this lane, at c; otherwise c == 0 and the whole lane
+                             * shifts, taking the previous lane's last entry */
+                            const float ins_d = pc == 4 ? v : pd;
+                            const uint32_t ins_i = pc == 4 ? vi : pi;
+                            d[3] = c == 3 ? ins_d : d[2];
+                            ix[3] = c == 3 ? ins_i : ix[2];
+                            d[2] = c > 2 ? d[2] : (c == 2 ? ins_d : d[1]);
+                            ix[2] = c > 2 ? ix[2] : (c == 2 ? ins_i : ix[1]);
+                            d[1] = c > 1 ? d[1] : (c == 1 ? ins_d : d[0]);
+                            ix[1] = c > 1 ? ix[1] : (c == 1 ? ins_i : ix[0]);
+                            d[0] = c > 0 ? d[0] : ins_d;
+                            ix[0] = c > 0 ? ix[0] : ins_i;
+                        }
+                        const float kd = k_reg == 0 ? d[0] : (k_reg == 1 ? d[1] : (k_reg == 2 ? d[2] : d[3]));
+                        const uint32_t ki = k_reg == 0 ? ix[0] : (k_reg == 1 ? ix[1] : (k_reg == 2 ? ix[2] : ix[3]));
+                        wd = __shfl(kd, k_lane, 8);
+                        wi = (uint32_t)__shfl((int)ki, k_lane, 8);
+                    }
+                }
+                break;
+            }
+            const float dl = box_d2(q, kd_lo[a], kd_hi[a]);
+            const float dr = box_d2(q, kd_lo[b], kd_hi[b]);
+            const uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
+            const float dn = fminf(dl, dr), df = fmaxf(dl, dr);
+            if (!(df > wd) && sp < STACK) {
+                if (l == 0u) {
+                    st_node[sp][grp] = farc;
+                    st_bound[sp][grp] = df;
+                }
+                ++sp;
+            }
+            if (dn > wd) break;
+            node = nearc;
         }
     }
-    float cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; /* 00 01 02 11 12 22 */
-    for (uint32_t j = 0; j < have; ++j) {
-        const float4 Nj = nrm[nb_idx[j][tx]];
-        float d[3];
-        for (int r = 0; r < 3; ++r) d[r] = ((M[r][0] * Nj.x + M[r][1] * Nj.y) + M[r][2] * Nj.z) - cen[r];
-        cov[0] += d[0] * d[0];
-        cov[1] += d[0] * d[1];
-        cov[2] += d[0] * d[2];
-        cov[3] += d[1] * d[1];
-        cov[4] += d[1] * d[2];
-        cov[5] += d[2] * d[2];
-    }
-    float ev[3], vmax[3];
-    jacobi_eigen3(cov, ev, vmax);
-    const float area_inv = 1.0f / (float)have;
-    out[0] = vmax[0];
-    out[1] = vmax[1];
-    out[2] = vmax[2];
-    out[3] = ev[1] * area_inv;
-    out[4] = ev[2] * area_inv;
+    /* entries 4 l .. 4 l + 3 of the query's row: the group writes one 128-byte line */
+    reinterpret_cast<uint4*>(lists)[(size_t)qi * 8u + l] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
+}
+
+/* curvature rows from the lists, one thread per query (row t of the caller's order: row_of[t], or t; without a query
+ * list the row is the point's original index) */
+__global__ __launch_bounds__(256) void k_curvature_lists(const float4* __restrict__ nrm, uint32_t k,
+                                                         const float4* __restrict__ queries, uint32_t n_queries,
+                                                         const uint32_t* __restrict__ lists, bool rows_by_index,
+                                                         const uint32_t* __restrict__ row_of, uint32_t row_base,
+                                                         float* __restrict__ curv5 /* zeroed */) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queries) return;
+    const float4 Q = queries[t];
+    if (!(Q.x == Q.x)) return; /* a non-finite query point keeps its zero row */
+    const uint32_t self = __float_as_uint(Q.w);
+    float* out = curv5 + (size_t)(rows_by_index ? self : (row_of ? row_of[row_base + t] : row_base + t)) * 5;
+    const uint32_t* row = lists + (size_t)t * kListRow;
+    curvature_of_list(nrm, self, k, [&](uint32_t j) { return row[j]; }, out);
 }
 
 /* dense x-fastest view with ORIGINAL indices (what the reference's voxel_data_ holds) for the ABI */
@@ -1649,6 +1784,9 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
                  o_idx = take(((size_t)n_idx + 1) * 4), o_out = take((size_t)n_idx * 20), o_lo = take(2 * (size_t)n * 16),
                  o_hi = take(2 * (size_t)n * 16), o_q0 = take((size_t)n * 16), o_q1 = take((size_t)n * 16),
                  o_cnt = take((3 + kLbvhMaxDepth + 3) * 4);
+    /* neighbour lists of one launch's queries (curv_groups): 128 bytes per query, at most kListChunk queries a launch */
+    constexpr uint32_t kListChunk = 1u << 20;
+    const size_t o_lists = c->opt.curv_groups ? take((size_t)std::min(n_idx, kListChunk) * kListRow * 4) : 0;
     /* subset mode: the queries are walked in the tree's order (a caller's list — ascending original index — is in no
      * spatial order when the cloud is not: every lane of a wave would go its own way) */
     const bool reorder = !all && n_idx >= 256u;
@@ -1708,9 +1846,23 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
         lap("tree");
         const uint32_t kk = std::min(k, n_fin);
         const uint32_t n_threads = all ? n_fin : n_idx;
-        hipLaunchKernelGGL(k_curvature<kLbvhStack>, dim3((n_threads + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads), 0,
-                           c->stream, d_lo.p, d_hi.p, d_pts.p, d_nrm.p, n_fin, kk, d_out.p, all ? (const float4*)nullptr : d_q.p,
-                           n_idx, reorder ? reinterpret_cast<const uint32_t*>(arena.p + o_row) : (const uint32_t*)nullptr);
+        const uint32_t* d_row_of = reorder ? reinterpret_cast<const uint32_t*>(arena.p + o_row) : (const uint32_t*)nullptr;
+        if (c->opt.curv_groups) {
+            /* eight lanes per query build the lists, one thread per query turns them into curvatures */
+            uint32_t* d_lists = reinterpret_cast<uint32_t*>(arena.p + o_lists);
+            const float4* d_queries = all ? d_pts.p : d_q.p; /* all: the tree's own points, every one finite */
+            for (uint32_t q0 = 0; q0 < n_threads; q0 += kListChunk) {
+                const uint32_t cnt = std::min(kListChunk, n_threads - q0);
+                hipLaunchKernelGGL(k_knn_lists<kLbvhStack>, dim3((cnt + 31u) / 32u), dim3(256), 0, c->stream, d_lo.p, d_hi.p,
+                                   d_pts.p, kk, d_queries + q0, cnt, d_lists);
+                hipLaunchKernelGGL(k_curvature_lists, dim3((cnt + 255u) / 256u), dim3(256), 0, c->stream, d_nrm.p, kk,
+                                   d_queries + q0, cnt, d_lists, all, d_row_of, q0, d_out.p);
+            }
+        } else {
+            hipLaunchKernelGGL(k_curvature<kLbvhStack>, dim3((n_threads + kCurvThreads - 1) / kCurvThreads), dim3(kCurvThreads),
+                               0, c->stream, d_lo.p, d_hi.p, d_pts.p, d_nrm.p, n_fin, kk, d_out.p,
+                               all ? (const float4*)nullptr : d_q.p, n_idx, d_row_of);
+        }
         e = hipGetLastError();
         lap("kernel");
     }
