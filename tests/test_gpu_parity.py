@@ -810,7 +810,7 @@ def test_edge_cases(gpu_ctx, gpu_small, oracle_small, small_case):
         assert e.code == capi.ERR_EMPTY
 
 
-def test_cloud_resolution_bit_exact(gpu_ctx):
+def test_cloud_resolution_bit_exact(gpu_ctx, curv_walk):
     """cloud->resolution(): GPU 2-NN distances and the f32 running mean equal the oracle's exhaustive
     version bit for bit (duplicates -> distance 0, non-finite points skipped)."""
     model, _ = synth.synth_model(6000, seed=5)
@@ -835,8 +835,9 @@ def test_cloud_resolution_bit_exact(gpu_ctx):
 
 @pytest.fixture(params=[1, 0], ids=["eight_lanes_per_query", "thread_per_query"])
 def curv_walk(request, gpu_ctx):
-    """the curvature pass's k-nearest lists: eight lanes per query with the list in registers (default) or one thread
-    per query with the list in LDS (curv_groups = 0) — the same lists either way"""
+    """the k-nearest lists of the curvature pass, of cloud->resolution() and of the neighbour accessors: eight lanes per
+    query with the list in registers (default) or one thread per query with the list in LDS (curv_groups = 0) — the
+    same lists either way"""
     old = gpu_ctx.get_option("curv_groups")
     gpu_ctx.set_option("curv_groups", request.param)
     yield request.param
@@ -1325,7 +1326,7 @@ def cloud_tree_route(request, gpu_ctx):
     gpu_ctx.set_option("model_host_build", old)
 
 
-def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case, cloud_tree_route):
+def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case, cloud_tree_route, curv_walk):
     """tm_cloud (the neighbour accessors of pointcloud<Point>, include/pointcloud:38-63): kNN (kd-tree route k <= 32,
     one-pass route k > 32) and radius search against the oracle's exhaustive scan — indices and squared distances
     bit for bit, order (d2, index) — and, independently of both, against scipy's cKDTree (same neighbour SETS up to

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtm_hip.so")
 SOURCES = ["tm_core.hip", "tm_model.hip", "tm_scene.hip", "tm_scene_build.hip", "tm_traits.hip", "tm_earlydrop.hip", "tm_comm.hip", "tm_cloud.hip"]
-HEADERS = ["tm_math.h", "tm_internal.h", "tm_table.h", "tm_traits_math.h", "tm_score.h", "tm_icp_math.h",
+HEADERS = ["tm_math.h", "tm_internal.h", "tm_table.h", "tm_traits_math.h", "tm_score.h", "tm_icp_math.h", "tm_knn.h",
            os.path.join("..", "..", "include", "tm_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall",

@@ -14,6 +14,7 @@
  * (PCL's nearestKSearch / radiusSearch do the same).
  */
 #include "tm_internal.h"
+#include "tm_knn.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -184,6 +185,34 @@ __global__ __launch_bounds__(kCloudThreads) void k_cloud_knn(const float4* __res
     }
     out_count[t] = have;
 }
+
+/* the same lists with eight lanes per query (k_knn_groups, tm_knn.h; default): queries as packed xyz — a non-finite one
+ * is not walked and keeps the empty list —, rows of k (index or -1, d2 or inf) and the number of neighbours found */
+struct cloud_queries_xyz {
+    const float* q;
+    __device__ float4 operator()(uint32_t qi) const {
+        const float x = q[3 * (size_t)qi], y = q[3 * (size_t)qi + 1], z = q[3 * (size_t)qi + 2];
+        const float inf = __builtin_inff();
+        const bool fin = fabsf(x) < inf && fabsf(y) < inf && fabsf(z) < inf;
+        return make_float4(fin ? x : __builtin_nanf(""), y, z, 0.f);
+    }
+};
+struct cloud_sink_rows {
+    int32_t* idx;
+    float* d2;
+    uint32_t* count;
+    uint32_t k, n_points;
+    __device__ void operator()(uint32_t qi, float4 Q, uint32_t l, const float d[4], const uint32_t ix[4], float) const {
+        for (uint32_t r = 0; r < 4u; ++r) {
+            const uint32_t j = 4u * l + r;
+            if (j < k) {
+                idx[(size_t)qi * k + j] = (int32_t)ix[r]; /* an unused entry is 0xFFFFFFFF = -1 */
+                d2[(size_t)qi * k + j] = d[r];
+            }
+        }
+        if (l == 0u) count[qi] = Q.x == Q.x ? min(k, n_points) : 0u;
+    }
+};
 
 /* a tree over a subset: the points' w = row of the subset list -> the cloud's own index */
 __global__ __launch_bounds__(256) void k_cloud_remap_w(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ subset) {
@@ -441,16 +470,28 @@ int tm_cloud_knn(tm_cloud* c, const float* queries_xyz, uint32_t n_queries, uint
         if (counts) std::fill(counts, counts + n_queries, 0u);
         return TM_OK;
     }
-    if (k <= (uint32_t)kCloudK) { /* the batch in one launch, lists kept in LDS */
+    if (k <= (uint32_t)kCloudK) { /* the batch in one launch */
         TM_FORWARD(c->w_q.ensure((size_t)n_queries * 3));
         TM_FORWARD(c->w_idx.ensure((size_t)n_queries * k));
         TM_FORWARD(c->w_out_d2.ensure((size_t)n_queries * k));
         TM_FORWARD(c->w_cnt.ensure(n_queries));
         TM_HIP_CHECK(hipMemcpyAsync(c->w_q.p, queries_xyz, (size_t)n_queries * 12, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(c->deep_tree ? k_cloud_knn<kLbvhStack> : k_cloud_knn<kCloudStack>,
-                           dim3((n_queries + kCloudThreads - 1) / kCloudThreads), dim3(kCloudThreads), 0, ctx->stream,
-                           c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, c->w_q.p, n_queries, k, c->w_idx.p, c->w_out_d2.p,
-                           c->w_cnt.p);
+        if (ctx->opt.curv_groups) {
+            const cloud_queries_xyz qs{c->w_q.p};
+            const cloud_sink_rows sink{c->w_idx.p, c->w_out_d2.p, c->w_cnt.p, k, c->n_kd};
+            const dim3 grid((n_queries + (uint32_t)kKnnGroupsPerBlock - 1u) / (uint32_t)kKnnGroupsPerBlock);
+            if (c->deep_tree)
+                hipLaunchKernelGGL((k_knn_groups<kLbvhStack, cloud_queries_xyz, cloud_sink_rows>), grid, dim3(256), 0, ctx->stream,
+                                   c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, k, qs, n_queries, sink);
+            else
+                hipLaunchKernelGGL((k_knn_groups<kCloudStack, cloud_queries_xyz, cloud_sink_rows>), grid, dim3(256), 0, ctx->stream,
+                                   c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, k, qs, n_queries, sink);
+        } else { /* one thread per query, lists in LDS */
+            hipLaunchKernelGGL(c->deep_tree ? k_cloud_knn<kLbvhStack> : k_cloud_knn<kCloudStack>,
+                               dim3((n_queries + kCloudThreads - 1) / kCloudThreads), dim3(kCloudThreads), 0, ctx->stream,
+                               c->kd_lo.p, c->kd_hi.p, c->kd_pts.p, c->w_q.p, n_queries, k, c->w_idx.p, c->w_out_d2.p,
+                               c->w_cnt.p);
+        }
         TM_HIP_CHECK(hipGetLastError());
         TM_HIP_CHECK(hipMemcpyAsync(indices, c->w_idx.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
         TM_HIP_CHECK(hipMemcpyAsync(sq_dists, c->w_out_d2.p, (size_t)n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));

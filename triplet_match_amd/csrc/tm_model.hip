@@ -12,6 +12,7 @@
 #include "tm_internal.h"
 #include "tm_traits_math.h"
 #include "tm_table.h"
+#include "tm_knn.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -475,116 +476,11 @@ __global__ __launch_bounds__(kCurvThreads) void k_curvature(const float4* __rest
     curvature_of_list(nrm, self, have, [&](uint32_t j) { return nb_idx[j][tx]; }, out);
 }
 
-/* ---- the same neighbour lists with EIGHT lanes per query (default, curv_groups = 1) ----
- * One thread per query leaves a wave executing 64 different tree walks one after the other, each step with one useful
- * lane, and a few ten thousand queries (the tangent candidates of a 1M-point scene) are a few hundred waves: the kernel
- * lasts as long as one wave's 64 walks. Here a query belongs to a group of 8 lanes: a leaf of the device-built tree
- * holds at most 8 points — one per lane —, the sorted list of 32 (d2, original index) entries lives in REGISTERS, four
- * consecutive entries per lane, and an insertion is one parallel step (every lane counts its entries below the
- * candidate; the lane where the count ends puts the candidate there and hands its last entry on, the lanes after it
- * shift by one — three 8-lane shuffles, no loop, no LDS). A wave walks 8 trees instead of 64, eight times as many waves
- * share the chip, and a step costs less. The (node, box distance) stack is per group in LDS. The walk's rules are
- * k_curvature's: a subtree is skipped when its box distance EXCEEDS the k-th distance, candidates are ordered by
- * (d2, original index) — so the lists, and the curvatures computed from them (k_curvature_lists, one thread per
- * query), are the same bit for bit. Unused list entries are (inf, 0xFFFFFFFF): "list not full" is "k-th distance =
- * inf", under which nothing is skipped and every point is accepted. */
-constexpr int kListRow = 32; /* entries per query in the list buffer: 8 lanes x 4 registers = kCurvK */
+/* ---- the same neighbour lists with EIGHT lanes per query (default, curv_groups = 1): k_knn_groups, tm_knn.h ----
+ * the lists come back as rows of 32 indices (knn_sink_rows); k_curvature_lists, one thread per query, turns them into
+ * curvatures — the same lists, so the same rows bit for bit */
+constexpr int kListRow = kKnnGroupK; /* entries per query in the list buffer */
 static_assert(kListRow == kCurvK, "the group's registers hold the whole neighbour list");
-
-__device__ __forceinline__ bool nb_less(float a, uint32_t ai, float b, uint32_t bi) { return a < b || (a == b && ai < bi); }
-
-template <int STACK>
-__global__ __launch_bounds__(256) void k_knn_lists(const float4* __restrict__ kd_lo, const float4* __restrict__ kd_hi,
-                                                   const float4* __restrict__ pts /* xyz, orig idx */,
-                                                   uint32_t k /* 1..32, <= number of points */,
-                                                   const float4* __restrict__ queries /* (xyz, orig idx), NaN x = skip */,
-                                                   uint32_t n_queries, uint32_t* __restrict__ lists /* n_queries x 32 */) {
-    __shared__ uint32_t st_node[STACK][32];
-    __shared__ float st_bound[STACK][32];
-    const uint32_t l = threadIdx.x & 7u, grp = threadIdx.x >> 3;
-    const uint32_t qi = blockIdx.x * 32u + grp;
-    if (qi >= n_queries) return; /* whole groups leave: the shuffles below stay inside a group */
-    const float4 Q = queries[qi];
-    if (!(Q.x == Q.x)) return;
-    const float q[3] = {Q.x, Q.y, Q.z};
-    float d[4] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
-    uint32_t ix[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    float wd = __builtin_inff(); /* the k-th entry: lane (k - 1) / 4, register (k - 1) % 4 */
-    uint32_t wi = 0xFFFFFFFFu;
-    const int k_lane = (int)((k - 1u) >> 2), k_reg = (int)((k - 1u) & 3u);
-    const uint32_t group_shift = threadIdx.x & 56u; /* the group's first lane within the wave */
-    int sp = 1;
-    if (l == 0u) {
-        st_node[0][grp] = 0u;
-        st_bound[0][grp] = 0.f;
-    }
-    while (sp > 0) {
-        --sp;
-        uint32_t node = st_node[sp][grp];
-        if (st_bound[sp][grp] > wd) continue;
-        for (;;) {
-            const uint32_t a = __float_as_uint(kd_lo[node].w), b = __float_as_uint(kd_hi[node].w);
-            if (a & 0x80000000u) {
-                for (uint32_t p0 = a & 0x7FFFFFFFu; p0 < b; p0 += 8u) { /* a leaf at the depth limit can hold more than 8 */
-                    const uint32_t p = p0 + l;
-                    const float4 P = pts[p < b ? p : p0];
-                    const float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;
-                    const uint32_t idx = __float_as_uint(P.w);
-                    const bool cand = p < b && nb_less(d2, idx, wd, wi);
-                    uint32_t m = (uint32_t)(__ballot(cand) >> group_shift) & 0xFFu;
-                    while (m) {
-                        const int j = __ffs((int)m) - 1;
-                        m &= m - 1u;
-                        const float v = __shfl(d2, j, 8);
-                        const uint32_t vi = (uint32_t)__shfl((int)idx, j, 8);
-                        if (!nb_less(v, vi, wd, wi)) continue; /* the k-th entry has moved since the ballot */
-                        const int c = (int)nb_less(d[0], ix[0], v, vi) + (int)nb_less(d[1], ix[1], v, vi) +
-                                      (int)nb_less(d[2], ix[2], v, vi) + (int)nb_less(d[3], ix[3], v, vi);
-                        int pc = __shfl_up(c, 1, 8);
-                        const float pd = __shfl_up(d[3], 1, 8);
-                        const uint32_t pi = (uint32_t)__shfl_up((int)ix[3], 1, 8);
-                        if (l == 0u) pc = 4;
-                        if (c < 4) {
-                            /* pc == 4: the sorted position is in this lane, at c; otherwise c == 0 and the whole lane
-                             * shifts, taking the previous lane's last entry */
-                            const float ins_d = pc == 4 ? v : pd;
-                            const uint32_t ins_i = pc == 4 ? vi : pi;
-                            d[3] = c == 3 ? ins_d : d[2];
-                            ix[3] = c == 3 ? ins_i : ix[2];
-                            d[2] = c > 2 ? d[2] : (c == 2 ? ins_d : d[1]);
-                            ix[2] = c > 2 ? ix[2] : (c == 2 ? ins_i : ix[1]);
-                            d[1] = c > 1 ? d[1] : (c == 1 ? ins_d : d[0]);
-                            ix[1] = c > 1 ? ix[1] : (c == 1 ? ins_i : ix[0]);
-                            d[0] = c > 0 ? d[0] : ins_d;
-                            ix[0] = c > 0 ? ix[0] : ins_i;
-                        }
-                        const float kd = k_reg == 0 ? d[0] : (k_reg == 1 ? d[1] : (k_reg == 2 ? d[2] : d[3]));
-                        const uint32_t ki = k_reg == 0 ? ix[0] : (k_reg == 1 ? ix[1] : (k_reg == 2 ? ix[2] : ix[3]));
-                        wd = __shfl(kd, k_lane, 8);
-                        wi = (uint32_t)__shfl((int)ki, k_lane, 8);
-                    }
-                }
-                break;
-            }
-            const float dl = box_d2(q, kd_lo[a], kd_hi[a]);
-            const float dr = box_d2(q, kd_lo[b], kd_hi[b]);
-            const uint32_t nearc = dl <= dr ? a : b, farc = dl <= dr ? b : a;
-            const float dn = fminf(dl, dr), df = fmaxf(dl, dr);
-            if (!(df > wd) && sp < STACK) {
-                if (l == 0u) {
-                    st_node[sp][grp] = farc;
-                    st_bound[sp][grp] = df;
-                }
-                ++sp;
-            }
-            if (dn > wd) break;
-            node = nearc;
-        }
-    }
-    /* entries 4 l .. 4 l + 3 of the query's row: the group writes one 128-byte line */
-    reinterpret_cast<uint4*>(lists)[(size_t)qi * 8u + l] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
-}
 
 /* curvature rows from the lists, one thread per query (row t of the caller's order: row_of[t], or t; without a query
  * list the row is the point's original index) */
@@ -1853,8 +1749,9 @@ static int curvature_run(tm_ctx* c, const float* d_cloud, const uint32_t* d_orde
             const float4* d_queries = all ? d_pts.p : d_q.p; /* all: the tree's own points, every one finite */
             for (uint32_t q0 = 0; q0 < n_threads; q0 += kListChunk) {
                 const uint32_t cnt = std::min(kListChunk, n_threads - q0);
-                hipLaunchKernelGGL(k_knn_lists<kLbvhStack>, dim3((cnt + 31u) / 32u), dim3(256), 0, c->stream, d_lo.p, d_hi.p,
-                                   d_pts.p, kk, d_queries + q0, cnt, d_lists);
+                hipLaunchKernelGGL((k_knn_groups<kLbvhStack, knn_queries_f4, knn_sink_rows>), dim3((cnt + 31u) / 32u), dim3(256), 0,
+                                   c->stream, d_lo.p, d_hi.p, d_pts.p, kk, knn_queries_f4{d_queries + q0}, cnt,
+                                   knn_sink_rows{d_lists});
                 hipLaunchKernelGGL(k_curvature_lists, dim3((cnt + 255u) / 256u), dim3(256), 0, c->stream, d_nrm.p, kk,
                                    d_queries + q0, cnt, d_lists, all, d_row_of, q0, d_out.p);
             }
@@ -1962,8 +1859,12 @@ static int cloud_nn_distances_on_device(tm_ctx* c, const float* surfels, uint32_
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && n_fin >= 2) {
         lbvh_build(c, dc.keys.p, d_pts, n_fin, d_lo, d_hi, d_q0, d_q1, d_cnt);
-        hipLaunchKernelGGL((k_knn2<kLbvhStack, true>), dim3((n_fin + 255) / 256), dim3(256), 0, c->stream, d_lo, d_hi, d_pts,
-                           d_pts, n_fin, d_out);
+        if (c->opt.curv_groups) /* eight lanes per point, the second entry of a list of two */
+            hipLaunchKernelGGL((k_knn_groups<kLbvhStack, knn_queries_f4, knn_sink_kth_by_w>), dim3((n_fin + 31u) / 32u), dim3(256),
+                               0, c->stream, d_lo, d_hi, d_pts, 2u, knn_queries_f4{d_pts}, n_fin, knn_sink_kth_by_w{d_out});
+        else
+            hipLaunchKernelGGL((k_knn2<kLbvhStack, true>), dim3((n_fin + 255) / 256), dim3(256), 0, c->stream, d_lo, d_hi, d_pts,
+                               d_pts, n_fin, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
