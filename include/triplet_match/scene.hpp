@@ -341,7 +341,9 @@ struct hip_backend {
         if (n == 0) return;
         std::vector<uint32_t> counts(n);
         std::vector<double> scores(n);
-        size_t stride = std::max<size_t>(batch_stride, 1024);
+        /* rows per pose: what the last call needed (kept across searches), or at first a little more than the model's
+         * size — a good pose matches about one scene point per model point; a short guess costs a second pass */
+        size_t stride = batch_stride ? batch_stride : std::max<size_t>(1024, mcloud ? mcloud->size() + mcloud->size() / 4 : 0);
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (sc_scratch.size() < stride * n) sc_scratch.resize(stride * n);
             if (mc_scratch.size() < stride * n) mc_scratch.resize(stride * n);
@@ -488,6 +490,7 @@ public:
         be.sc_scratch.swap(keep_sc_);
         be.mc_scratch.swap(keep_mc_);
         be.t_pairs.swap(keep_pairs_);
+        be.batch_stride = keep_stride_;
         if (comm_ && tm_comm_world(comm_) > 1) {
             detail::hip_exchange hx{comm_};
             found = search::find_all(be, tangent_mask, be.p, hx);
@@ -497,6 +500,7 @@ public:
         be.sc_scratch.swap(keep_sc_);
         be.mc_scratch.swap(keep_mc_);
         be.t_pairs.swap(keep_pairs_);
+        keep_stride_ = be.batch_stride;
         std::vector<match_t> results;
         for (auto& c : found) {
             match_t r;
@@ -878,6 +882,7 @@ protected:
     std::shared_ptr<detail::context_holder> ctx_;
     tm_scene* h_ = nullptr;
     std::vector<uint32_t> keep_sc_, keep_mc_, keep_pairs_; /* hip_backend staging kept between searches */
+    size_t keep_stride_ = 0;                                /* ... and the rows per pose its batched finish_find needed */
     uint32_t last_projector_searches_ = 0;
     std::vector<uint32_t> tan_idx_; /* tangent points of the current projected scene */
     std::vector<float> tan_rows_;
