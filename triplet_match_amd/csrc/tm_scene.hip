@@ -1008,19 +1008,35 @@ __global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uin
 __global__ __launch_bounds__(256) void k_extract_batch(score_args a, uint32_t n_pad, uint32_t n,
                                                        uint32_t* __restrict__ match_of_orig,
                                                        unsigned long long* __restrict__ count_fx) {
-    uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_pad) return;
-    float4 v = a.spos[s];
-    if (!(v.x == v.x)) return;
+    __shared__ unsigned long long s_fx[4];
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     const uint32_t k = blockIdx.y;
-    const pose12 T = load_pose(a.poses + 16 * (size_t)k);
+    const float4 v = s < n_pad ? a.spos[s] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
     long long fx = 0;
-    uint32_t pass = 0, m = 0xFFFFFFFFu;
-    uint32_t hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
-    if (hit) {
-        match_of_orig[(size_t)k * n + __float_as_uint(v.w)] = m;
-        atomicAdd(&count_fx[2 * (size_t)k + 1], (unsigned long long)fx);
-        atomicAdd(&count_fx[2 * (size_t)k], 1ull);
+    uint32_t hit = 0;
+    if (v.x == v.x) {
+        const pose12 T = load_pose(a.poses + 16 * (size_t)k);
+        uint32_t pass = 0, m = 0xFFFFFFFFu;
+        hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
+        if (hit) match_of_orig[(size_t)k * n + __float_as_uint(v.w)] = m;
+    }
+    /* count and score sum (integers: any order) per workgroup, then one pair of atomics — one pair per match put
+     * ~2e5 atomics per pose on two addresses, 0.17 ms of a 4-pose call */
+    unsigned long long w = hit ? (unsigned long long)fx : 0ull;
+    for (int off = 32; off > 0; off >>= 1) w += (unsigned long long)__shfl_down((long long)w, off);
+    const uint32_t c = (uint32_t)__popcll(__ballot(hit != 0u));
+    if ((threadIdx.x & 63u) == 0u) {
+        s_fx[threadIdx.x >> 6] = w;
+        s_cnt[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t cb = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        if (cb) {
+            atomicAdd(&count_fx[2 * (size_t)k + 1], (s_fx[0] + s_fx[1]) + (s_fx[2] + s_fx[3]));
+            atomicAdd(&count_fx[2 * (size_t)k], (unsigned long long)cb);
+        }
     }
 }
 /* ordered compaction of those matches: ascending scene index = the reference's scan order (finish_find walks 0..n-1,
@@ -1149,27 +1165,32 @@ __device__ void icp_step(const unsigned long long* sums, float* pose, icp_state*
 
 /* st != null (tm_icp_refine): thread 0 goes on with the turn of the loop these sums belong to. One workgroup per
  * candidate (blockIdx.x): partials [cand][n_blocks][16], sums [cand][16], pose [cand][16], st[cand]. */
-__global__ __launch_bounds__(256) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
+constexpr int kIcpFinalizeThreads = 1024; /* 64 slices of the block list x 16 sums: 8 loads per thread for 512 blocks */
+__global__ __launch_bounds__(kIcpFinalizeThreads) void k_icp_finalize(const unsigned long long* __restrict__ partials, uint32_t n_blocks,
                                                       unsigned long long* __restrict__ sums /* [cand][16] */,
                                                       int check_done = 0,
                                                       float* pose = nullptr, icp_state* st = nullptr,
                                                       uint32_t max_iterations = 0, int first = 0) {
-    __shared__ unsigned long long s_part[16][16];
+    constexpr uint32_t kSlices = kIcpFinalizeThreads / 16;
+    __shared__ unsigned long long s_part[kSlices][16];
     const uint32_t cand = blockIdx.x;
     partials += (size_t)cand * n_blocks * 16;
     sums += (size_t)cand * 16;
     if (pose) pose += (size_t)cand * 16;
     if (st) st += cand;
     if (check_done && st && st->done) return;
-    const uint32_t k = threadIdx.x & 15, slice = threadIdx.x >> 4; /* 16 slices of the block list */
+    const uint32_t k = threadIdx.x & 15, slice = threadIdx.x >> 4; /* slices of the block list */
     unsigned long long t = 0;
-    for (uint32_t b = slice; b < n_blocks; b += 16) t += partials[(size_t)b * 16 + k];
+    for (uint32_t b = slice; b < n_blocks; b += kSlices) t += partials[(size_t)b * 16 + k];
     s_part[slice][k] = t;
     __syncthreads();
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < 64) { /* four lanes per sum, 16 slices each, then two shuffles */
+        const uint32_t kk = threadIdx.x & 15, q = threadIdx.x >> 4;
         unsigned long long r = 0;
-        for (int sl = 0; sl < 16; ++sl) r += s_part[sl][threadIdx.x];
-        sums[threadIdx.x] = r;
+        for (uint32_t sl = q * (kSlices / 4); sl < (q + 1) * (kSlices / 4); ++sl) r += s_part[sl][kk];
+        r += (unsigned long long)__shfl_down((long long)r, 32);
+        r += (unsigned long long)__shfl_down((long long)r, 16);
+        if (threadIdx.x < 16) sums[threadIdx.x] = r;
     }
     if (st) {
         __threadfence_block();
@@ -2341,7 +2362,7 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     icp_score_args(s, m, dist_thres, a);
     hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
                        s->w_scores_fx.p + 16);
-    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(256), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(kIcpFinalizeThreads), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
                        s->w_scores_fx.p, 0);
     TM_HIP_CHECK(hipGetLastError());
     unsigned long long h_sums[16];
@@ -2384,7 +2405,7 @@ int tm_icp_refine_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t
     for (uint32_t pass = 0; pass <= max_iterations; ++pass) {
         hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks, n), dim3(256), 0, c->stream, a, s->n_sorted, partials,
                            pass ? st : (const icp_state*)nullptr);
-        hipLaunchKernelGGL(k_icp_finalize, dim3(n), dim3(256), 0, c->stream, partials, icp_blocks, sums, pass ? 1 : 0,
+        hipLaunchKernelGGL(k_icp_finalize, dim3(n), dim3(kIcpFinalizeThreads), 0, c->stream, partials, icp_blocks, sums, pass ? 1 : 0,
                            s->w_poses.p, st, max_iterations, pass == 0 ? 1 : 0);
     }
     TM_HIP_CHECK(hipGetLastError());
