@@ -472,8 +472,8 @@ public:
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
                                            float early_out_factor, const sample_parameters& sample_params,
                                            uint32_t max_icp_iterations) {
-        std::vector<int32_t> tangent_mask;
-        ensure_scene(tangent_mask);
+        ensure_scene();
+        const std::vector<int32_t>& tangent_mask = cached_tmask_; /* tangent_mask_ (:46-54), kept with the device scene */
         detail::hip_backend<Point> be;
         be.s = h_;
         be.m = m.handle();
@@ -493,9 +493,10 @@ public:
         be.batch_stride = keep_stride_;
         if (comm_ && tm_comm_world(comm_) > 1) {
             detail::hip_exchange hx{comm_};
-            found = search::find_all(be, tangent_mask, be.p, hx);
+            found = search::find_all(be, tangent_mask, be.p, hx, nullptr, &keep_ws_);
         } else {
-            found = search::find_all(be, tangent_mask, be.p);
+            search::single_rank one;
+            found = search::find_all(be, tangent_mask, be.p, one, nullptr, &keep_ws_);
         }
         be.sc_scratch.swap(keep_sc_);
         be.mc_scratch.swap(keep_mc_);
@@ -781,7 +782,13 @@ protected:
      * upload + sort for 1M points) is reused while the cloud's CONTENT (a 64-bit hash of the raw surfel bytes,
      * ~5 ms per million points) and the mask settings are unchanged — the reference re-reads cloud_ on every call,
      * so an in-place edit of the points between two calls must be seen; the searches reset mask_ themselves */
+    /* a copy of tangent_mask_ for a caller that edits it (the projected searches) */
     void ensure_scene(std::vector<int32_t>& tangent_mask) {
+        ensure_scene();
+        tangent_mask = cached_tmask_;
+    }
+    /* the device scene and tangent_mask_ (cached_tmask_) for the cloud's current content */
+    void ensure_scene() {
         const uint32_t n = (uint32_t)cloud_->size();
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { /* set_verbose(true): where the scene preparation's time goes */
@@ -794,11 +801,10 @@ protected:
         lap("content hash");
         cloud_->sync(hash); /* curvature computed for other content is forgotten */
         if (h_ && hash != cached_hash_) invalidate();
-        if (h_ && cached_n_ == n && cached_curv_k_ == curvature_k_ && cached_curv_ok_ == curvature_ok_) {
-            tangent_mask = cached_tmask_; /* same content, same settings: the mask is the one already built */
-            return;
-        }
-        tangent_mask.assign(n, 0);
+        if (h_ && cached_n_ == n && cached_curv_k_ == curvature_k_ && cached_curv_ok_ == curvature_ok_)
+            return; /* same content, same settings: the mask is the one already built */
+        std::vector<int32_t> tangent_mask(n, 0);
+        keep_ws_.tangent_indices_valid = false; /* the kept list of tangent points belongs to the old mask */
         if (!detail::env_once().host_curvature_tree) {
             /* tangent_mask_ (:46-54) where the cloud is: the scene goes up with an empty tangent mask, and one call
              * finds the points with |tangent| > 0.7 (and the caller's flag), computes the kNN curvature of exactly
@@ -858,7 +864,7 @@ protected:
             lap("scene on the device");
         }
         cached_n_ = n;
-        cached_tmask_ = tangent_mask;
+        cached_tmask_.swap(tangent_mask);
         cached_hash_ = hash;
         cached_curv_k_ = curvature_k_;
         cached_curv_ok_ = curvature_ok_;
@@ -883,6 +889,7 @@ protected:
     tm_scene* h_ = nullptr;
     std::vector<uint32_t> keep_sc_, keep_mc_, keep_pairs_; /* hip_backend staging kept between searches */
     size_t keep_stride_ = 0;                                /* ... and the rows per pose its batched finish_find needed */
+    search::find_all_workspace keep_ws_;                    /* ... and find_all's masks and list of tangent points */
     uint32_t last_projector_searches_ = 0;
     std::vector<uint32_t> tan_idx_; /* tangent points of the current projected scene */
     std::vector<float> tan_rows_;

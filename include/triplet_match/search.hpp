@@ -948,20 +948,40 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     return arbitrate(std::move(cands), be.scene_size(), tangent_mask, min_points, min_points_all, p.verbose);
 }
 
+/* vectors of find_all a caller may keep between searches over one scene (scene<Point> does): the two masks, and the
+ * indices of the tangent points — valid as long as the tangent mask they were listed from is the one passed in (the
+ * owner clears tangent_indices_valid when it builds another mask) */
+struct find_all_workspace {
+    std::vector<int32_t> mask, fp_mask;
+    std::vector<uint32_t> tangent_indices;
+    bool tangent_indices_valid = false;
+};
+
 /* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
  * inverts them (:92). */
 template <class Backend, class Exchange>
 inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>& tangent_mask,
                                          const params_t& p, Exchange& ex,
-                                         const std::vector<int32_t>* initial_mask = nullptr) {
+                                         const std::vector<int32_t>* initial_mask = nullptr,
+                                         find_all_workspace* keep = nullptr) {
     const uint32_t n = be.scene_size();
     /* mask_ starts empty in the reference (:41-44); the projected searches of one scene pass the points
-     * earlier projectors have already explained */
-    std::vector<int32_t> mask(n, 0), fp_mask(n, 0);
+     * earlier projectors have already explained. With a workspace the two masks are the caller's vectors, cleared
+     * (4 MB each per million points: fresh vectors are fresh pages), and the list of tangent points is taken over
+     * when the caller says it still belongs to this tangent mask. */
+    find_all_workspace local;
+    find_all_workspace& ws = keep ? *keep : local;
+    std::vector<int32_t>&mask = ws.mask, &fp_mask = ws.fp_mask;
+    mask.assign(n, 0);
+    fp_mask.assign(n, 0);
     if (initial_mask) mask = *initial_mask;
-    std::vector<uint32_t> tangent_indices;
-    for (uint32_t i = 0; i < n; ++i)
-        if (tangent_mask[i]) tangent_indices.push_back(i);
+    std::vector<uint32_t>& tangent_indices = ws.tangent_indices;
+    if (!ws.tangent_indices_valid) {
+        tangent_indices.clear();
+        for (uint32_t i = 0; i < n; ++i)
+            if (tangent_mask[i]) tangent_indices.push_back(i);
+        ws.tangent_indices_valid = keep != nullptr;
+    }
     const uint32_t n_scene = (uint32_t)tangent_indices.size();
     TM_TIMED(total);
     be.set_mask(mask);
