@@ -730,32 +730,41 @@ inline std::vector<candidate_t> arbitrate(std::vector<candidate_t> cands, uint32
     });
     std::vector<candidate_t> result;
     std::vector<unsigned char> used(n_scene_points, 0); /* the reference's std::set<uint32_t> used, :198 */
-    for (const auto& cand : cands) { /* greedy disjoint accept, :200-237 */
+    for (auto& cand : cands) { /* greedy disjoint accept, :200-237 */
         candidate_t out;
         out.transform = cand.transform;
         out.signed_score = cand.signed_score;
         /* one pass: the points no accepted candidate holds yet, and how many of them are tangent points; `used`
          * is only written once the candidate is accepted (a rejected one gives its points back, used_copy :203) */
         const size_t n_c = cand.scene_corrs.size();
-        out.scene_corrs.resize(n_c);
-        out.model_corrs.resize(n_c);
         uint32_t score = 0, kept = 0;
         const uint32_t* sc = cand.scene_corrs.data();
         const uint32_t* mc = cand.model_corrs.data();
-        for (size_t k = 0; k < n_c; ++k) {
+        for (size_t k = 0; k < n_c; ++k) { /* counted first: a candidate that overlaps nothing keeps its lists as they are */
             const uint32_t idx = sc[k];
             if (used[idx]) continue;
-            out.scene_corrs[kept] = idx;
-            out.model_corrs[kept] = mc[k];
             ++kept;
             score += tangent_mask[idx] ? 1u : 0u;
         }
-        out.scene_corrs.resize(kept);
-        out.model_corrs.resize(kept);
+        if (kept == n_c) {
+            out.scene_corrs = std::move(cand.scene_corrs);
+            out.model_corrs = std::move(cand.model_corrs);
+        } else {
+            out.scene_corrs.resize(kept);
+            out.model_corrs.resize(kept);
+            uint32_t at = 0;
+            for (size_t k = 0; k < n_c; ++k) {
+                const uint32_t idx = sc[k];
+                if (used[idx]) continue;
+                out.scene_corrs[at] = idx;
+                out.model_corrs[at] = mc[k];
+                ++at;
+            }
+        }
         const uint32_t score_all = kept;
         if (verbose)
             fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
-                    cand.scene_corrs.size(), score_all, score, min_points, score_all, min_points_all);
+                    n_c, score_all, score, min_points, score_all, min_points_all);
         if (score < min_points || score_all < min_points_all) continue; /* :227 */
         for (uint32_t idx : out.scene_corrs) used[idx] = 1;
         result.push_back(std::move(out));
