@@ -1391,6 +1391,58 @@ def test_cloud_neighbour_queries_equal_oracle_and_scipy(gpu_ctx, small_case, clo
     assert (cnt == 5).all() and (idx[:, 5:] == -1).all() and np.isinf(d2[:, 5:]).all()
 
 
+def _brute_knn(points, queries, k):
+    """k smallest (d2, index) per query with d2 = (dx*dx + dy*dy) + dz*dz in float32, as the kernels form it"""
+    P = points.astype(np.float32)
+    idx = np.full((len(queries), k), -1, np.int32)
+    d2 = np.full((len(queries), k), np.inf, np.float32)
+    for t, q in enumerate(queries.astype(np.float32)):
+        d = P - q
+        v = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        order = np.lexsort((np.arange(len(P)), v))[:k]
+        idx[t, :len(order)] = order
+        d2[t, :len(order)] = v[order]
+    return idx, d2
+
+
+def test_neighbour_lists_with_many_ties(gpu_ctx, cloud_tree_route, curv_walk):
+    """clouds made of ties: an integer lattice (dozens of points at every distance), the same point a hundred times,
+    collinear points, a lattice stored twice — the k nearest come out in (d2, index) order on every route (tree on the
+    device / host, eight lanes per query / one thread per query), equal to a numpy scan of all points; k from 1 to the
+    list's capacity, more neighbours asked than there are points, queries on and off the lattice"""
+    rng = np.random.default_rng(21)
+    g = np.arange(9, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    lattice = lattice[rng.permutation(len(lattice))]
+    clouds = {
+        "lattice": lattice,
+        "lattice twice": np.concatenate([lattice, lattice[::-1]]),
+        "one point": np.tile(np.array([[0.5, -1.0, 2.0]], np.float32), (100, 1)),
+        "collinear": np.stack([np.arange(300, dtype=np.float32) % 50, np.zeros(300, np.float32), np.zeros(300, np.float32)], 1),
+        "few": lattice[:5],
+    }
+    for name, pts in clouds.items():
+        surfels = np.zeros((len(pts), 12), np.float32)
+        surfels[:, 0:3] = pts
+        surfels[:, 3] = 1.0
+        surfels[:, 6] = 1.0
+        gc = capi.Cloud(gpu_ctx, surfels)
+        queries = np.concatenate([pts[rng.integers(0, len(pts), 24)], pts[:8] + np.float32(0.5),
+                                  (rng.random((8, 3)) * 8).astype(np.float32)])
+        for k in (1, 2, 7, 27, 30, 32):
+            idx, d2, cnt = gc.knn(queries, k)
+            bi, bd = _brute_knn(pts, queries, k)
+            assert np.array_equal(idx, bi), (name, k)
+            assert np.array_equal(d2.view(np.uint32), bd.view(np.uint32)), (name, k)
+            assert (cnt == min(k, len(pts))).all()
+        # the curvature pass walks the same lists (self included): its rows agree between the routes by the other tests;
+        # here the lists' k-th distance is what cloud->resolution() reads with k = 2 — zero wherever a point has a twin
+        if len(pts) >= 2:
+            res, nn = gpu_ctx.cloud_resolution(surfels)
+            bi, bd = _brute_knn(pts, pts, 2)
+            assert np.array_equal(nn.view(np.uint32), np.sqrt(bd[:, 1]).astype(np.float32).view(np.uint32)), name
+
+
 def test_gpu_curvature_and_resolution_against_scipy_and_numpy(gpu_ctx, curv_walk):
     """tm_cloud_curvature / tm_cloud_resolution (kd-tree kNN kernel, own Jacobi) against the float64 scipy cKDTree +
     numpy.linalg.eigh vectors of tests/golden/curvature_20k.npz — an answer that passes through none of our code"""
