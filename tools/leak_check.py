@@ -14,7 +14,8 @@ def used():
     free, total = torch.cuda.mem_get_info(0)
     return (total - free) / 1e6
 base = None
-for it in range(30):
+N_IT = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for it in range(N_IT):
     gm = capi.Model(ctx, model, res); gm.build_voxels(); gm.build_pairs(subset)
     gs = capi.Scene(ctx, S, np.zeros(len(S), np.int32))
     idx = np.nonzero(tm)[0].astype(np.uint32)
@@ -32,6 +33,6 @@ for it in range(30):
     if it == 4: base = u
     cached = ctx.pool_stats()[0] / 1e6  # released blocks the context keeps for reuse (option pool_mib) are not a leak
     if it == 4: base_live = u - cached
-    if it in (4, 29): print("iteration %d: %.0f MB in use, %.0f MB of it in the context's block cache" % (it, u, cached))
+    if it == 4 or it % 25 == 4 or it == N_IT - 1: print("iteration %d: %.0f MB in use, %.0f MB of it in the context's block cache" % (it, u, cached))
 print("growth after warm-up: %.1f MB (outside the block cache: %.1f MB); cache reused %d requests, hipMalloc served %d"
       % (used() - base, used() - ctx.pool_stats()[0] / 1e6 - base_live, ctx.pool_stats()[1], ctx.pool_stats()[2]))
