@@ -77,7 +77,7 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
  * score_parts, score_slot_mib, item_sort, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
  * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
- * ed_prefix_group, score_off32, pool_mib, voxel_packet, curv_groups, model_host_build, search_step_check (DESIGN.md section 6 says what each selects).
+ * ed_prefix_group, score_off32, pool_mib, voxel_packet, voxel_seed, curv_groups, model_host_build, search_step_check (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */

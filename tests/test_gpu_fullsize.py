@@ -82,6 +82,11 @@ def test_voxel_grid_full_size(gpu_ctx, full):
     assert np.array_equal(vox, vb)
     del vb
     gb.close()
+    with gpu_ctx.option("voxel_seed", 0):  # ... the packets without their super-brick's candidate
+        gu = capi.Model(gpu_ctx, full["model"], full["res"])
+        gu.build_voxels()
+        assert np.array_equal(vox, gu.voxels())
+        gu.close()
     with gpu_ctx.option("voxel_packet", 0):  # ... and the per-voxel descent == the packet descent (the default)
         gp = capi.Model(gpu_ctx, full["model"], full["res"])
         gp.build_voxels()

@@ -665,6 +665,11 @@ def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
         ka, kh = a.table(), h.table()
         assert all(np.array_equal(x, y) for x, y in zip(ka, kh)) and len(ka[0]) > 10  # same order -> same table
         h.close()
+    with gpu_ctx.option("voxel_seed", 0):  # the packets start without the super-brick's candidate
+        u = capi.Model(gpu_ctx, model, res)
+        u.build_voxels()
+        assert np.array_equal(va, u.voxels())
+        u.close()
     with gpu_ctx.option("voxel_packet", 0):  # every voxel on its own stack instead of a brick's 64 as one packet
         c = capi.Model(gpu_ctx, model, res)
         c.build_voxels()

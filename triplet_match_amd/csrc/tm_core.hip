@@ -186,6 +186,7 @@ static const opt_entry kOptions[] = {
     {"scene_morton", &options::scene_morton, 0, 1},
     {"voxel_bruteforce", &options::voxel_bruteforce, 0, 1},
     {"voxel_packet", &options::voxel_packet, 0, 1},
+    {"voxel_seed", &options::voxel_seed, 0, 1},
     {"curv_groups", &options::curv_groups, 0, 1},
     {"model_host_build", &options::model_host_build, 0, 1},
     {"ed_one_kernel", &options::ed_one_kernel, 0, 1},

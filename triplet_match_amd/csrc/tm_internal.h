@@ -118,6 +118,7 @@ struct options {
     int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
     int voxel_packet = 1;     /* 0: kd descent per voxel on per-thread stacks instead of one packet per brick */
+    int voxel_seed = 1;       /* 0: the packet walk of the voxel grid starts without a candidate */
     int curv_groups = 1;      /* 0: the curvature pass's neighbour lists one thread per query (lists in LDS) instead of eight lanes per query */
     int model_host_build = 0; /* 1: tm_model_create sorts the cloud and builds a median kd-tree on the host (cross-check) */
     int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;

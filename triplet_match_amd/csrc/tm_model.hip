@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void k_voxel_nn_packet(const float4* __restric
                                                          const uint32_t* __restrict__ new2orig, grid_t g,
                                                          uint64_t voxel_slots, int bx, int by,
                                                          uint32_t* __restrict__ voxels,
-                                                         uint32_t* __restrict__ brick_min_bits) {
+                                                         uint32_t* __restrict__ brick_min_bits,
+                                                         const uint32_t* __restrict__ seed /* per super-brick, or null */,
+                                                         const float4* __restrict__ pos /* model points by new index */) {
     __shared__ uint32_t st_node[4][kKdPacketStack];
     const uint32_t wave = threadIdx.x >> 6;
     const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -226,6 +228,20 @@ __global__ __launch_bounds__(256) void k_voxel_nn_packet(const float4* __restric
     q[2] = isz * (float)k + (-(g.tz * isz));
     float best = __builtin_inff();
     uint32_t besti = 0xFFFFFFFFu, besto = 0xFFFFFFFFu;
+    if (seed) {
+        /* every lane starts from one real candidate — the model point nearest to the centre of the brick's 16^3-voxel
+         * super-brick (k_voxel_seed_queries + one k-nearest walk per super-brick, 1/4096 of the voxels) — instead of
+         * from nothing: the descent that only FINDS a first bound is gone, what remains is the part that proves it
+         * (11.2 -> 8.5 ms per 1.7e8 voxels; the voxel's own answer as the seed: 8.0). A candidate is a candidate: it
+         * loses to any point with a smaller d2, or an equal d2 and a lower original index, and no subtree that could
+         * hold such a point is skipped (its box distance does not exceed this bound). */
+        const uint32_t si = seed[brick >> 6];
+        const float4 P = pos[si];
+        const float dx = P.x - q[0], dy = P.y - q[1], dz = P.z - q[2];
+        best = (dx * dx + dy * dy) + dz * dz;
+        besti = si;
+        besto = new2orig[si];
+    }
     if (__ballot(live)) { /* wave-uniform: a brick with no voxel in the grid has nothing to find */
         int sp = 1;
         if ((threadIdx.x & 63u) == 0u) st_node[wave][0] = 0u;
@@ -281,6 +297,24 @@ __global__ __launch_bounds__(256) void k_voxel_nn_packet(const float4* __restric
     for (int off = 32; off > 0; off >>= 1) bmin = min(bmin, (uint32_t)__shfl_down((int)bmin, off));
     if ((threadIdx.x & 63) == 0 && slot < voxel_slots) brick_min_bits[slot >> 6] = bmin;
 }
+
+/* the centre voxel (8, 8, 8) of every super-brick as a query point, in model space (the voxel kernels' formula) */
+__global__ __launch_bounds__(256) void k_voxel_seed_queries(grid_t g, int bx, int by, uint32_t n_super, float4* __restrict__ q) {
+    const uint32_t sb = blockIdx.x * 256 + threadIdx.x;
+    if (sb >= n_super) return;
+    const uint32_t sk = sb / (uint32_t)(bx * by), sr = sb - sk * (uint32_t)(bx * by);
+    const uint32_t sj = sr / (uint32_t)bx, si = sr - sj * (uint32_t)bx;
+    const uint32_t i = (si << 4) + 8u, j = (sj << 4) + 8u, k = (sk << 4) + 8u;
+    const float isx = 1.0f / g.sx, isy = 1.0f / g.sy, isz = 1.0f / g.sz;
+    q[sb] = make_float4(isx * (float)i + (-(g.tx * isx)), isy * (float)j + (-(g.ty * isy)), isz * (float)k + (-(g.tz * isz)), 0.f);
+}
+/* the nearest point's index (the tree's w) per query */
+struct knn_sink_first {
+    uint32_t* out;
+    __device__ void operator()(uint32_t qi, float4, uint32_t l, const float*, const uint32_t ix[4], float) const {
+        if (l == 0u) out[qi] = ix[0];
+    }
+};
 
 /* second-smallest squared distance from each point to the cloud (the point itself included, as
  * nearestKSearch(pnt, 2) does): same box-pruned kd descent, bound = current second best. STACK > 32 (the device-built
@@ -2114,9 +2148,30 @@ int tm_model_build_voxels(tm_model* m) {
         TM_REQUIRE(kd_blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
         /* a brick's 64 voxels as one packet (default), or every voxel on its own stack (voxel_packet = 0: the
          * cross-check; identical tables) */
-        hipLaunchKernelGGL(c->opt.voxel_packet ? k_voxel_nn_packet : k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0,
-                           c->stream, m->kd_lo.p, m->kd_hi.p, m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots,
-                           m->bdim[0], m->bdim[1], m->voxels.p, m->brick_min_bits.p);
+        if (c->opt.voxel_packet) {
+            /* voxel_seed (default): one candidate per super-brick from a k-nearest walk of its centre */
+            dbuf<float4> d_sq;
+            dbuf<uint32_t> d_seed;
+            const uint32_t n_super = n_bricks >> 6;
+            const bool seeded = c->opt.voxel_seed && d_sq.alloc(n_super) == TM_OK && d_seed.alloc(n_super) == TM_OK;
+            if (seeded) {
+                hipLaunchKernelGGL(k_voxel_seed_queries, dim3((n_super + 255) / 256), dim3(256), 0, c->stream, m->grid, m->bdim[0],
+                                   m->bdim[1], n_super, d_sq.p);
+                hipLaunchKernelGGL((k_knn_groups<kLbvhStack, knn_queries_f4, knn_sink_first>),
+                                   dim3((n_super + (uint32_t)kKnnGroupsPerBlock - 1u) / (uint32_t)kKnnGroupsPerBlock), dim3(256), 0,
+                                   c->stream, m->kd_lo.p, m->kd_hi.p, m->kd_pts.p, 1u, knn_queries_f4{d_sq.p}, n_super,
+                                   knn_sink_first{d_seed.p});
+            }
+            hipLaunchKernelGGL(k_voxel_nn_packet, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_lo.p, m->kd_hi.p,
+                               m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p,
+                               m->brick_min_bits.p, seeded ? d_seed.p : (const uint32_t*)nullptr, m->pos.p);
+            d_sq.release(); /* stream-ordered reuse: the blocks go back to the context's cache behind the kernels */
+            d_seed.release();
+        } else {
+            hipLaunchKernelGGL(k_voxel_nn_kd, dim3((uint32_t)kd_blocks), dim3(256), 0, c->stream, m->kd_lo.p, m->kd_hi.p,
+                               m->kd_pts.p, m->new2orig.p, m->grid, m->voxel_slots, m->bdim[0], m->bdim[1], m->voxels.p,
+                               m->brick_min_bits.p);
+        }
     }
     TM_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_brick_codes, dim3((n_bricks + 255) / 256), dim3(256), 0, c->stream,
