@@ -504,6 +504,38 @@ def measured_traffic(args):
     return None
 
 
+def preprocessing_extra(ctx, model, res, scene, gs):
+    """SURVEY 8(f) row 1 at the bench's sizes, whole C-ABI calls (host buffers in, host results out), best of three:
+    kNN-30 curvature of the scene's tangent candidates on the scene's device copy (what tangent_mask_ needs), of all
+    points of the model; cloud->resolution() of the model; the voxel grid and the pair table of a new model."""
+    from triplet_match_amd import capi
+
+    def best(fn, reps=3):
+        b = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            b = min(b, time.perf_counter() - t0)
+        return round(b * 1e3, 3)
+
+    S = scene["surfels"]
+    cand = np.nonzero(np.linalg.norm(S[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+    subset = np.nonzero(np.linalg.norm(model[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+    out = {"scene_points": int(len(S)), "scene_tangent_candidates": int(len(cand)), "model_points": int(len(model)),
+           "curvature_k": 30, "unit": "ms"}
+    try:
+        out["scene_candidates_curvature_ms"] = best(lambda: gs.curvature_subset(cand, 30))
+        out["model_curvature_all_points_ms"] = best(lambda: ctx.cloud_curvature(model, 30))
+        out["model_resolution_ms"] = best(lambda: ctx.cloud_resolution(model))
+        gm2 = capi.Model(ctx, model, res)
+        out["model_voxel_grid_ms"] = best(gm2.build_voxels, reps=2)
+        out["model_pair_table_ms"] = best(lambda: gm2.build_pairs(subset), reps=2)
+        gm2.close()
+    except Exception as e:  # an extra must not take the line down
+        out["error"] = str(e)
+    return out
+
+
 def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_hyp, dist_thres, accept_prob):
     """(1) early_drop_ball: the batch scored the way find_in_subset scores (include/impl/scene.hpp:273,326,
     492-506): every hypothesis on nn = radius_search_inclusive(model diameter, its first sample point) with
@@ -524,6 +556,7 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
         cnt, _, dropped, saved = gs.score_hypotheses_early_drop_ball(gm, poses, centers, gm.diameter, dist_thres,
                                                                     accept_prob)
         dt = time.perf_counter() - t0
+        out["preprocessing"] = preprocessing_extra(ctx, model, res, scene, gs)
         out["early_drop_ball"] = {"value": round(n_hyp / dt, 1), "unit": "hypotheses/s", "ms": round(dt * 1e3, 3),
                                   "hypotheses": int(n_hyp), "dropped_fraction": round(float((dropped >= 0).mean()), 4),
                                   "max_inliers": int(cnt.max()),
