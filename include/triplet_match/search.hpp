@@ -730,23 +730,36 @@ inline std::vector<candidate_t> arbitrate(std::vector<candidate_t> cands, uint32
     });
     std::vector<candidate_t> result;
     std::vector<unsigned char> used(n_scene_points, 0); /* the reference's std::set<uint32_t> used, :198 */
-    for (auto& cand : cands) { /* greedy disjoint accept, :200-237 */
+    /* the tangent points among each candidate's correspondences do not depend on the order of acceptance: counted side
+     * by side (the gathers from a 4 MB mask are most of the greedy loop's time); the loop below then only asks
+     * `used`, and counts again only for a candidate that overlaps an accepted one */
+    std::vector<uint32_t> tangent_of(cands.size(), 0);
+    ::triplet_match::detail::worker_pool::instance().run(cands.size(), [&](size_t c) {
+        uint32_t t = 0;
+        for (uint32_t idx : cands[c].scene_corrs) t += tangent_mask[idx] ? 1u : 0u;
+        tangent_of[c] = t;
+    });
+    for (size_t ci = 0; ci < cands.size(); ++ci) { /* greedy disjoint accept, :200-237 */
+        candidate_t& cand = cands[ci];
         candidate_t out;
         out.transform = cand.transform;
         out.signed_score = cand.signed_score;
-        /* one pass: the points no accepted candidate holds yet, and how many of them are tangent points; `used`
-         * is only written once the candidate is accepted (a rejected one gives its points back, used_copy :203) */
+        /* the points no accepted candidate holds yet, and how many of them are tangent points; `used` is only
+         * written once the candidate is accepted (a rejected one gives its points back, used_copy :203) */
         const size_t n_c = cand.scene_corrs.size();
         uint32_t score = 0, kept = 0;
         const uint32_t* sc = cand.scene_corrs.data();
         const uint32_t* mc = cand.model_corrs.data();
-        for (size_t k = 0; k < n_c; ++k) { /* counted first: a candidate that overlaps nothing keeps its lists as they are */
-            const uint32_t idx = sc[k];
-            if (used[idx]) continue;
-            ++kept;
-            score += tangent_mask[idx] ? 1u : 0u;
-        }
+        for (size_t k = 0; k < n_c; ++k) kept += used[sc[k]] ? 0u : 1u;
         if (kept == n_c) {
+            score = tangent_of[ci]; /* overlaps nothing: every correspondence counts */
+        } else {
+            for (size_t k = 0; k < n_c; ++k) {
+                const uint32_t idx = sc[k];
+                if (!used[idx]) score += tangent_mask[idx] ? 1u : 0u;
+            }
+        }
+        if (kept == n_c) { /* ... and the candidate keeps its lists as they are */
             out.scene_corrs = std::move(cand.scene_corrs);
             out.model_corrs = std::move(cand.model_corrs);
         } else {
