@@ -1,6 +1,6 @@
 /*
  * triplet_match/traits.hpp — the *_traits plugin surface (identity / plane / plane2 / cylinder) of the
- * drop-in API. Mirrors include/{identity,plane,plane2,cylinder}_traits (+ impl/*.hpp): state_t,
+ * drop-in API. Mirrors include/{identity,plane,plane2,cylinder}_traits (+ the impl/ headers): state_t,
  * handle_t, const_handle_t, sample_count, samples_t and the seven statics, all over the C ABI
  * (tm_traits_*). In this snapshot of the reference the traits are compiled but not wired into
  * model<>/scene<>; here a projected search is wired by projecting the clouds with
