@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
+#include <new>
 #include <map>
 #include <mutex>
 #include <string>
@@ -256,6 +258,65 @@ struct tm_model {
     std::vector<uint32_t> h_voxels_cache; /* lazily downloaded for tm_model_voxel_query */
 };
 
+namespace tmx {
+/* Host mirror of a per-point int32 mask. An all-zero mask (every new scene starts with two) comes from calloc — fresh zero
+ * pages that nothing touches until a helper reads them — instead of a 4 MB memset per million points, and says so
+ * (all_zero), so that its device copy is a memset as well instead of an upload. */
+class mask_mirror {
+public:
+    mask_mirror() = default;
+    ~mask_mirror() { free(p_); }
+    mask_mirror(const mask_mirror&) = delete;
+    mask_mirror& operator=(const mask_mirror& o) {
+        if (this != &o) assign(o.p_, o.p_ + o.n_);
+        return *this;
+    }
+    void assign(size_t n, int32_t v) {
+        free(p_);
+        p_ = static_cast<int32_t*>(v == 0 ? calloc(n ? n : 1, 4) : malloc((n ? n : 1) * 4));
+        if (!p_) throw std::bad_alloc();
+        n_ = n;
+        zero_ = v == 0;
+        if (v != 0) std::fill(p_, p_ + n, v);
+    }
+    void assign(const int32_t* b, const int32_t* e) {
+        const size_t n = (size_t)(e - b);
+        int32_t* q = static_cast<int32_t*>(malloc((n ? n : 1) * 4));
+        if (!q) throw std::bad_alloc();
+        if (n) memcpy(q, b, n * 4);
+        free(p_);
+        p_ = q;
+        n_ = n;
+        zero_ = false;
+    }
+    void resize(size_t n) { /* content unspecified beyond the old size (callers overwrite it) */
+        if (n == n_) return;
+        int32_t* q = static_cast<int32_t*>(realloc(p_, (n ? n : 1) * 4));
+        if (!q) throw std::bad_alloc();
+        p_ = q;
+        n_ = n;
+        zero_ = false;
+    }
+    int32_t* data() { /* a writer may follow */
+        zero_ = false;
+        return p_;
+    }
+    const int32_t* data() const { return p_; }
+    int32_t& operator[](size_t i) {
+        zero_ = false;
+        return p_[i];
+    }
+    const int32_t& operator[](size_t i) const { return p_[i]; }
+    size_t size() const { return n_; }
+    bool all_zero() const { return zero_; } /* known to be all zero (false = unknown) */
+
+private:
+    int32_t* p_ = nullptr;
+    size_t n_ = 0;
+    bool zero_ = false;
+};
+}  // namespace tmx
+
 struct tm_scene {
     tm_ctx* ctx = nullptr;
     uint32_t n = 0;
@@ -263,7 +324,7 @@ struct tm_scene {
      * reads a row (tmx::scene_mirror): copying it at creation cost 6.5 ms of a 9 ms tm_scene_create per million
      * points, and the drop-in search never reads it */
     mutable std::vector<float> h_cloud;
-    std::vector<int32_t> h_tmask, h_mask;
+    tmx::mask_mirror h_tmask, h_mask;
     /* A projected scene (tm_scene_create_projected) keeps its host mirror SPARSE: the host side of the search only
      * ever reads the surfels of tangent points (sample filters), so only those come back from the device — 1.7 MB
      * instead of 48 MB per projector at 1M points. h_tan_idx ascending, h_tan_rows 12 floats each; h_cloud stays

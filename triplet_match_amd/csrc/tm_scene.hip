@@ -1938,12 +1938,14 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
     TM_GUARD(s);
     TM_REQUIRE(s, TM_ERR_INVALID, "null scene");
     TM_HIP_CHECK(hipSetDevice(s->ctx->device));
-    if (mask)
+    if (mask) {
         s->h_mask.assign(mask, mask + s->n);
-    else
+        TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, static_cast<const tmx::mask_mirror&>(s->h_mask).data(), (size_t)s->n * 4,
+                                    hipMemcpyHostToDevice, s->ctx->stream));
+    } else {
         s->h_mask.assign(s->n, 0);
-    TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)s->n * 4, hipMemcpyHostToDevice,
-                                s->ctx->stream));
+        TM_HIP_CHECK(hipMemsetAsync(s->d_mask.p, 0, (size_t)s->n * 4, s->ctx->stream));
+    }
     return scene_build(s, false);
 }
 

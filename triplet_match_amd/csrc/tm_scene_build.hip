@@ -387,8 +387,12 @@ int scene_upload(tm_scene* s, const float* surfels) {
     /* surfels = the caller's buffer (tm_scene_create); null = the cloud is on the device already */
     if (surfels)
         TM_HIP_CHECK(hipMemcpyAsync(s->d_cloud.p, surfels, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, s->h_tmask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, s->h_mask.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    /* an all-zero mask (every new scene has two) is set on the device, not sent */
+    const tmx::mask_mirror &ht = s->h_tmask, &hm = s->h_mask;
+    if (ht.all_zero()) TM_HIP_CHECK(hipMemsetAsync(s->d_tmask.p, 0, (size_t)n * 4, c->stream));
+    else TM_HIP_CHECK(hipMemcpyAsync(s->d_tmask.p, ht.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (hm.all_zero()) TM_HIP_CHECK(hipMemsetAsync(s->d_mask.p, 0, (size_t)n * 4, c->stream));
+    else TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, hm.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     return TM_OK;
 }
 
