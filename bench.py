@@ -586,7 +586,7 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                                "-Wl,-rpath," + libdir, "-pthread"])
         # early drop on, 10 ICP iterations, the search repeated once on the kept scene, two frames with a new cloud, then
         # a stream of new clouds on 1..4 host threads with a context each
-        r = subprocess.run([exe, fx, "1", "10", "1", "0", "2", "4"], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, fx, "1", "10", "1", "0", "2", "6"], capture_output=True, text=True, timeout=300)
         os.unlink(fx)
         os.unlink(exe)
         import re
@@ -605,7 +605,7 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                 "note": "drop-in scene<Point>::find_all_parallel, early drop on, 10 ICP iterations, curvature masks on; "
                         "second call = the same search again with the prepared scene kept on the device; new_cloud_frame_s = "
                         "new cloud + new scene object + search (upload, curve order, tangent_mask_ on the device); "
-                        "stream_frames_per_s = such frames worked off by 1..4 host threads with a context (stream) each"}
+                        "stream_frames_per_s = such frames worked off by 1..6 host threads with a context (stream) each"}
         else:
             log("extras: e2e demo output not understood:\n" + r.stdout[-800:] + r.stderr[-800:])
     except Exception as exc:
