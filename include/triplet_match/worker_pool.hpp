@@ -19,12 +19,14 @@ namespace detail {
 
 /* The reference starts hardware_concurrency() - 1 std::async tasks per find_parallel call
  * (include/impl/scene.hpp:146-166); a thread per chunk and round cost more than the 1.6 ms of sampling it spread
- * out. run(n, fn) calls fn(0 .. n-1), the caller taking part, and returns when all are done; one batch at a time.
- * The threads are created on first use and joined when the process exits.
- * A task that throws (on the caller's thread or on a worker) does not tear anything down: the first exception is
- * kept, the indices not yet started are passed over, run() waits until every thread has left the batch and rethrows
- * on the caller — as the reference's fut.get() would (:168-171). run() from inside a task (a pooled task that hashes
- * a cloud, say) runs inline on that thread instead of waiting for the pool it is part of. */
+ * out. run(n, fn) calls fn(0 .. n-1), the caller taking part, and returns when all are done. Batches of different
+ * callers are open side by side (searches on several host threads, each with its context, share these workers: with
+ * one batch at a time a search waited for another search's hash before it could sample its own chunks); a worker
+ * takes indices of the oldest open batch. The threads are created on first use and joined when the process exits.
+ * A task that throws (on the caller's thread or on a worker) does not tear anything down: the first exception of its
+ * batch is kept, the indices not yet started are passed over, run() waits until every thread has left the batch and
+ * rethrows on the caller — as the reference's fut.get() would (:168-171). run() from inside a task (a pooled task
+ * that hashes a cloud, say) runs inline on that thread instead of waiting for the pool it is part of. */
 class worker_pool {
 public:
     static worker_pool& instance() {
@@ -37,31 +39,34 @@ public:
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
-        std::lock_guard<std::mutex> one_batch(run_mutex_);
+        batch b;
+        b.fn = &fn;
+        b.n = n;
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn;
-            total_ = n;
-            next_.store(0);
-            done_ = 0;
-            failed_.store(false);
-            error_ = nullptr;
-            ++generation_;
+            open_.push_back(&b);
         }
         cv_.notify_all();
-        work(fn, n);
+        work(b);
         std::exception_ptr err;
         {
             std::unique_lock<std::mutex> lk(m_);
-            cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
-            job_ = nullptr;
-            err = error_;
-            error_ = nullptr;
+            close(b); /* every index has been handed out */
+            cv_done_.wait(lk, [&] { return b.done == b.n && b.active == 0; });
+            err = b.error;
         }
         if (err) std::rethrow_exception(err);
     }
 
 private:
+    struct batch {
+        const std::function<void(size_t)>* fn = nullptr;
+        size_t n = 0;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+        size_t done = 0, active = 0; /* under m_: indices finished; workers (not the caller) inside the batch */
+        std::exception_ptr error;    /* under m_ */
+    };
     worker_pool() {
         const unsigned hw = std::thread::hardware_concurrency();
         const unsigned n = hw > 1 ? std::min(6u, hw - 1u) : 0u;
@@ -79,62 +84,59 @@ private:
         static thread_local bool flag = false;
         return flag;
     }
-    void work(const std::function<void(size_t)>& fn, size_t n) {
+    /* m_ held: the batch takes no more workers */
+    void close(batch& b) {
+        auto it = std::find(open_.begin(), open_.end(), &b);
+        if (it != open_.end()) open_.erase(it);
+    }
+    void work(batch& b) {
         size_t finished = 0;
         std::exception_ptr err;
         bool& nested = in_task();
         nested = true;
         for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= n) break;
-            if (!failed_.load(std::memory_order_relaxed)) {
+            const size_t i = b.next.fetch_add(1);
+            if (i >= b.n) break;
+            if (!b.failed.load(std::memory_order_relaxed)) {
                 try {
-                    fn(i);
+                    (*b.fn)(i);
                 } catch (...) {
                     if (!err) err = std::current_exception();
-                    failed_.store(true);
+                    b.failed.store(true);
                 }
             }
-            ++finished; /* an index passed over after a failure still counts: run() waits for done_ == total_ */
+            ++finished; /* an index passed over after a failure still counts: run() waits for done == n */
         }
         nested = false;
         if (finished || err) {
             std::lock_guard<std::mutex> lk(m_);
-            done_ += finished;
-            if (err && !error_) error_ = err;
+            b.done += finished;
+            if (err && !b.error) b.error = err;
         }
     }
     void loop() {
-        uint64_t seen = 0;
         for (;;) {
-            const std::function<void(size_t)>* fn = nullptr;
-            size_t n = 0;
+            batch* b = nullptr;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (generation_ != seen && job_ != nullptr); });
+                cv_.wait(lk, [&] { return stop_ || !open_.empty(); });
                 if (stop_) return;
-                seen = generation_;
-                fn = job_;
-                n = total_;
-                ++active_;
+                b = open_.front();
+                ++b->active; /* its caller does not return before this is back at zero */
             }
-            work(*fn, n);
+            work(*b);
             {
                 std::lock_guard<std::mutex> lk(m_);
-                --active_;
+                close(*b); /* work() returned: no index left */
+                --b->active;
             }
             cv_done_.notify_all();
         }
     }
     std::vector<std::thread> threads_;
-    std::mutex m_, run_mutex_;
+    std::mutex m_;
     std::condition_variable cv_, cv_done_;
-    const std::function<void(size_t)>* job_ = nullptr;
-    size_t total_ = 0, done_ = 0, active_ = 0;
-    std::atomic<size_t> next_{0};
-    std::atomic<bool> failed_{false};
-    std::exception_ptr error_;
-    uint64_t generation_ = 0;
+    std::vector<batch*> open_; /* batches that still hand out indices, oldest first */
     bool stop_ = false;
 };
 

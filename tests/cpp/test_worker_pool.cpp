@@ -38,6 +38,36 @@ int main() {
         other.join();
         failures += (int)(sums[0].load() + sums[1].load());
     }
+    {   // six callers at once (searches on six host threads share the pool): batches of different lengths open side by
+        // side, one of the callers' tasks throwing now and then — every batch sees each of its indices once and only
+        // its own exception
+        std::atomic<int> bad{0};
+        auto caller = [&](int who) {
+            for (int rep = 0; rep < 200; ++rep) {
+                const size_t n = (size_t)(3 + 17 * who + rep % 5);
+                std::vector<std::atomic<int>> hit(n);
+                for (auto& h : hit) h.store(0);
+                const bool throws = who == 2 && rep % 7 == 0;
+                bool caught = false;
+                try {
+                    pool.run(n, [&](size_t i) {
+                        hit[i].fetch_add(1);
+                        if (throws && i == 1) throw std::runtime_error("mine");
+                    });
+                } catch (const std::runtime_error&) {
+                    caught = true;
+                }
+                if (caught != throws) bad.fetch_add(1);
+                for (size_t i = 0; i < n; ++i)
+                    if (hit[i].load() > 1 || (!throws && hit[i].load() != 1)) bad.fetch_add(1);
+            }
+        };
+        std::vector<std::thread> others;
+        for (int who = 1; who < 6; ++who) others.emplace_back(caller, who);
+        caller(0);
+        for (auto& t : others) t.join();
+        failures += bad.load();
+    }
     {   // a task that throws is the caller's business (find_parallel catches inside the task); the pool must go on
         std::atomic<int> ran{0};
         pool.run(8, [&](size_t i) {
