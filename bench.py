@@ -603,6 +603,8 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                                         re.findall(r"stream: \d+ frames on (\d+) threads?, a context each: ([0-9.]+) frames/s",
                                                    r.stdout)} or None,
                 "note": "drop-in scene<Point>::find_all_parallel, early drop on, 10 ICP iterations, curvature masks on; "
+                        "model_init_s is the process's first use of the library: it includes the HIP start-up behind the first "
+                        "context (~0.1 s; a further model<Point>::init is extras.preprocessing's 14 ms); "
                         "second call = the same search again with the prepared scene kept on the device; new_cloud_frame_s = "
                         "new cloud + new scene object + search (upload, curve order, tangent_mask_ on the device); "
                         "stream_frames_per_s = such frames worked off by 1..6 host threads with a context (stream) each"}
