@@ -88,6 +88,40 @@ struct single_rank {
     }
 };
 
+/* What a search did, entry by entry, filled when params_t::trace points at one (tests compare it with the traces of
+ * the reference text restated in Python, tests/golden/search_trace_*.json.gz): per find_parallel round the RANSAC
+ * bound and the sampled first points (:131-150), per chunk and first point the neighbourhood size, inner bound
+ * (:276-279), positions drawn and valid second points (:288-305), the chunk's first sufficient hypothesis (:330-338)
+ * and `cons` (:271), the candidates after icp_ (:169-171) and the accepted matches (:200-237). */
+struct trace_first {
+    uint32_t i = 0, nn = 0;
+    uint64_t inner_bound = 0, draws = 0;
+    bool sampled = false; /* false: skipped because the chunk already had its candidate */
+    std::vector<uint32_t> js;
+};
+struct trace_chunk {
+    std::vector<uint32_t> firsts_in;
+    std::vector<trace_first> firsts;
+    uint32_t cons = 0;
+    bool hit = false;
+    pose_t hit_pose;
+};
+struct trace_match {
+    pose_t transform;
+    std::vector<uint32_t> scene_corrs, model_corrs;
+    double signed_score = 0.0;
+};
+struct trace_round {
+    uint64_t left = 0, outer_bound = 0, batch_size = 0;
+    uint32_t min_points = 0, min_points_all = 0;
+    std::vector<uint32_t> outer;
+    std::vector<trace_chunk> chunks;
+    std::vector<trace_match> candidates, accepted;
+};
+struct trace_t {
+    std::vector<trace_round> rounds;
+};
+
 struct params_t {
     float dist_thres = 3.f;
     float accept_prob = 0.5f; /* model_match_factor */
@@ -108,6 +142,8 @@ struct params_t {
     uint32_t min_tangent_inliers = 0;
     bool verbose = false;   /* progress lines on stderr (the reference prints pdebug lines) */
     stats_t* stats = nullptr;
+    trace_t* trace = nullptr;             /* whole search */
+    trace_chunk* trace_chunk_ = nullptr;  /* set per chunk by find_parallel */
 };
 
 /*
@@ -555,7 +591,10 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             bool found = false;
             if (detail::fused_batch(be, batch_ij, be.model_diameter(), p.early_drop, sufficient, hit, found,
                                     detail::has_search_batch<Backend>{})) {
-                if (found) best_ts.push_back(hit);
+                if (found) {
+                    best_ts.push_back(hit);
+                    if (p.trace_chunk_) p.trace_chunk_->hit = true, p.trace_chunk_->hit_pose = hit;
+                }
                 batch_ij.clear();
                 return;
             }
@@ -566,7 +605,10 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             for (size_t h = 0; h < poses.size(); ++h) centers[h] = batch_ij[2 * (size_t)pair_of_hyp[h]];
             be.score_ball(poses, centers, be.model_diameter(), p.early_drop, counts, scores);
             const long h = first_sufficient(poses, counts, scores);
-            if (h >= 0) best_ts.push_back(poses[(size_t)h]);
+            if (h >= 0) {
+                best_ts.push_back(poses[(size_t)h]);
+                if (p.trace_chunk_) p.trace_chunk_->hit = true, p.trace_chunk_->hit_pose = poses[(size_t)h];
+            }
         }
         batch_ij.clear();
     };
@@ -595,6 +637,12 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         uint64_t inner_bound = (uint64_t)(-std::log(1.0 - match_probability) / prob); /* :277 */
         inner_bound = std::max(inner_bound, min_sample_count);
         inner_bound = std::min<uint64_t>(inner_bound, n_nn);
+        trace_first* tf = nullptr;
+        if (p.trace_chunk_) {
+            p.trace_chunk_->firsts.emplace_back();
+            tf = &p.trace_chunk_->firsts.back();
+            tf->i = i, tf->nn = (uint32_t)n_nn, tf->inner_bound = inner_bound;
+        }
         if (!best_ts.empty()) continue; /* the reference keeps looping without effect once a candidate
                                            exists (best_ts.empty() gates :331; early-out is unreachable,
                                            SURVEY Q8): skip the dead work, keep `cons` */
@@ -604,6 +652,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
          * what this definition fixes (range-v3's action::shuffle is unpinned). */
         ij.clear();
         uint32_t valid_samples = 0;
+        if (tf) tf->sampled = true;
         {
         TM_TIMED(sample);
         if (p.stats) {
@@ -616,6 +665,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
             shuffled.reset(t_pairs, n_t_pairs, n_nn);
             for (size_t k = 0; k < n_nn; ++k) {
                 if (p.stats) ++p.stats->draws;
+                if (tf) ++tf->draws;
                 if (k + 1 < n_nn) {
                     const size_t r = k + (size_t)(rng() % (uint32_t)(n_nn - k));
                     if (r != k) {
@@ -639,6 +689,7 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         inner0.assign(nn_ptr, nn_ptr + n_nn); /* a copy is shuffled (:284-285): project_ scans nn in its own order */
         for (size_t k = 0; k < n_nn; ++k) {
             if (p.stats) ++p.stats->draws;
+            if (tf) ++tf->draws;
             if (k + 1 < n_nn) {
                 const size_t r = k + (size_t)(rng() % (uint32_t)(n_nn - k));
                 std::swap(inner0[k], inner0[r]);
@@ -653,6 +704,8 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         }
         }
         }
+        if (tf)
+            for (size_t e = 1; e < ij.size(); e += 2) tf->js.push_back(ij[e]);
         if (ij.empty()) continue;
         if (batched) {
             batch_ij.insert(batch_ij.end(), ij.begin(), ij.end());
@@ -672,9 +725,13 @@ inline std::pair<std::vector<candidate_t>, uint32_t> find_in_subset(
         be.score(poses, nn, p.early_drop, counts, scores); /* project_ on nn, :326 */
         /* :330-338: score > best_score(=0) and #corrs > accept_prob * |model cloud| */
         const long h = first_sufficient(poses, counts, scores);
-        if (h >= 0) best_ts.push_back(poses[(size_t)h]);
+        if (h >= 0) {
+            best_ts.push_back(poses[(size_t)h]);
+            if (p.trace_chunk_) p.trace_chunk_->hit = true, p.trace_chunk_->hit_pose = poses[(size_t)h];
+        }
     }
     if (batched) flush_batch();
+    if (p.trace_chunk_) p.trace_chunk_->cons = cons;
     std::vector<candidate_t> matches;
     TM_TIMED(extract);
     for (size_t k = 0; k < best_ts.size() && matches.size() < 5; ++k) { /* :361-364 */
@@ -801,6 +858,12 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     std::vector<uint32_t> left;
     for (uint32_t idx : tangent_indices)
         if (!fp_mask[idx] && !mask[idx]) left.push_back(idx); /* :131 */
+    trace_round* tr = nullptr;
+    if (p.trace) {
+        p.trace->rounds.emplace_back();
+        tr = &p.trace->rounds.back();
+        tr->left = left.size(), tr->min_points = min_points, tr->min_points_all = min_points_all;
+    }
     if (left.empty()) return {};
     double outer_prob = (double)n_model / (double)left.size();
     uint64_t outer_bound;
@@ -819,6 +882,19 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     const uint32_t concurrency = std::max(1u, p.workers); /* :146 */
     uint64_t batch = outer_bound / concurrency;
     if (outer_bound % concurrency > 0) ++batch;
+    if (tr) {
+        tr->outer_bound = outer_bound, tr->batch_size = batch, tr->outer = outer;
+        tr->chunks.resize(batch ? (size_t)((outer.size() + batch - 1) / batch) : 0);
+        for (size_t ci = 0; ci < tr->chunks.size(); ++ci)
+            tr->chunks[ci].firsts_in.assign(outer.begin() + ci * batch,
+                                            outer.begin() + std::min<uint64_t>((ci + 1) * batch, outer.size()));
+    }
+    /* the parameters of chunk ci: the caller's, with that chunk's trace slot */
+    auto chunk_params = [&](size_t ci) {
+        params_t pl = p;
+        pl.trace_chunk_ = tr ? &tr->chunks[ci] : nullptr;
+        return pl;
+    };
     std::vector<candidate_t> cands;
     if (ex.world() > 1) {
         /* Several ranks: the chunks are independent of one another inside a round (a chunk reads fp_mask_
@@ -837,7 +913,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             chunks[ci].assign(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
         }
         for (uint32_t ci = rank; ci < n_chunks; ci += world) {
-            auto res = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, p);
+            auto res = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, chunk_params(ci));
             chunk_record& r = local[ci / world];
             r.considered = res.second;
             if (!res.first.empty()) { /* at most one per chunk: the first sufficient hypothesis */
@@ -887,7 +963,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             cons_of.assign(chunks.size(), 0u);
             ::triplet_match::detail::worker_pool::instance().run(chunks.size(), [&](size_t ci) {
                 try {
-                    params_t pl = p;
+                    params_t pl = chunk_params(ci);
                     pl.stats = p.stats ? &chunk_stats[ci] : nullptr;
                     cons_of[ci] = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, pl, &chunk_batches[ci]).second;
                 } catch (...) {
@@ -908,7 +984,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         } else {
             for (size_t ci = 0; ci < chunks.size(); ++ci) {
                 first_batch_of.push_back((uint32_t)batches.size());
-                auto res = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, p, &batches);
+                auto res = find_in_subset(be, chunks[ci], mask, fp_mask, tangent_mask, chunk_params(ci), &batches);
                 cons_of.push_back(res.second);
             }
         }
@@ -928,6 +1004,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             for (uint32_t b = first_batch_of[ci]; b < first_batch_of[ci + 1]; ++b)
                 if (found[b]) {
                     starts.push_back(poses[b]);
+                    if (tr) tr->chunks[ci].hit = true, tr->chunks[ci].hit_pose = poses[b];
                     break;
                 }
         }
@@ -958,7 +1035,7 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
     } else
     for (uint64_t c0 = 0; c0 < outer.size(); c0 += batch) { /* chunks, :156-166 (run one after another) */
         std::vector<uint32_t> chunk(outer.begin() + c0, outer.begin() + std::min<uint64_t>(c0 + batch, outer.size()));
-        auto res = find_in_subset(be, chunk, mask, fp_mask, tangent_mask, p);
+        auto res = find_in_subset(be, chunk, mask, fp_mask, tangent_mask, chunk_params((size_t)(c0 / batch)));
         uint32_t cons = res.second;
         if (p.verbose)
             fprintf(stderr, "[search] chunk of %zu firsts: %u considered, %zu candidate(s)%s\n", chunk.size(), cons,
@@ -967,7 +1044,13 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
         for (auto& mt : res.first) cands.push_back(icp(be, mt, p)); /* :169-171 */
     }
     TM_TIMED(arbitration);
-    return arbitrate(std::move(cands), be.scene_size(), tangent_mask, min_points, min_points_all, p.verbose);
+    auto to_trace = [](const std::vector<candidate_t>& from, std::vector<trace_match>& to) {
+        for (const auto& c : from) to.push_back(trace_match{c.transform, c.scene_corrs, c.model_corrs, c.signed_score});
+    };
+    if (tr) to_trace(cands, tr->candidates);
+    auto accepted = arbitrate(std::move(cands), be.scene_size(), tangent_mask, min_points, min_points_all, p.verbose);
+    if (tr) to_trace(accepted, tr->accepted);
+    return accepted;
 }
 
 /* vectors of find_all a caller may keep between searches over one scene (scene<Point> does): the two masks, and the

@@ -170,6 +170,72 @@ static pointcloud<P>::Ptr read_cloud(std::ifstream& in) {
     return c;
 }
 
+/* the search's trace as JSON, in the layout of tests/golden/search_trace_*.json.gz (oracle/ref_search.py) */
+static unsigned long long fnv_u32(const std::vector<uint32_t>& v) {
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char* d = (const unsigned char*)v.data();
+    for (size_t k = 0; k < v.size() * 4; ++k) h = (h ^ d[k]) * 1099511628211ull;
+    return h;
+}
+static void write_pose(FILE* f, const search::pose_t& T) {
+    fputc('[', f);
+    for (int k = 0; k < 16; ++k) {
+        uint32_t b;
+        memcpy(&b, &T.m[k], 4);
+        fprintf(f, "%s%u", k ? "," : "", b);
+    }
+    fputc(']', f);
+}
+static void write_matches(FILE* f, const char* name, const std::vector<search::trace_match>& v) {
+    fprintf(f, "\"%s\":[", name);
+    for (size_t k = 0; k < v.size(); ++k) {
+        fprintf(f, "%s{\"pose\":", k ? "," : "");
+        write_pose(f, v[k].transform);
+        fprintf(f, ",\"n\":%zu,\"scene\":\"%016llx\",\"model\":\"%016llx\",\"score\":%.17g}", v[k].scene_corrs.size(),
+                fnv_u32(v[k].scene_corrs), fnv_u32(v[k].model_corrs), v[k].signed_score);
+    }
+    fputc(']', f);
+}
+static void write_trace(const char* path, const search::trace_t& t) {
+    FILE* f = fopen(path, "w");
+    if (!f) exit(6);
+    fprintf(f, "{\"rounds\":[");
+    for (size_t r = 0; r < t.rounds.size(); ++r) {
+        const auto& R = t.rounds[r];
+        fprintf(f, "%s{\"left\":%llu,\"min_points\":%u,\"min_points_all\":%u,\"outer_bound\":%llu,\"batch_size\":%llu,\"outer\":[",
+                r ? "," : "", (unsigned long long)R.left, R.min_points, R.min_points_all, (unsigned long long)R.outer_bound,
+                (unsigned long long)R.batch_size);
+        for (size_t k = 0; k < R.outer.size(); ++k) fprintf(f, "%s%u", k ? "," : "", R.outer[k]);
+        fprintf(f, "],\"chunks\":[");
+        for (size_t c = 0; c < R.chunks.size(); ++c) {
+            const auto& C = R.chunks[c];
+            fprintf(f, "%s{\"cons\":%u,\"firsts\":[", c ? "," : "", C.cons);
+            for (size_t k = 0; k < C.firsts.size(); ++k) {
+                const auto& F = C.firsts[k];
+                fprintf(f, "%s{\"i\":%u,\"nn\":%u,\"inner_bound\":%llu,\"draws\":%llu,\"sampled\":%s,\"js\":[", k ? "," : "", F.i,
+                        F.nn, (unsigned long long)F.inner_bound, (unsigned long long)F.draws, F.sampled ? "true" : "false");
+                for (size_t e = 0; e < F.js.size(); ++e) fprintf(f, "%s%u", e ? "," : "", F.js[e]);
+                fprintf(f, "]}");
+            }
+            fprintf(f, "],\"hit\":");
+            if (C.hit) {
+                fprintf(f, "{\"pose\":");
+                write_pose(f, C.hit_pose);
+                fputc('}', f);
+            } else
+                fprintf(f, "null");
+            fputc('}', f);
+        }
+        fprintf(f, "],");
+        write_matches(f, "candidates", R.candidates);
+        fputc(',', f);
+        write_matches(f, "accepted", R.accepted);
+        fputc('}', f);
+    }
+    fprintf(f, "]}\n");
+    fclose(f);
+}
+
 static void dump(const char* tag, const std::vector<search::candidate_t>& r) {
     printf("%s: %zu candidates\n", tag, r.size());
     for (const auto& c : r)
@@ -182,7 +248,11 @@ int main(int argc, char** argv) {
     const bool both = std::string(argv[2]) == "both" || std::string(argv[2]) == "both_noearlydrop";
     /* "sharded <dir> <rank> <world>": this process is one rank of a rank-sharded search over the oracle */
     const bool sharded = std::string(argv[2]) == "sharded" && argc >= 6;
-    const bool no_early_drop = std::string(argv[2]) == "both_noearlydrop" || std::string(argv[2]) == "oracle_noearlydrop";
+    /* "trace_oracle|trace_hip <out.json> <max_icp_iterations> <early_drop 0|1> <workers>": run one search over that backend
+     * and write its trace (tests/test_search_traces.py compares it with the committed traces of the Python restatement) */
+    const bool trace_oracle = std::string(argv[2]) == "trace_oracle" && argc >= 7;
+    const bool trace_hip = std::string(argv[2]) == "trace_hip" && argc >= 7;
+    bool no_early_drop = std::string(argv[2]) == "both_noearlydrop" || std::string(argv[2]) == "oracle_noearlydrop";
     std::ifstream in(argv[1], std::ios::binary);
     auto mcloud = read_cloud(in);
     auto scloud = read_cloud(in);
@@ -218,7 +288,44 @@ int main(int argc, char** argv) {
     p.accept_prob = 0.5f;
     p.max_icp_iterations = 2;
     p.workers = 4;
+    if (trace_oracle || trace_hip) {
+        p.max_icp_iterations = (uint32_t)atoi(argv[4]);
+        no_early_drop = atoi(argv[5]) == 0;
+        p.workers = (uint32_t)atoi(argv[6]);
+    }
     p.early_drop = !no_early_drop;
+    if (trace_hip) { /* the product alone: model<P>::init and the scene on the device, search.hpp over the HIP backend */
+        discretization_params dp;
+        dp.distance_step_count = 20.f;
+        dp.angle_step = angle_step;
+        mcloud->set_resolution(res);
+        model<P> gm(mcloud, dp);
+        sample_parameters sp;
+        gm.init(sp);
+        if (gm.point_count() != subset.size()) {
+            printf("FAIL model<P>::init subset (%u) differs from the oracle's masks (%zu)\n", gm.point_count(), subset.size());
+            return 1;
+        }
+        tm_scene* gs = nullptr;
+        detail::check(tm_scene_create(gm.context(), scloud->points[0].raw(), (uint32_t)scloud->size(), tmask.data(), &gs),
+                      "tm_scene_create");
+        detail::hip_backend<P> hb;
+        hb.s = gs;
+        hb.m = gm.handle();
+        hb.scloud = scloud.get();
+        hb.mcloud = mcloud.get();
+        hb.n_t = gm.point_count();
+        hb.diam = gm.diameter();
+        hb.p = p;
+        search::trace_t tr;
+        p.trace = &tr;
+        auto rg = search::find_all(hb, tmask, p);
+        dump("hip backend", rg);
+        write_trace(argv[3], tr);
+        tm_scene_destroy(gs);
+        printf("PASSED (trace written)\n");
+        return 0;
+    }
 
     oracle_backend ob;
     ob.m = tmo_model_create(mcloud->points[0].raw(), (uint32_t)mcloud->size(), res, 20.f, angle_step);
@@ -231,6 +338,17 @@ int main(int argc, char** argv) {
     ob.p = p;
     ob.tmask = tmask;
     std::vector<search::candidate_t> ro;
+    if (trace_oracle) {
+        search::trace_t tr;
+        p.trace = &tr;
+        ro = search::find_all(ob, tmask, p);
+        dump("oracle backend", ro);
+        write_trace(argv[3], tr);
+        tmo_scene_destroy(ob.s);
+        tmo_model_destroy(ob.m);
+        printf("PASSED (trace written)\n");
+        return 0;
+    }
     if (sharded) {
         file_exchange fx{argv[3], atoi(argv[4]), atoi(argv[5])};
         ro = search::find_all(ob, tmask, p, fx);
