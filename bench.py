@@ -5,8 +5,15 @@ One "step" = one pass of the hot path over one batch of synthetic input, all inp
 in HBM: hypothesis generation from a batch of scene sample pairs (descriptor -> hashed match ->
 base transform, <= 200 poses per pair, capped at 65,536) -> inlier scoring of every hypothesis
 against the whole scene -> best-(count, score, pose) record (+ one RCCL all-gather of the 96-byte
-records when N > 1). Workload = BASELINE.json configs[1]: identity traits, 100k-pt model, 1M-pt
-scene, 64k hypotheses per batch. Data: seeded synthetic clouds (triplet_match_amd/synth.py).
+records when N > 1). Workload (--workload, default c2 = BASELINE.json configs[1], the configuration the metric is quoted on: identity
+traits, 100k-pt model, 1M-pt scene, 64k hypotheses per batch). The other single-GPU-sized configurations run
+through the same code path and print the same line (roofline + cpu_baseline):
+  c3 = configs[2] cylinder_traits, 500k-pt pipe plant (scene and model projected into the cylinder's uvw space
+       on the device, scoring under the wrap-around metric);
+  c4 = configs[3] plane2_traits, 1M-pt indoor scan (2-D metric);
+  c5 = configs[4] 32 models x 4M-pt scene: a step = one 64k batch per model (32 scoring launches) and ONE reduce
+       of the 32 per-model best records.
+Data: seeded synthetic clouds (triplet_match_amd/synth.py).
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); scene / model / table are
 replicated, sample pairs are sharded round-robin, every rank scores its own 64k batch (weak scaling).
@@ -38,6 +45,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="BASELINE.json configs[1] (default, the headline), [2], [3] or [4]")
     ap.add_argument("--model-points", type=int, default=100_000)
     ap.add_argument("--scene-points", type=int, default=1_000_000)
     ap.add_argument("--hyp-per-batch", type=int, default=65_536)
@@ -103,46 +112,28 @@ def main():
     mode = {"auto": capi.SCORE_AUTO, "brute": capi.SCORE_BRUTEFORCE, "culled": capi.SCORE_CULLED}[args.mode]
     DIST_THRES, ACCEPT_PROB = 3.0, 0.5
 
-    # ---- synthetic inputs (identical on every rank) ----
-    t0 = time.time()
-    model, subset = synth.synth_model(args.model_points, seed=1)
-    res = synth.resolution(model)
-    scene = synth.synth_scene(args.scene_points, args.model_points, seed=2, copies=args.copies,
-                              model_resolution=res)
-    log("[rank %d] synth %.1fs: model %d (tangent %d), scene %d (tangent %d), resolution %.5f"
-        % (rank, time.time() - t0, model.shape[0], len(subset), scene["surfels"].shape[0],
-           int(scene["tangent_mask"].sum()), res))
-
-    # ---- device setup (not timed: model init is a one-off) ----
-    ctx = capi.Context(local_rank)
-    t0 = time.time()
-    gm = capi.Model(ctx, model, res)
-    gm.build_voxels()
-    t_vox = time.time() - t0
-    t0 = time.time()
-    gm.build_pairs(subset)
-    t_pairs = time.time() - t0
-    gs = capi.Scene(ctx, scene["surfels"], scene["tangent_mask"])
-    pc = gm.pair_counts()
-    ext, _ = gm.grid()
-    log("[rank %d] model init: voxels %s in %.2fs, pair table %d entries / %d keys in %.2fs"
-        % (rank, list(ext), t_vox, pc["entries"], pc["distinct_keys"], t_pairs))
-
-    # ---- scene sample pairs (seeded, RANSAC visit order), sharded round-robin over ranks ----
+    # ---- the workload: clouds (identical on every rank), model(s) and scene on the device, sample pairs ----
     H = args.hyp_per_batch
-    n_first = max(64, H // 400)
-    pairs_all = synth.sample_scene_pairs(scene, gm.diameter, n_first * world, 24, seed=13)
-    pairs = tmd.shard_pairs(pairs_all, rank, world)
-    d_ij = ctx.alloc(max(pairs.nbytes, 8))
-    ctx.h2d(d_ij, pairs)
+    W = prepare_workload(args, ctx_factory=lambda: capi.Context(local_rank), rank=rank, world=world, log=log)
+    ctx, units, gs = W["ctx"], W["units"], W["gs"]
+    u0 = units[0]
+    gm, pairs, model, res, subset, scene = u0["gm"], u0["pairs"], u0["M"], u0["res"], u0["subset"], W["scene"]
     d_poses = ctx.alloc(H * 64)
     d_prov = ctx.alloc(H * 16)
     d_counts = ctx.alloc(H * 4)
     d_scores = ctx.alloc(H * 8)
-    n_hyp, total = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
-    log("[rank %d] %d sample pairs -> %d hypotheses (%d before the batch cap)" % (rank, len(pairs), n_hyp, total))
-    if n_hyp < H:
-        log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (n_hyp, H))
+    for u in units:
+        u["d_ij"] = ctx.alloc(max(u["pairs"].nbytes, 8))
+        ctx.h2d(u["d_ij"], u["pairs"])
+        u["n_hyp"], total = u["gs"].generate_hypotheses_dev(u["gm"], u["d_ij"], len(u["pairs"]), d_poses, d_prov, H)
+        log("[rank %d] %s: %d sample pairs -> %d hypotheses (%d before the batch cap)"
+            % (rank, u["name"], len(u["pairs"]), u["n_hyp"], total))
+        if u["n_hyp"] < H:
+            log("warning: batch not full (%d < %d); throughput is reported for the hypotheses scored" % (u["n_hyp"], H))
+    # the buffers hold the LAST unit's batch after the loop; the single-unit helpers below (early-drop figure, CPU
+    # baseline) work on unit 0's batch, which step() leaves there when there is one unit and which is regenerated
+    # for them otherwise
+    n_hyp = u0["n_hyp"]
 
     if args.ed_profile:
         out = early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, DIST_THRES, ACCEPT_PROB, reps=3, parity=False)
@@ -192,7 +183,9 @@ def main():
         if comm is not None:
             comm_route = "tm_best_reduce"
     comm_world = int(capi.lib().tm_comm_world(comm.h)) if comm is not None else 1
-    d_best = ctx.alloc(96)
+    n_units = len(units)
+    d_best = ctx.alloc(96 * n_units)
+    import ctypes
 
     class _First:
         def __init__(self, pending):
@@ -202,22 +195,27 @@ def main():
             return self._p.result()[0]
 
     def step():
-        n, _ = gs.generate_hypotheses_dev(gm, d_ij, len(pairs), d_poses, d_prov, H)
-        gs.score_hypotheses_dev(gm, d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode)
-        # local argmax on the device with ids that do not depend on the number of ranks (global sample pair
-        # index * query_limit + entry), then ONE ncclAllGather of the 96-byte records on the library's stream,
-        # the deterministic selection and an asynchronous copy of the winner into pinned memory
-        # (tm_best_reduce_begin): nothing here waits for the GPU. The wait (tm_best_reduce_end) happens in
-        # .result(), which the timed loop calls only after the NEXT batch has been queued.
-        ctx.best_of_batch_prov(d_counts, d_scores, d_poses, d_prov, n, d_best, pair_offset=rank, pair_stride=world,
-                               query_limit=200)
+        # one batch per unit (one unit = one model; c5 has 32), everything on the context's one stream: generation,
+        # scoring under the unit's metric, local argmax on the device with ids that do not depend on the number of
+        # ranks (global sample pair index * query_limit + entry) into the unit's 96-byte record; then ONE
+        # ncclAllGather of the n_units records on the library's stream, the deterministic selection per model and an
+        # asynchronous copy of the winners into pinned memory (tm_best_reduce_begin): nothing here waits for the GPU.
+        # The wait (tm_best_reduce_end) happens in .result(), which the timed loop calls only after the NEXT step has
+        # been queued.
+        total = 0
+        for k, u in enumerate(units):
+            n, _ = u["gs"].generate_hypotheses_dev(u["gm"], u["d_ij"], len(u["pairs"]), d_poses, d_prov, H)
+            u["gs"].score_hypotheses_dev(u["gm"], d_poses, n, DIST_THRES, d_counts, d_scores, mode=mode, traits=u["K"])
+            ctx.best_of_batch_prov(d_counts, d_scores, d_poses, d_prov, n, ctypes.c_void_p(d_best.value + 96 * k),
+                                   pair_offset=rank, pair_stride=world, query_limit=200)
+            total += n
         if comm is not None or world == 1:
-            return n, _First(capi.best_reduce_begin(ctx, comm, d_best, 1))
+            return total, _First(capi.best_reduce_begin(ctx, comm, d_best, n_units))
         # rehearsal of N ranks on one GPU (RCCL refuses two ranks per device) or no usable RCCL: the same
-        # records through torch.distributed
+        # records through torch.distributed (first unit's record; the rehearsal is plumbing, not a measurement)
         rec = capi.BestRecord()
         ctx.d2h(np.frombuffer(rec, dtype=np.uint8), d_best)
-        return n, tmd.allgather_best_async(rec, device=cuda_dev)
+        return total, tmd.allgather_best_async(rec, device=cuda_dev)
 
     def sync_all():
         if world > 1:
@@ -237,7 +235,7 @@ def main():
     if args.warmup > 0:
         cnt = ctx.score_timing_totals()
         ctx.enable_timing(False)
-        if cnt["launches"] != args.warmup:
+        if cnt["launches"] != args.warmup * n_units:
             cnt = None
     # kernel timing = HIP events recorded on the library's own stream around each scoring launch; read AFTER the
     # timed region. Inside it the host waits once per step, for the PREVIOUS step's 96-byte winner (an event behind
@@ -260,8 +258,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     tot = ctx.score_timing_totals()
     ctx.enable_timing(False)
-    if tot["launches"] != args.steps:
-        log("warning: %d timed scoring launches for %d steps" % (tot["launches"], args.steps))
+    if tot["launches"] != args.steps * n_units:
+        log("warning: %d timed scoring launches for %d steps of %d unit(s)" % (tot["launches"], args.steps, n_units))
     if cnt:  # per-launch counters of the warm-up window, scaled to the timed launches (same batch every step)
         f = tot["launches"] / float(cnt["launches"])
         for k in ("evaluations", "passing", "in_grid", "near", "staged_chunks"):
@@ -292,7 +290,7 @@ def main():
     #              orientation records per distance-passing point, 64 B pose per hypothesis
     L = max(1, tot["launches"])
     k_ms = tot["ms"] / L
-    E, P, Hh = evals / L, passing / L, hyps / args.steps
+    E, P, Hh = evals / L, passing / L, hyps / float(L)
     N_in, N_near = tot["in_grid"] / L, tot["near"] / L
     alg_bytes = 40.0 * E + 32.0 * P + 64.0 * Hh
     N_items = tot["staged_chunks"] / L
@@ -334,6 +332,21 @@ def main():
                 "physical_bytes_per_launch": phys_bytes, "achieved_physical": round(achieved_phys, 1),
                 "frac_physical": round(achieved_phys / HBM_PEAK_GBS, 4),
                 "measured_copy_GBs": copy_gbs}
+    # The two figures that actually bound this kernel (review of round 4): VALU issue and the rate of random lines.
+    #   valu_issue_frac = wave-level VALU instructions x 4 cycles (a wave64 op occupies its SIMD16 for four) over
+    #                     1024 SIMDs x shader cycles, both counted under the profiler;
+    #   line_rate_frac  = fabric lines per second of this run over the rate at which this chip delivers uniformly
+    #                     random 128-B lines to all CUs (tools/ubench_l2.hip, profiles/r04/ubench_l2.txt): 3.12 ns per
+    #                     line and CU out of an Infinity-Cache-resident table, 4.59 ns out of HBM.
+    if pmc and pmc.get("sq_insts_valu") and pmc.get("shader_cycles_per_launch"):
+        roofline["valu_issue_frac"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
+    if pmc and pmc.get("l2_fabric_read_requests"):
+        lines_per_s = pmc["l2_fabric_read_requests"] / k_s
+        roofline["line_rate_frac"] = round(lines_per_s / (256.0 / 3.12e-9), 4)
+        roofline["line_rate_frac_hbm_resident"] = round(lines_per_s / (256.0 / 4.59e-9), 4)
+        roofline["line_rate_basis"] = ("L2->fabric lines / kernel time over the measured random-line rate of "
+                                       "tools/ubench_l2.hip (profiles/r04/ubench_l2.txt): 8.2e10 lines/s out of the "
+                                       "Infinity Cache, 5.6e10 out of HBM")
     if pmc:
         # how much of a fetched voxel line is used: 4 B per near point over the 128-B lines the voxel gathers
         # bring in (fabric lines of the kernel minus those of the same kernel with its voxel index folded into
@@ -350,15 +363,19 @@ def main():
     # sub-figures measured after the headline region (rank 0, N = 1): the reference's default inner loop
     # (project_ on the neighbourhood of the first sample point, with the early-drop rule) on the same batch,
     # and the whole drop-in search scene<Point>::find_all_parallel on the same clouds
+    if n_units > 1 and rank == 0 and world == 1:  # the buffers hold the last unit's batch: put unit 0's back
+        n_hyp, _ = u0["gs"].generate_hypotheses_dev(gm, u0["d_ij"], len(pairs), d_poses, d_prov, H)
+        u0["gs"].score_hypotheses_dev(gm, d_poses, n_hyp, DIST_THRES, d_counts, d_scores, mode=mode, traits=u0["K"])
     extras = None
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "c2":
         extras = run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_hyp, DIST_THRES,
                             ACCEPT_PROB)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU leg runs at N = 1 only
         cpu_baseline = run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp,
-                                        DIST_THRES, ACCEPT_PROB, pairs=pairs, d_prov=d_prov)
+                                        DIST_THRES, ACCEPT_PROB, pairs=pairs, d_prov=d_prov, K=u0["K"], radius=u0["radius"],
+                                        unit_note=("" if n_units == 1 else "model 0 of the %d; " % n_units))
 
     if rank == 0 and cpu_baseline is not None and not cpu_baseline["gpu_counts_equal_oracle_on_sample"]:
         log("FATAL: the GPU's inlier counts differ from the oracle's on the sampled hypotheses; no value is reported")
@@ -370,9 +387,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "identity_traits: %d-pt model / %d-pt scene, %d hypotheses/batch, full-scene scoring"
-                       % (args.model_points, args.scene_points, H),
-                       "hypotheses_per_batch_scored": int(hyps / args.steps), "dist_thres": DIST_THRES,
+            "config": {"workload": W["description"], "baseline_config": args.workload,
+                       "models_per_step": n_units,
+                       "hypotheses_per_step_scored": int(hyps / args.steps), "dist_thres": DIST_THRES,
                        "query_limit": 200, "score_mode": args.mode, "parallelism": "hyp-shard x%d" % world},
             "comm_route": comm_route, "comm_world": comm_world, "per_rank_ms_per_step": per_rank_ms,
             "gpoints_per_s": round(evals_all / elapsed / 1e9, 2),
@@ -392,6 +409,131 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pick_cylinder_samples(s, sel, rng):
+    """two points of the selected surface with clearly different normals (cylinder_traits::init_from_samples takes two)"""
+    idx = np.nonzero(sel)[0]
+    a = int(idx[rng.integers(len(idx))])
+    for _ in range(1000):
+        b = int(idx[rng.integers(len(idx))])
+        if abs(float(s[a, 4:7] @ s[b, 4:7])) < 0.3:
+            return [a, b]
+    raise SystemExit("no cylinder sample pair")
+
+
+def _pick_plane_samples(s, sel, rng):
+    idx = np.nonzero(sel)[0]
+    for _ in range(1000):
+        a, b, c = (int(idx[k]) for k in rng.integers(len(idx), size=3))
+        d1, d2 = s[b, 0:3] - s[a, 0:3], s[c, 0:3] - s[a, 0:3]
+        if np.linalg.norm(np.cross(d1, d2)) > 0.5 * np.linalg.norm(d1) * np.linalg.norm(d2) > 0.05:
+            return [a, b, c]
+    raise SystemExit("no plane sample triple")
+
+
+def prepare_workload(args, ctx_factory, rank, world, log):
+    """Clouds, model(s) and scene on the device, and this rank's share of the scene sample pairs, for one of the
+    BASELINE.json configurations. Returns dict(ctx, gs, scene (what is scored: surfels + tangent_mask, in the
+    projector's uvw space for c3 / c4), units, description); a unit = one model: dict(name, gm, gs, K (traits kind),
+    radius, M (model cloud as scored), res, subset, pairs). tools/report_configs.py goes through here too."""
+    from triplet_match_amd import capi, synth
+    from triplet_match_amd import dist as tmd
+    H = args.hyp_per_batch
+    t0 = time.time()
+    ctx = ctx_factory()
+    wl = args.workload
+
+    def init_model(M, res, subset, K=0, radius=0.0):
+        t1 = time.time()
+        gm = capi.Model(ctx, M, res)
+        if K:
+            gm.set_metric(K, radius)
+        gm.build_voxels()
+        t_vox = time.time() - t1
+        t1 = time.time()
+        gm.build_pairs(subset)
+        return gm, t_vox, time.time() - t1
+
+    if wl == "c2":
+        model, subset = synth.synth_model(args.model_points, seed=1)
+        res = synth.resolution(model)
+        scene = synth.synth_scene(args.scene_points, args.model_points, seed=2, copies=args.copies, model_resolution=res)
+        log("[rank %d] synth %.1fs: model %d (tangent %d), scene %d (tangent %d), resolution %.5f"
+            % (rank, time.time() - t0, model.shape[0], len(subset), scene["surfels"].shape[0],
+               int(scene["tangent_mask"].sum()), res))
+        gm, t_vox, t_pairs = init_model(model, res, subset)
+        gs = capi.Scene(ctx, scene["surfels"], scene["tangent_mask"])
+        pc = gm.pair_counts()
+        log("[rank %d] model init: voxels %s in %.2fs, pair table %d entries / %d keys in %.2fs"
+            % (rank, list(gm.grid()[0]), t_vox, pc["entries"], pc["distinct_keys"], t_pairs))
+        n_first = max(64, H // 400)
+        pairs_all = synth.sample_scene_pairs(scene, gm.diameter, n_first * world, 24, seed=13)
+        unit = dict(name="model", gm=gm, gs=gs, K=capi.IDENTITY, radius=0.0, M=model, res=res, subset=subset,
+                    pairs=tmd.shard_pairs(pairs_all, rank, world))
+        desc = ("identity_traits: %d-pt model / %d-pt scene, %d hypotheses/batch, full-scene scoring"
+                % (args.model_points, args.scene_points, H))
+        return dict(ctx=ctx, gs=gs, scene=scene, units=[unit], description=desc, planted=scene)
+    if wl in ("c3", "c4"):
+        if wl == "c3":
+            K, rng = capi.CYLINDER, np.random.default_rng(2)
+            model, _ = synth.synth_pipe_section(50_000, seed=3)
+            sc = synth.synth_pipe_plant(500_000, 50_000, seed=4)
+            msamples = _pick_cylinder_samples(model, np.ones(len(model), bool), rng)
+            ssamples = _pick_cylinder_samples(sc["surfels"], sc["pipe_id"] == 0, rng)
+            what = "cylinder_traits (cylinder.cl path): 500k-pt pipe-plant scene, 50k-pt pipe-section model"
+        else:
+            K, rng = capi.PLANE2, np.random.default_rng(3)
+            model, _ = synth.synth_wall_panel(15_000, seed=5)
+            sc = synth.synth_indoor(1_000_000, 15_000, seed=6)
+            msamples = _pick_plane_samples(model, np.ones(len(model), bool), rng)
+            ssamples = _pick_plane_samples(sc["surfels"], sc["wall_id"] == 0, rng)
+            what = "plane2_traits: 1M-pt indoor scan, 15k-pt wall-panel model"
+        S, tm = sc["surfels"], sc["tangent_mask"]
+        threshold = 0.05
+        ms = np.zeros(capi.STATE_FLOATS, np.float32)
+        ms[1] = threshold
+        mstate = capi.traits_init_from_samples(K, ms, np.concatenate([model[i] for i in msamples]))
+        sstate = capi.traits_init_from_samples(K, ms, np.concatenate([S[i] for i in ssamples]))
+        radius = float(mstate[0]) if K == capi.CYLINDER else 0.0
+        raw = capi.Scene(ctx, S, tm)
+        gp = raw.project(K, sstate)  # the per-projector step on the device (tm_scene_create_projected)
+        su, tmask = gp.download()
+        mu, mv = ctx.traits_project_cloud(K, mstate, model)
+        mu = mu[mv == 1]
+        res = synth.resolution(mu)
+        subset = np.nonzero(np.linalg.norm(mu[:, 9:12], axis=1) > 0.7)[0].astype(np.uint32)
+        gm, t_vox, t_pairs = init_model(mu, res, subset, K, radius)
+        log("[rank %d] %s: projected scene %d live of %d, model %d (tangent %d), voxels %s in %.2fs, pair table in %.2fs"
+            % (rank, wl, int(np.isfinite(su[:, 0]).sum()), len(su), len(mu), len(subset), list(gm.grid()[0]), t_vox, t_pairs))
+        # first points among the tangent points on the projector's surface (|w| small)
+        near = tmask * (np.abs(np.nan_to_num(su[:, 2], nan=1e9)) < (threshold / radius if radius else threshold))
+        pairs_all = synth.sample_scene_pairs(dict(surfels=su, tangent_mask=near), gm.diameter, 400 * world, 3, seed=13)
+        unit = dict(name="model", gm=gm, gs=gp, K=K, radius=radius, M=mu, res=res, subset=subset,
+                    pairs=tmd.shard_pairs(pairs_all, rank, world))
+        desc = "%s, %d hypotheses/batch, scoring of the whole projected scene under the traits' intrinsic_distance" % (what, H)
+        return dict(ctx=ctx, gs=gp, scene=dict(surfels=su, tangent_mask=tmask), units=[unit], description=desc,
+                    planted=None, keep=raw)
+    # c5: 32 models against one 4M-point scene
+    models, scene = synth.synth_multi_model_scene(4_000_000, 32, seed=7)
+    S, tm = scene["surfels"], scene["tangent_mask"]
+    log("[rank %d] synth %.1fs: 32 models (%d..%d points), scene %d" % (rank, time.time() - t0, min(len(m[0]) for m in models),
+                                                                       max(len(m[0]) for m in models), len(S)))
+    gs = capi.Scene(ctx, S, tm)
+    units = []
+    for k, (M, sub, res) in enumerate(models):
+        gm, _, _ = init_model(M, res, sub)
+        own = dict(surfels=S, tangent_mask=tm * (scene["instance_id"] == k))
+        pairs_all = np.concatenate([synth.sample_scene_pairs(own, gm.diameter, 100 * world, 4, seed=13 + k),
+                                    synth.sample_scene_pairs(dict(surfels=S, tangent_mask=tm), gm.diameter, 300 * world, 4,
+                                                             seed=113 + k)])
+        pairs_all = np.ascontiguousarray(pairs_all[np.random.default_rng(k).permutation(len(pairs_all))])
+        units.append(dict(name="model %d" % k, gm=gm, gs=gs, K=capi.IDENTITY, radius=0.0, M=M, res=res, subset=sub,
+                          pairs=tmd.shard_pairs(pairs_all, rank, world)))
+    log("[rank %d] 32 models on the device in %.1fs" % (rank, time.time() - t0))
+    desc = ("multi-model search: 32 models (20k..100k pts) x 4M-pt scene, one %d-hypothesis batch per model and step, "
+            "per-model best-pose reduce" % H)
+    return dict(ctx=ctx, gs=gs, scene=scene, units=units, description=desc, planted=None)
 
 
 def launch_ranks(n, argv):
@@ -485,23 +627,25 @@ def measured_traffic(args):
     tools/make_traffic_json.py from separate rocprofv3 --pmc runs of this same command). Null when the
     workload differs from the profiled one or the kernel sources changed since."""
     t = None
+    fname = "traffic.json" if args.workload == "c2" else "traffic_%s.json" % args.workload
     for rnd in _profile_rounds():  # the newest round whose PMC passes were taken on these kernel sources
         try:
-            cand = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+            cand = json.load(open(os.path.join(ROOT, "profiles", rnd, fname)))
         except (OSError, ValueError):
             continue
         if cand.get("source_hash") == source_hash():
             t = cand
-            t["file"] = "profiles/%s/traffic.json" % rnd
+            t["file"] = "profiles/%s/%s" % (rnd, fname)
             break
     if t is None:
-        log("no profiles/r*/traffic.json was taken on these kernel sources: roofline.traffic = null")
+        log("no profiles/r*/%s was taken on these kernel sources: roofline.traffic = null" % fname)
         return None
     w = t.get("workload", {})
-    if (w.get("model_points") == args.model_points and w.get("scene_points") == args.scene_points
-            and w.get("hyp_per_batch") == args.hyp_per_batch and w.get("mode") == args.mode):
-        return t
-    return None
+    if w.get("workload", "c2") != args.workload or w.get("hyp_per_batch") != args.hyp_per_batch or w.get("mode") != args.mode:
+        return None
+    if args.workload == "c2" and (w.get("model_points") != args.model_points or w.get("scene_points") != args.scene_points):
+        return None
+    return t
 
 
 def preprocessing_extra(ctx, model, res, scene, gs):
@@ -682,7 +826,7 @@ def early_drop_dev_figure(ctx, gm, gs, pairs, d_poses, d_prov, n_hyp, dist_thres
 
 
 def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts, n_hyp, dist_thres,
-                     accept_prob, pairs=None, d_prov=None):
+                     accept_prob, pairs=None, d_prov=None, K=0, radius=0.0, unit_note=""):
     """Times the oracle's project_ (the CPU restatement of the reference path, kind "port") on a
     bounded sample of the same hypothesis batch, threads = hardware_concurrency() - 1 as the
     reference does (include/impl/scene.hpp:146). The voxel table is imported from the GPU build
@@ -690,6 +834,8 @@ def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts
     from oracle import tmo
     threads = max(1, (os.cpu_count() or 2) - 1)
     om = tmo.Model(model, res)
+    if K:
+        om.set_metric(K, radius)  # the traits' intrinsic_distance (plane2: 2-D, cylinder: wrap-around)
     om.set_voxels(gm.voxels())
     os_ = tmo.Scene(scene["surfels"], scene["tangent_mask"])
     poses = np.zeros((n_hyp, 16), np.float32)
@@ -717,7 +863,7 @@ def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts
     # like for like with what the GPU's culling leaves: the reference's own inner loop scores on
     # nn = radius_search_inclusive(model diameter, first sample point), with the early-drop rule
     ref_shaped = None
-    if pairs is not None and d_prov is not None:
+    if pairs is not None and d_prov is not None and not K:
         prov = np.zeros((n_hyp, 4), np.uint32)
         ctx.d2h(prov, d_prov)
         centers = pairs[prov[:, 0], 0]
@@ -735,8 +881,8 @@ def run_cpu_baseline(args, model, res, subset, scene, gm, ctx, d_poses, d_counts
                           "note": "project_ on nn(first point, model diameter) with early drop, %d first points" % len(uniq)}
     return {"value": round(k / t_full, 2), "unit": "hypotheses/s", "cores": threads, "kind": "port",
             "reference_shaped_ball_early_drop": ref_shaped,
-            "sample": "%d of the %d hypotheses of one batch, full pass over the %d-pt scene (early drop off), %.1fs"
-                      % (k, n_hyp, scene["surfels"].shape[0], t_full),
+            "sample": "%s%d of the %d hypotheses of one batch, full pass over the %d-pt scene (early drop off), %.1fs"
+                      % (unit_note, k, n_hyp, scene["surfels"].shape[0], t_full),
             "gpoints_per_s": round(ev_full / t_full / 1e9, 4),
             "early_drop_on": {"value": round(k / t_ed, 2), "unit": "hypotheses/s",
                               "gpoints_per_s": round(ev_ed / t_ed / 1e9, 4), "seconds": round(t_ed, 2)},

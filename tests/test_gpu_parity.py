@@ -678,6 +678,13 @@ def test_voxel_kdtree_equals_bruteforce_kernel(gpu_ctx):
         assert np.array_equal(sc.score_hypotheses(c, np.eye(4, dtype=np.float32).reshape(1, 16), DT)[0],
                               sc.score_hypotheses(a, np.eye(4, dtype=np.float32).reshape(1, 16), DT)[0])  # brick minima too
         c.close()
+    # the option toggled BETWEEN create and build_voxels: the model was created with the deep device-built tree, which
+    # the per-voxel walk's 24-entry stack must never descend (it would drop subtrees without a word): same table
+    t = capi.Model(gpu_ctx, model, res)
+    with gpu_ctx.option("voxel_packet", 0):
+        t.build_voxels()
+    assert np.array_equal(va, t.voxels())
+    t.close()
     assert not np.isin(va, np.arange(15000, 15500)).any()  # duplicates never win over their originals
     poses = np.eye(4, dtype=np.float32).reshape(1, 16)
     s = capi.Scene(gpu_ctx, model, (np.linalg.norm(model[:, 9:12], axis=1) > 0.7).astype(np.int32))

@@ -214,6 +214,8 @@ struct tm_model {
     tmx::dbuf<float4> kd_lo, kd_hi;
     tmx::dbuf<float4> kd_pts;
     uint32_t kd_n_nodes = 0, kd_n_pts = 0;
+    bool deep_tree = false; /* the tree is the device-built linear BVH (depth up to kLbvhMaxDepth): only walks with a
+                               kLbvhStack-entry stack may descend it (the packet walk; never k_voxel_nn_kd's 24 entries) */
     tmx::dbuf<float4> pos;  /* xyz, w = (|tangent| > 0.7) ? 1 : 0 ; non-finite points keep NaN */
     tmx::dbuf<float4> ref;  /* tangent if is_tangent else normal */
     tmx::dbuf<float4> tan4; /* raw tangent xyz (pair build / hypothesis generation) */
@@ -464,6 +466,7 @@ int scene_build(tm_scene* s, bool resort);
  * kLbvhStack entries. lo / hi: 2 * n_fin nodes, q0 / q1: n_fin work items each, cnt: 3 + kLbvhMaxDepth + 3 words
  * (cnt[0] = node count afterwards). Queued on the context's stream (with a few 4-byte read-backs in between). */
 constexpr int kLbvhStack = 48, kLbvhMaxDepth = kLbvhStack - 2;
+static_assert(kLbvhStack >= kLbvhMaxDepth + 2, "walks with kLbvhStack entries never overflow on a device-built tree");
 void lbvh_build(tm_ctx* c, const unsigned long long* d_keys, const float4* d_pts, uint32_t n_fin, float4* d_lo,
                 float4* d_hi, uint4* d_q0, uint4* d_q1, uint32_t* d_cnt);
 void curve_points(tm_ctx* c, const float* d_cloud, const uint32_t* d_order, uint32_t n, float4* d_pts, uint32_t* d_n_fin);

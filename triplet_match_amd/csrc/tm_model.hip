@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_voxel_nn_kd(const float4* __restrict__ 
  * original index), so every lane ends with the same (distance, index) as on its own. The order of the two children
  * follows lane 21 (a voxel in the middle of the brick); any order is correct. */
 constexpr int kKdPacketStack = 64;
+static_assert(kKdPacketStack >= kLbvhMaxDepth + 2, "the packet walk must hold a path of the deepest device-built tree");
 __global__ __launch_bounds__(256) void k_voxel_nn_packet(const float4* __restrict__ kd_lo,
                                                          const float4* __restrict__ kd_hi,
                                                          const float4* __restrict__ pts,
@@ -1602,6 +1603,7 @@ static int model_arrays_on_device(tm_model* m, const float* surfels) {
     for (uint32_t k = 0; k < n; ++k) m->h_orig2new[m->h_new2orig[k]] = k;
     m->kd_n_nodes = n_nodes;
     m->kd_n_pts = n_fin;
+    m->deep_tree = true;
     return TM_OK;
 }
 
@@ -2149,8 +2151,10 @@ int tm_model_build_voxels(tm_model* m) {
         uint64_t kd_blocks = (m->voxel_slots + 255) / 256;
         TM_REQUIRE(kd_blocks <= 0x7FFFFFFFull, TM_ERR_UNSUPPORTED, "voxel grid too large for one launch");
         /* a brick's 64 voxels as one packet (default), or every voxel on its own stack (voxel_packet = 0: the
-         * cross-check; identical tables) */
-        if (c->opt.voxel_packet) {
+         * cross-check; identical tables). The model records which tree it was created with: the per-voxel walk's
+         * 24-entry stack would silently drop subtrees of the deep device-built tree, so a model that holds one takes
+         * the packet walk whatever the option says now (it selects the host tree only at tm_model_create). */
+        if (c->opt.voxel_packet || m->deep_tree) {
             /* voxel_seed (default): one candidate per super-brick from a k-nearest walk of its centre */
             dbuf<float4> d_sq;
             dbuf<uint32_t> d_seed;
