@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turns the PMC passes of tools/pmc_rdreq.sh into profiles/rNN/traffic.json (what bench.py quotes as
-roofline.traffic).  usage: tools/make_traffic_json.py <pmc outdir> [kernel substring] [out path] [folded outdir]
+roofline.traffic).  usage: [TM_WORKLOAD=c3|c4|c5] tools/make_traffic_json.py <pmc outdir> [kernel substring] [out path] [folded outdir]
+(the passes of `bench.py --workload cX` go to profiles/rNN/traffic_cX.json)
 <folded outdir> = the pass-1 counters of the same command on the timing-experiments build with TM_ABLATE=7 (voxel
 index folded into 1 MB): the difference of the line counts = the lines the voxel gathers fetch.
 
@@ -37,7 +38,9 @@ k_ms = line["roofline"]["kernel_ms"]
 cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
 res = {
     "kernel": name,
-    "workload": {"model_points": 100000, "scene_points": 1000000, "hyp_per_batch": 65536, "mode": "auto"},
+    "workload": ({"model_points": 100000, "scene_points": 1000000, "hyp_per_batch": 65536, "mode": "auto"}
+                 if os.environ.get("TM_WORKLOAD", "c2") == "c2" else
+                 {"workload": os.environ["TM_WORKLOAD"], "hyp_per_batch": 65536, "mode": "auto"}),
     "source_hash": bench.source_hash(),
     "source": "tools/pmc_rdreq.sh: separate rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 "
               "--no-cpu-baseline --no-extras`, mean per dispatch",
