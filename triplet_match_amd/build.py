@@ -47,6 +47,11 @@ def build(force=False, verbose=False, timing_experiments=False):
     return _build(LIB, [], ".o", verbose)
 
 
+def build_variant(name, defines, verbose=False):
+    """A/B aid: libtm_hip_<name>.so built with extra -D switches (select it with TM_LIB=<path>); never the product."""
+    return _build(os.path.join(HERE, "libtm_hip_%s.so" % name), list(defines), ".%s.o" % name, verbose)
+
+
 def _build(lib, extra, obj_suffix, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -70,4 +75,8 @@ def _build(lib, extra, obj_suffix, verbose):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m triplet_match_amd.build --variant NAME -DTM_X=1 ...
+        k = sys.argv.index("--variant")
+        print(build_variant(sys.argv[k + 1], [a for a in sys.argv[k + 2:] if a.startswith("-D")], verbose=False))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, timing_experiments="--timing-experiments" in sys.argv))

@@ -273,10 +273,20 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
                 in[k] = in[k] & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
                         (vz < a.g.fez);
+#if TM_VAR_ADDR24
+                /* the conversions saturate, so the address arithmetic may run on whatever an outside point gives: one
+                 * select on the brick (the byte gather must stay inside the table) instead of three on the coordinates;
+                 * super-brick index with 24-bit multiplies (full rate; v_mad_u64_u32 is not): counts are < 2^20 */
+                const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
+                const uint32_t sb = __umul24(__umul24(iz >> 4, (uint32_t)a.by) + (iy >> 4), (uint32_t)a.bx) + (ix >> 4);
+                brick[k] = in[k] ? ((sb << 6) | ((((iz >> 2) & 3u) << 4) | (((iy >> 2) & 3u) << 2) | ((ix >> 2) & 3u))) : 0u;
+                lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
+#else
                 uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
                          iz = in[k] ? (uint32_t)(int)vz : 0u;
                 brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
                 lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
+#endif
             }
             uint32_t code[4];
 #pragma unroll
@@ -617,6 +627,19 @@ struct f3pack {
     float x, y, z;
 };
 
+/* trunc(term * 2^40) for term >= 0 in integer arithmetic: the value is M * 2^(e - 150) with M = 2^23 | mantissa, so
+ * the result is (M << 40) >> (150 - e) for biased exponents 87..150 and 0 below (term < 2^-40, denormals included).
+ * Equal to (unsigned long long)(long long)((double)term * kFx) for every finite term < 2^24 (the fixed-point sum's own
+ * packing gives out at 2^12); NaN / inf / >= 2^24 give 0. Eight full-rate integer instructions instead of eight f64
+ * conversions (cvt, ldexp, trunc, ldexp, floor, fma, two cvt). */
+__device__ __forceinline__ unsigned long long fx40_trunc(float term) {
+    const uint32_t b = __float_as_uint(term) & 0x7FFFFFFFu;
+    const uint32_t e = b >> 23;
+    uint32_t hi = ((b & 0x7FFFFFu) | 0x800000u) << 8; /* M << 40 = hi : 0 */
+    hi = (e - 87u <= 63u) ? hi : 0u;
+    return ((unsigned long long)hi << 32) >> ((150u - e) & 63u);
+}
+
 /* BALL: every hypothesis scores only the scene points within ca.ball_r of its own centre point (the reference's
  * nn = radius_search_inclusive(diameter, p1)): quarter-tiles conservatively by a sphere-sphere test, points exactly
  * by (dx*dx + dy*dy) + dz*dz <= r*r on the untransformed point, as k_score_culled does */
@@ -884,11 +907,23 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                                 const float4* pp = poses + 3u * gk[k0 + j];
                                 f3 r = lds_xform_dir(pp[0], pp[1], pp[2], sr[j].x, sr[j].y, sr[j].z);
                                 float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
+#if TM_VAR_FX_INT
+                                const unsigned long long t = fx40_trunc(term);
+#else
                                 const unsigned long long t = (unsigned long long)(long long)((double)term * kFx);
+#endif
+#if TM_VAR_LDS_ATOMIC
+                                /* every lane adds its own term to the hypothesis' sum in LDS: count << 52 | t */
+                                atomicAdd(&acc[gk[k0 + j]], (1ull << 52) + t);
+#else
                                 w_lo = (uint32_t)(t & 0xFFFFFull) | (1u << 24);
                                 w_hi = (uint32_t)(t >> 20);
+#endif
                             }
                         }
+#if TM_VAR_LDS_ATOMIC
+                        (void)w_lo, (void)w_hi;
+#else
                         if (__ballot(w_lo != 0u)) {
                             w_lo = row16_sum(w_lo);
                             w_hi = row16_sum(w_hi);
@@ -898,6 +933,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                                               ((unsigned long long)w_hi << 20) + (unsigned long long)(w_lo & 0xFFFFFFu));
                             }
                         }
+#endif
                     }
                 }
             }
