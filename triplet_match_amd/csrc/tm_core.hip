@@ -166,7 +166,7 @@ struct opt_entry {
     int lo, hi;
 };
 static const opt_entry kOptions[] = {
-    {"ablate", &options::ablate, 0, 99},
+    {"ablate", &options::ablate, 0, 255},
     {"debug_stats", &options::debug_stats, 0, 1},
     {"debug_items", &options::debug_items, 0, 1},
     {"debug_times", &options::debug_times, 0, 1},

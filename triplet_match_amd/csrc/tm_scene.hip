@@ -273,20 +273,10 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                 float vx = a.g.sx * q[k].x + a.g.tx, vy = a.g.sy * q[k].y + a.g.ty, vz = a.g.sz * q[k].z + a.g.tz;
                 in[k] = in[k] & (vx > -1.f) & (vx < a.g.fex) & (vy > -1.f) & (vy < a.g.fey) & (vz > -1.f) &
                         (vz < a.g.fez);
-#if TM_VAR_ADDR24
-                /* the conversions saturate, so the address arithmetic may run on whatever an outside point gives: one
-                 * select on the brick (the byte gather must stay inside the table) instead of three on the coordinates;
-                 * super-brick index with 24-bit multiplies (full rate; v_mad_u64_u32 is not): counts are < 2^20 */
-                const uint32_t ix = (uint32_t)(int)vx, iy = (uint32_t)(int)vy, iz = (uint32_t)(int)vz;
-                const uint32_t sb = __umul24(__umul24(iz >> 4, (uint32_t)a.by) + (iy >> 4), (uint32_t)a.bx) + (ix >> 4);
-                brick[k] = in[k] ? ((sb << 6) | ((((iz >> 2) & 3u) << 4) | (((iy >> 2) & 3u) << 2) | ((ix >> 2) & 3u))) : 0u;
-                lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
-#else
                 uint32_t ix = in[k] ? (uint32_t)(int)vx : 0u, iy = in[k] ? (uint32_t)(int)vy : 0u,
                          iz = in[k] ? (uint32_t)(int)vz : 0u;
                 brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
                 lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
-#endif
             }
             uint32_t code[4];
 #pragma unroll
@@ -339,7 +329,7 @@ __global__ __launch_bounds__(256, 5) void k_score_culled(score_args a, cull_args
                             if (sr[j].w == mr[j].w) { /* use_tangent == is_tangent, reference :472 */
                                 f3 r = xform_dir(T, make3(sr[j].x, sr[j].y, sr[j].z));
                                 float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
-                                fx += (long long)((double)term * kFx);
+                                fx += (long long)fx40_trunc(term);
                                 ++cnt;
                             }
                         }
@@ -581,15 +571,6 @@ __global__ __launch_bounds__(256) void k_item_scatter(group_args ga, const uint3
     }
 }
 
-/* sum over the 16 lanes of a DPP row; lane 15 of every row ends up with the row's total */
-__device__ __forceinline__ uint32_t row16_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); /* row_shr:1 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); /* row_shr:2 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); /* row_shr:4 */
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); /* row_shr:8 */
-    return v;
-}
-
 /* pose as staged in LDS: three float4 laid out for two-wide arithmetic on (x, y):
  *   A = (r00, r10, r01, r11)   B = (r02, r12, tx, ty)   C = (r20, r21, r22, tz)
  * so that T*p = ((A.xy * px + A.zw * py) + B.xy * pz) + B.zw for (x, y) — register pairs straight from the
@@ -626,19 +607,6 @@ __device__ __forceinline__ T ld_off32(const T* base, uint32_t byte_off) {
 struct f3pack {
     float x, y, z;
 };
-
-/* trunc(term * 2^40) for term >= 0 in integer arithmetic: the value is M * 2^(e - 150) with M = 2^23 | mantissa, so
- * the result is (M << 40) >> (150 - e) for biased exponents 87..150 and 0 below (term < 2^-40, denormals included).
- * Equal to (unsigned long long)(long long)((double)term * kFx) for every finite term < 2^24 (the fixed-point sum's own
- * packing gives out at 2^12); NaN / inf / >= 2^24 give 0. Eight full-rate integer instructions instead of eight f64
- * conversions (cvt, ldexp, trunc, ldexp, floor, fma, two cvt). */
-__device__ __forceinline__ unsigned long long fx40_trunc(float term) {
-    const uint32_t b = __float_as_uint(term) & 0x7FFFFFFFu;
-    const uint32_t e = b >> 23;
-    uint32_t hi = ((b & 0x7FFFFFu) | 0x800000u) << 8; /* M << 40 = hi : 0 */
-    hi = (e - 87u <= 63u) ? hi : 0u;
-    return ((unsigned long long)hi << 32) >> ((150u - e) & 63u);
-}
 
 /* BALL: every hypothesis scores only the scene points within ca.ball_r of its own centre point (the reference's
  * nn = radius_search_inclusive(diameter, p1)): quarter-tiles conservatively by a sphere-sphere test, points exactly
@@ -838,7 +806,8 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                          iz = in[k] ? (uint32_t)(int)vz : 0u;
                 brick[k] = brick_of(ix, iy, iz, (uint32_t)a.bx, (uint32_t)a.by);
                 lin[k] = brick[k] * 64u + (((iz & 3u) << 4) | ((iy & 3u) << 2) | (ix & 3u));
-                code[k] = NEAR ? (uint32_t)a.bcode[brick[k]] : 0u;
+                code[k] = NEAR ? (uint32_t)a.bcode[TM_ABLATE_BIT(a, 8) ? (brick[k] & 1023u) : brick[k]] : 0u;
+                if (TM_ABLATE_BIT(a, 8)) code[k] = 0u; /* the folded code is another brick's: every in-grid point is near */
                 __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
             }
 #pragma unroll
@@ -850,90 +819,81 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 }
                 lin[k] = near[k] ? lin[k] : 0u;
                 if (TM_ABLATE_EQ(a, 7)) lin[k] &= 0x3FFFFu; /* timing experiment: voxel gathers stay in 1 MB */
+                /* timing experiments (wrong results): the access pattern of a table with 2-byte / 1-byte entries — a
+                 * brick is one 128-B line / half a line, the touched shell a half / a quarter of today's */
+                if (TM_ABLATE_EQ(a, 12)) lin[k] = near[k] ? ((brick[k] << 5) | (lin[k] & 31u)) : 0u;
+                if (TM_ABLATE_EQ(a, 13)) lin[k] = near[k] ? ((brick[k] << 4) | (lin[k] & 15u)) : 0u;
+                if (TM_ABLATE_BIT(a, 2)) lin[k] &= 0x3FFFu; /* 64 KB window */
             }
 #pragma unroll
             for (int k = 0; k < NC; ++k) mi[k] = W32 ? ld_off32(a.vox, lin[k] << 2) : a.vox[lin[k]];
-            bool ok[NC];
-            bool any_ok = false;
+            if (TM_ABLATE_BIT(a, 4)) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) mi[k] &= 1023u;
+            }
+            /* the model position and, for the near points, both orientation records (scene point's, model point's) in
+             * ONE level: mi is known, the scene point always was. The orientation term then starts without a round
+             * trip of its own (kernel 7.72 -> 7.39 ms on the bench batch); the fifth of the near points that fail the
+             * distance test fetch their two records for nothing. */
+            float mpx[NC][3];
+            float4 sr[NC], mr[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                float mp[3];
                 if (W32) {
                     const f3pack t = ld_off32(reinterpret_cast<const f3pack*>(a.mpos3), mi[k] * 12u);
-                    mp[0] = t.x, mp[1] = t.y, mp[2] = t.z;
+                    mpx[k][0] = t.x, mpx[k][1] = t.y, mpx[k][2] = t.z;
                 } else {
                     const float* src = a.mpos3 + 3u * (size_t)mi[k];
-                    mp[0] = src[0], mp[1] = src[1], mp[2] = src[2];
+                    mpx[k][0] = src[0], mpx[k][1] = src[1], mpx[k][2] = src[2];
                 }
+            }
+            if (!TM_ABLATE_BIT(a, 1)) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    if (near[k]) {
+                        if (W32) {
+                            sr[k] = ld_off32(a.sref, ((TM_ABLATE_BIT(a, 32) ? 0u : chunk * (uint32_t)kChunkPts) + pidx[k]) << 4);
+                            mr[k] = ld_off32(a.mref, (TM_ABLATE_BIT(a, 16) ? (mi[k] & 1023u) : mi[k]) << 4);
+                        } else {
+                            sr[k] = a.sref[chunk * (uint32_t)kChunkPts + pidx[k]];
+                            mr[k] = a.mref[mi[k]];
+                        }
+                    }
+                }
+            }
+            bool ok[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
                 if (L2) {
-                    float dx = q[k].x - mp[0], dy = q[k].y - mp[1], dz = q[k].z - mp[2];
+                    float dx = q[k].x - mpx[k][0], dy = q[k].y - mpx[k][1], dz = q[k].z - mpx[k][2];
                     float d2 = (dx * dx + dy * dy) + dz * dz;
                     ok[k] = near[k] & (d2 <= a.d2max);
                 } else {
                     /* !(sqrtf(d2) > thres) without the square root: sqrtf is correctly rounded and monotone and
                      * d2max is the largest float whose root is <= thres, so sqrtf(d2) > thres <=> d2 > d2max; a
                      * NaN fails both comparisons alike. The exhaustive kernel keeps the literal form (eval_point). */
-                    float d2 = traits_distance2(a.kind, a.radius, q[k], make3(mp[0], mp[1], mp[2]));
+                    float d2 = traits_distance2(a.kind, a.radius, q[k], make3(mpx[k][0], mpx[k][1], mpx[k][2]));
                     ok[k] = near[k] & !(d2 > a.d2max);
                 }
-                any_ok |= ok[k];
+                if (TM_ABLATE_BIT(a, 6)) ok[k] = near[k] & ((pidx[k] & 7u) != 0u); /* folded entries fail the test: let 7 of 8 through */
             }
-            if (TM_ABLATE_EQ(a, 1)) { pass += any_ok ? 1u : 0u; continue; } /* timing experiment: no orientation stage */
-            if (__ballot(any_ok)) {
+            if (TM_ABLATE_EQ(a, 1) || TM_ABLATE_EQ(a, 7) || TM_ABLATE_EQ(a, 12) || TM_ABLATE_EQ(a, 13) || TM_ABLATE_BIT(a, 1)) {
 #pragma unroll
-                for (int k0 = 0; k0 < NC; k0 += 2) {
-                    float4 sr[2], mr[2];
+                for (int k = 0; k < NC; ++k) pass += ok[k] ? 1u : 0u; /* timing experiments: no orientation stage */
+                continue;
+            }
+            /* orientation term (:441-488): every correspondence adds count << 52 | 2^-40 fixed-point term to its
+             * hypothesis' sum in LDS, one atomic per lane (the 16-lane DPP reductions of two dwords that used to stand
+             * here were a third of the loop's VALU instructions for the same integers) */
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (k0 + j < NC && ok[(k0 + j) % NC]) {
-                            if (W32) {
-                                sr[j] = ld_off32(a.sref, (chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]) << 4);
-                                mr[j] = ld_off32(a.mref, mi[(k0 + j) % NC] << 4);
-                            } else {
-                                sr[j] = a.sref[chunk * (uint32_t)kChunkPts + pidx[(k0 + j) % NC]];
-                                mr[j] = a.mref[mi[(k0 + j) % NC]];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (k0 + j >= NC) continue;
-                        /* 2^40 fixed-point term split as hi * 2^20 + lo, the match flag rides above lo:
-                         * two dwords to add up over the 16 lanes of the entry */
-                        uint32_t w_lo = 0u, w_hi = 0u;
-                        if (ok[k0 + j]) {
-                            if (STATS) ++pass;
-                            if (sr[j].w == mr[j].w) {
-                                const float4* pp = poses + 3u * gk[k0 + j];
-                                f3 r = lds_xform_dir(pp[0], pp[1], pp[2], sr[j].x, sr[j].y, sr[j].z);
-                                float term = fabsf(dot3(r, make3(mr[j].x, mr[j].y, mr[j].z)));
-#if TM_VAR_FX_INT
-                                const unsigned long long t = fx40_trunc(term);
-#else
-                                const unsigned long long t = (unsigned long long)(long long)((double)term * kFx);
-#endif
-#if TM_VAR_LDS_ATOMIC
-                                /* every lane adds its own term to the hypothesis' sum in LDS: count << 52 | t */
-                                atomicAdd(&acc[gk[k0 + j]], (1ull << 52) + t);
-#else
-                                w_lo = (uint32_t)(t & 0xFFFFFull) | (1u << 24);
-                                w_hi = (uint32_t)(t >> 20);
-#endif
-                            }
-                        }
-#if TM_VAR_LDS_ATOMIC
-                        (void)w_lo, (void)w_hi;
-#else
-                        if (__ballot(w_lo != 0u)) {
-                            w_lo = row16_sum(w_lo);
-                            w_hi = row16_sum(w_hi);
-                            if ((lane & 15u) == 15u && w_lo != 0u) {
-                                atomicAdd(&acc[gk[k0 + j]],
-                                          ((unsigned long long)(w_lo >> 24) << 52) +
-                                              ((unsigned long long)w_hi << 20) + (unsigned long long)(w_lo & 0xFFFFFFu));
-                            }
-                        }
-#endif
+            for (int k = 0; k < NC; ++k) {
+                if (ok[k]) {
+                    if (STATS) ++pass;
+                    if (sr[k].w == mr[k].w) {
+                        const float4* pp = poses + 3u * gk[k];
+                        f3 r = lds_xform_dir(pp[0], pp[1], pp[2], sr[k].x, sr[k].y, sr[k].z);
+                        float term = fabsf(dot3(r, make3(mr[k].x, mr[k].y, mr[k].z)));
+                        atomicAdd(&acc[gk[k]], (1ull << 52) + fx40_trunc(term));
                     }
                 }
             }
