@@ -81,6 +81,7 @@ def grid_entry(cloud, res, threads, extra=None):
     v = m.voxels()
     ext, tv = m.grid()
     e = dict(points=int(len(cloud)), cloud_sha256=sha(np.ascontiguousarray(cloud, np.float32)),
+             positions_sha256=sha(np.ascontiguousarray(np.asarray(cloud)[:, 0:3], np.float32)),
              resolution=float(res), extents=[int(x) for x in ext], voxels=int(v.size),
              voxel_sha256=sha(np.ascontiguousarray(v, np.uint32)), seconds=round(time.time() - t0, 1))
     if extra:

@@ -50,8 +50,14 @@ def full(gpu_ctx):
 def oracle_full(full):
     """Oracle model with its own pair table; the voxel table is imported from the GPU build, whose
     correctness at this size is what test_voxel_grid_full_size establishes."""
+    import hashlib
+    import json
     om = tmo.Model(full["model"], full["res"])
-    om.set_voxels(full["gm"].voxels())
+    vox = full["gm"].voxels()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_voxel_grid.json")))
+    # ... which the oracle built on its own, offline (make_voxel_sha.py): checked before the table is handed over
+    assert hashlib.sha256(np.ascontiguousarray(vox, np.uint32).tobytes()).hexdigest() == gold["sha256_kd_tree"]
+    om.set_voxels(vox)
     assert om.build_pairs(full["subset"]) == 0
     os_ = tmo.Scene(full["scene"]["surfels"], full["scene"]["tangent_mask"])
     return dict(model=om, scene=os_)

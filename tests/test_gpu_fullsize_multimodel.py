@@ -3,6 +3,10 @@ scene, one 64k-hypothesis batch per model, per-model best record. Checked: culle
 on a slice of every batch; the oracle's project_ on a sample for three of the models; every model's best
 hypothesis finds its own planted instance; the per-model records go through the same reduce the N-GPU
 path uses (triplet_match_amd.dist.allgather_best_many)."""
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +18,8 @@ pytestmark = pytest.mark.gpu
 
 DT = 3.0
 N_SCENE, N_MODELS, H = 4_000_000, 32, 65_536
+# SHA-256 of the voxel tables of models 0, 15 and 31 as the ORACLE builds them on the CPU (make_voxel_sha_configs.py)
+PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c345_voxel_grids.json")))
 
 
 def test_32_models_4m_scene(gpu_ctx):
@@ -57,11 +63,16 @@ def test_32_models_4m_scene(gpu_ctx):
         sel = np.unique(np.r_[rng.integers(0, n_hyp, 500), order[:12]])
         cb, sb = gs.score_hypotheses(gm, poses[sel], DT, mode=capi.SCORE_BRUTEFORCE)
         assert np.array_equal(cb, counts[sel]) and np.array_equal(sb, scores[sel])
-        if k in (0, 13, 31):  # the oracle on a sample (voxel table imported; its parity is shown elsewhere)
+        if k in (0, 15, 31):  # the oracle on a sample; the imported voxel table is first checked against the oracle's own
+            pin = PINS["c5_model_%d" % k]
+            vox = gm.voxels()
+            assert hashlib.sha256(np.ascontiguousarray(M, np.float32).tobytes()).hexdigest() == pin["cloud_sha256"]
+            assert [int(e) for e in gm.grid()[0]] == pin["extents"]
+            assert hashlib.sha256(np.ascontiguousarray(vox, np.uint32).tobytes()).hexdigest() == pin["voxel_sha256"]
             if os_ is None:
                 os_ = tmo.Scene(S, tm)
             om = tmo.Model(M, res)
-            om.set_voxels(gm.voxels())
+            om.set_voxels(vox)
             osel = np.r_[sel[:6], order[:4]]
             co, so, _ = os_.score_hypotheses(om, poses[osel], 0.5, DT, threads=32)
             assert np.array_equal(co, counts[osel])

@@ -8,6 +8,10 @@ plane2_traits on a 1M-pt indoor scan. The per-projector step runs on the device
     identical between the two scenes and equal the oracle's project_ on a sample incl. the best ones;
   * the best hypothesis explains the planted section / panel of the projector's pipe / wall.
 """
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -18,6 +22,13 @@ from triplet_match_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 DT = 3.0
+# SHA-256 of the projected models and of their voxel tables as the ORACLE alone builds them on the CPU
+# (tests/golden/make_voxel_sha_configs.py: oracle traits functions per point, oracle kd-tree voxel build)
+PINS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c345_voxel_grids.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
 def _pick_cylinder_samples(s, sel, rng):
@@ -41,7 +52,7 @@ def _pick_plane_samples(s, sel, rng):
     raise AssertionError("no sample triple")
 
 
-def _run_case(gpu_ctx, K, model, msamples, scene, ssamples, threshold, target_sel, n_first, min_best_fraction):
+def _run_case(gpu_ctx, K, model, msamples, scene, ssamples, threshold, target_sel, n_first, min_best_fraction, pin=None):
     rng = np.random.default_rng(17)
     S, tm = scene["surfels"], scene["tangent_mask"]
     ms = np.zeros(capi.STATE_FLOATS, np.float32)
@@ -84,6 +95,14 @@ def _run_case(gpu_ctx, K, model, msamples, scene, ssamples, threshold, target_se
     gm.set_metric(K, radius)
     gm.build_voxels()
     gm.build_pairs(subset)
+    if pin is not None:
+        # the GPU's projected model and its voxel table against what the oracle built on its own, BEFORE the table is
+        # handed to the oracle's project_ below: that comparison no longer rests on a table nobody else has built
+        assert msamples == pin["msamples"]
+        # (the positions: what the voxel grid is built from; tangents / normals are compared on a sample above)
+        assert _sha(np.ascontiguousarray(mu[:, 0:3], np.float32)) == pin["positions_sha256"], "projected model differs from the oracle's"
+        assert [int(e) for e in gm.grid()[0]] == pin["extents"]
+        assert _sha(np.ascontiguousarray(gm.voxels(), np.uint32)) == pin["voxel_sha256"], "voxel table differs from the oracle's"
 
     # --- hypotheses from tangent pairs of the projected scene: identical on both scene objects
     gs2 = capi.Scene(gpu_ctx, su, tmask)
@@ -146,7 +165,7 @@ def test_cylinder_traits_pipe_plant_500k(gpu_ctx):
         ssamples = _pick_cylinder_samples(sc["surfels"], sc["pipe_id"] == pipe, rng)
         inst = [k for k, it in enumerate(sc["instances"]) if it[0] == pipe][0]
         r = _run_case(gpu_ctx, capi.CYLINDER, model, msamples, sc, ssamples, 0.05, sc["instance_id"] == inst,
-                      n_first=400, min_best_fraction=0.5)
+                      n_first=400, min_best_fraction=0.5, pin=PINS["c3_pipe_section_cylinder"])
         assert 0.1 < r["valid_frac"] < 0.6  # only this pipe (and what touches its shell) projects
 
 
@@ -158,5 +177,5 @@ def test_plane2_traits_indoor_1m(gpu_ctx):
     wall = sc["instances"][0][0]
     ssamples = _pick_plane_samples(sc["surfels"], sc["wall_id"] == wall, rng)
     r = _run_case(gpu_ctx, capi.PLANE2, model, msamples, sc, ssamples, 0.05, sc["instance_id"] == 0,
-                  n_first=400, min_best_fraction=0.5)
+                  n_first=400, min_best_fraction=0.5, pin=PINS["c4_wall_panel_plane2"])
     assert r["valid_frac"] == 1.0  # plane2 project() never rejects (include/impl/plane2_traits.hpp:86-88)
