@@ -382,7 +382,9 @@ def main():
         value = None
     if rank == 0:
         out = {
-            "metric": "scored RANSAC hypotheses/sec (1M-pt scene); inlier-score Gpoints/sec in gpoints_per_s",
+            "metric": "scored RANSAC hypotheses/sec (%s-pt scene); inlier-score Gpoints/sec in gpoints_per_s"
+                      % {1_000_000: "1M", 500_000: "500k", 4_000_000: "4M"}.get(int(W["scene"]["surfels"].shape[0]),
+                                                                                 str(int(W["scene"]["surfels"].shape[0]))),
             "value": round(value, 1) if value is not None else None, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",

@@ -73,11 +73,11 @@ int tm_memcpy_h2d(tm_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 /* Switches of a context (cross-check kernels, timing comparisons; none changes a result). Every switch NAME is
  * read once from the environment variable TM_<NAME IN UPPER CASE> inside tm_ctx_create; afterwards only these
- * calls change it — no call of the path reads the environment. Names: debug_stats, debug_items, debug_times,
- * debug_ed, score_grouped, ball_ungrouped, group_hyps, item_static, item_nosteal, item_run, score_item_wgs,
- * score_parts, score_slot_mib, item_sort, near_metric, model_morton, scene_morton, voxel_bruteforce, ed_one_kernel, ed_narrow,
- * ed_wide, ed_bruteforce, ed_unfused, search_segment, search_per_range, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
- * ed_prefix_group, score_off32, pool_mib, voxel_packet, voxel_seed, curv_groups, model_host_build, search_step_check (DESIGN.md section 6 says what each selects).
+ * calls change it — no call of the path reads the environment. Names: debug_stats, debug_times, debug_ed,
+ * score_grouped, ball_ungrouped, group_hyps, score_item_wgs, score_slot_mib, item_sort, near_metric, voxel_bruteforce,
+ * voxel_packet, voxel_seed, curv_groups, model_host_build, ed_one_kernel, ed_narrow, ed_bruteforce, ed_unfused,
+ * search_segment, search_per_range, search_step_check, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
+ * ed_prefix_group, score_off32, pool_mib (DESIGN.md section 6 says what each selects).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */
@@ -260,6 +260,10 @@ int tm_scene_create_dev(tm_ctx* ctx, const float* d_surfels, uint32_t n, const i
 int tm_scene_destroy(tm_scene* scene);
 /* mask_ (include/impl/scene.hpp:41,87-90); NULL clears */
 int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);
+/* mask_[idx] = 1 for the n listed points on top of the mask the scene holds (the loop of include/impl/scene.hpp:87-90
+ * over an accepted match's scene_corrs): same state as tm_scene_set_mask with the updated mask, without moving 4 bytes
+ * per scene point up and down for a few correspondences' worth of change. */
+int tm_scene_mask_add(tm_scene* scene, const uint32_t* indices, uint32_t n);
 uint32_t tm_scene_size(const tm_scene* scene);
 
 /* nn = cloud_->radius_search_inclusive(radius, p1) as used at include/impl/scene.hpp:273
@@ -297,6 +301,8 @@ int tm_scene_radius_tangent_lists(tm_scene* scene, const uint32_t* centers, uint
 /* host-side predicate of the sample filters of find_in_subset (include/impl/scene.hpp:290-302):
  * tangent_mask[j], masks, i != j, squared-distance window, collinearity, feature validity. Same
  * arithmetic as the device kernel; lets host orchestration count "valid samples" (:305,350). */
+/* Returns 1 / 0, or a negative TM_ERR_* when the scene's host mirror (fetched from the device on the first call of a
+ * host-side helper: 48 bytes per point and one stream synchronise) could not be read. */
 int tm_pair_is_valid_sample(const tm_scene* scene, const tm_model* model, uint32_t i, uint32_t j,
                             float min_diameter_factor, float max_diameter_factor);
 /* The same filters (:293-302: distance window, collinearity, feature validity) on two surfels the caller holds, with

@@ -67,7 +67,9 @@ struct hip_backend {
         if (raw_rows)
             return i != j && tm_pair_valid_raw(scloud->points[i].raw(), scloud->points[j].raw(), diam, p.min_diameter_factor,
                                                p.max_diameter_factor, bmin, bmax) != 0;
-        return tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor) != 0;
+        const int rc = tm_pair_is_valid_sample(s, m, i, j, p.min_diameter_factor, p.max_diameter_factor);
+        if (rc < 0) check(rc, "tm_pair_is_valid_sample"); /* throws: the scene's rows could not be read */
+        return rc != 0;
     }
     /* radius_search_inclusive(radius, i), include/impl/scene.hpp:273: the ascending index lists are built on
      * the device for up to 16 of the announced first points per call (announce_firsts) and handed out when
@@ -393,6 +395,12 @@ struct hip_backend {
         return r;
     }
     void set_mask(const std::vector<int32_t>& mask) { check(tm_scene_set_mask(s, mask.data()), "tm_scene_set_mask"); }
+    /* the two changes find_all makes to mask_ (:41 all clear, :87-90 an accepted match's points) without moving the
+     * whole mask: a device memset (nothing at all when it is clear already), the new indices only */
+    void clear_mask() { check(tm_scene_set_mask(s, nullptr), "tm_scene_set_mask"); }
+    void add_to_mask(const std::vector<uint32_t>& idx) {
+        check(tm_scene_mask_add(s, idx.data(), (uint32_t)idx.size()), "tm_scene_mask_add");
+    }
 };
 
 /* search.hpp Exchange over the C ABI's RCCL communicator */

@@ -477,6 +477,23 @@ struct sparse_list {
     }
 };
 
+/* does the backend take the two changes find_all makes to mask_ — all clear (:41), an accepted match's points set
+ * (:87-90) — as such, instead of the whole mask every time? (hip_backend: a device memset, tm_scene_mask_add) */
+template <class B, class = void>
+struct has_sparse_mask : std::false_type {};
+template <class B>
+struct has_sparse_mask<B, decltype(void(std::declval<B&>().clear_mask()),
+                                   void(std::declval<B&>().add_to_mask(std::declval<const std::vector<uint32_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline void mask_clear(B& be, const std::vector<int32_t>&, std::true_type) { be.clear_mask(); }
+template <class B>
+inline void mask_clear(B& be, const std::vector<int32_t>& mask, std::false_type) { be.set_mask(mask); }
+template <class B>
+inline void mask_add(B& be, const std::vector<int32_t>&, const std::vector<uint32_t>& added, std::true_type) { be.add_to_mask(added); }
+template <class B>
+inline void mask_add(B& be, const std::vector<int32_t>& mask, const std::vector<uint32_t>&, std::false_type) { be.set_mask(mask); }
+
 /* does the backend run the whole ICP loop itself? (hip_backend: tm_icp_refine) */
 template <class B, class = void>
 struct has_icp_refine : std::false_type {};
@@ -1089,18 +1106,32 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     }
     const uint32_t n_scene = (uint32_t)tangent_indices.size();
     TM_TIMED(total);
-    be.set_mask(mask);
+    {
+        TM_TIMED(mask);
+        if (initial_mask)
+            be.set_mask(mask);
+        else
+            detail::mask_clear(be, mask, detail::has_sparse_mask<Backend>{}); /* :41 */
+    }
     std::vector<candidate_t> results;
+    std::vector<uint32_t> added;
     for (;;) {
         if (p.stats) ++p.stats->rounds;
         auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p, ex);
         if (matches.empty()) break;
+        TM_TIMED(mask);
+        added.clear();
+        {
+            size_t total = 0;
+            for (const auto& mt : matches) total += mt.scene_corrs.size();
+            added.reserve(total);
+        }
         for (auto& mt : matches) {
             for (uint32_t idx : mt.scene_corrs) mask[idx] = 1; /* :88-90 */
+            added.insert(added.end(), mt.scene_corrs.begin(), mt.scene_corrs.end());
             results.push_back(std::move(mt));
         }
-        TM_TIMED(mask);
-        be.set_mask(mask);
+        detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
     }
     return results;
 }

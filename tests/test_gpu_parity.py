@@ -250,6 +250,25 @@ def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
         cp, sp = gpu_small["scene"].score_hypotheses_on_points(gpu_small["model"], poses, sub, DT)
         cso, _, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, subset=sub)
         assert np.array_equal(cp, cs) and np.array_equal(sp, ss) and np.array_equal(cs, cso)
+        # mask_add: the listed points set on top of the current mask == set_mask with the updated mask (counts, scores,
+        # radius neighbourhoods, the host-side sample filter), also in two instalments and with repeated indices
+        more = inst0[1::4].astype(np.uint32)
+        gpu_small["scene"].mask_add(more[: len(more) // 2])
+        gpu_small["scene"].mask_add(np.r_[more[len(more) // 2:], more[:3]])
+        mask2 = mask.copy()
+        mask2[more] = 1
+        oracle_small["scene"].set_mask(mask2)
+        co2, so2, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT)
+        ca, sa = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+        assert np.array_equal(ca, co2) and np.allclose(sa, so2, rtol=SCORE_RTOL, atol=1e-15)
+        gpu_small["scene"].set_mask(mask2)
+        cb, sb = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+        assert np.array_equal(ca, cb) and np.array_equal(sa, sb)
+        gpu_small["scene"].set_mask(None)
+        gpu_small["scene"].set_mask(None)  # clearing a clear mask is a no-op
+        gpu_small["scene"].mask_add(np.flatnonzero(mask2).astype(np.uint32))
+        cc, sc_ = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
+        assert np.array_equal(cc, cb) and np.array_equal(sc_, sb)
     finally:
         oracle_small["scene"].set_mask(None)
         gpu_small["scene"].set_mask(None)
@@ -1096,7 +1115,7 @@ def test_search_batch_equals_generate_score_scan(gpu_small, oracle_small, small_
     c, sc, dr, _ = gs.score_hypotheses_early_drop_ball(gm, poses, centers, diam, DT, 0.5)
     order = np.sort(c[sc > 0])
     for env in ({"search_segment": 0}, {"search_segment": 300}, {"ed_unfused": 1}, {"ed_narrow": 1},
-                {"ed_one_kernel": 1}, {"ed_wide": 1, "search_segment": 0}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1}, {"ed_prefix_list": 0},
+                {"ed_one_kernel": 1}, {"ed_wave_rows": 0}, {"ed_wave_rows": 1}, {"ed_prefix_list": 0},
                 {"ed_wave_rows": 3, "search_segment": 300}, {"ed_hist": 0}, {"ed_hist": 0, "ed_wave_rows": 0}, {"ed_prefix_group": 0}, {"ed_prefix_group": 0, "ed_hist": 0}, {"ed_ball_list": 0}, {"ed_prefix_group": 5},
                 {"ed_hist": 0, "search_segment": 300}, {"search_step_check": 0}, {"search_step_check": 0, "search_segment": 300}):
         old_env = {k: gs.ctx.get_option(k) for k in env}
@@ -1258,7 +1277,7 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
     # the other instantiations and hand-out forms of the item kernel: 64-bit addresses for its gathers (what a voxel table
     # beyond 4 GiB takes), a fixed item share per wave, no continuation in other XCDs' items, short runs per XCD, a small
     # persistent grid — same integers every way
-    for opts in ({"score_off32": 0}, {"item_static": 1}, {"item_nosteal": 1}, {"item_run": 0}, {"item_run": 3, "item_sort": 4},
+    for opts in ({"score_off32": 0}, {"item_sort": 4},
                  {"score_item_wgs": 8}, {"score_off32": 0, "group_hyps": 32}):
         old = {k: gpu_ctx.get_option(k) for k in opts}
         for k, v in opts.items():

@@ -22,3 +22,5 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA
   timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $out/pass$i -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/pass$i.json 2> $out/pass$i.log || echo "pass $i failed rc=$?" >> $out/progress.log
 done
 python3 tools/pmc_summary.py $out
+# the raw counter tables are tens of MB per pass (gpurun copies back at most 64 MiB): the summary is what is kept
+[ -n "$PMC_KEEP_RAW" ] || rm -rf $out/pass*/

@@ -105,6 +105,7 @@ SIGNATURES = {
     "tm_scene_create_dev": (C.c_int, [vp, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(vp)]),
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
+    "tm_scene_mask_add": (C.c_int, [vp, u32p, C.c_uint32]),
     "tm_scene_size": (C.c_uint32, [vp]),
     "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
     "tm_scene_probe_projected": (C.c_int, [vp, C.c_int, f32p, C.c_float, u64p, u32p]),
@@ -794,6 +795,11 @@ class Scene:
         else:
             m, p = _i(mask)
             _check(lib().tm_scene_set_mask(self.h, p))
+
+    def mask_add(self, indices):
+        """mask_[idx] = 1 for the listed points, on top of the current mask (reference include/impl/scene.hpp:87-90)"""
+        idx, p = _u(indices)
+        _check(lib().tm_scene_mask_add(self.h, p, idx.size))
 
     def curvature_subset(self, indices, k=30):
         """curvature(k, idx) of the listed points from the scene's device copy (tm_scene_curvature_subset)"""

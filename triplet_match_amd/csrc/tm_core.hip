@@ -96,6 +96,17 @@ static void pool_trim_locked(device_pool& pool, size_t keep) {
     }
 }
 
+/* An allocation failed: give back what EVERY live context of this process holds in its cache (contexts of other
+ * threads may sit on gigabytes of released blocks while this one runs out), not only the caller's. */
+static void pool_trim_all() {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    if (g_exiting) return;
+    for (tm_ctx* other : g_ctx_live) {
+        std::lock_guard<std::mutex> pl(other->pool.mu);
+        pool_trim_locked(other->pool, 0);
+    }
+}
+
 void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner) {
     tm_ctx* c = current_ctx();
     if (bytes == 0) bytes = 1;
@@ -118,10 +129,9 @@ void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner) {
         }
         if (!p) {
             hipError_t e = hipMalloc(&p, cap);
-            if (e != hipSuccess) { /* give the cache back to the device and try once more */
+            if (e != hipSuccess) { /* give the caches back to the device and try once more */
                 (void)hipGetLastError();
-                std::lock_guard<std::mutex> lk(c->pool.mu);
-                pool_trim_locked(c->pool, 0);
+                pool_trim_all();
                 e = hipMalloc(&p, cap);
             }
             if (e != hipSuccess) {
@@ -137,6 +147,11 @@ void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner) {
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        pool_trim_all();
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
         return nullptr;
     }
@@ -146,15 +161,20 @@ void* device_take(size_t bytes, size_t* capacity, tm_ctx** owner) {
 void device_give(void* p, size_t capacity, tm_ctx* owner) {
     if (!p) return;
     /* back to its context's cache while that context lives and keeps one; a block larger than half the budget is
-     * not worth holding on to (a voxel table) */
-    if (owner && ctx_alive(owner) && owner->opt.pool_mib > 0) {
-        const size_t limit = (size_t)owner->opt.pool_mib << 20;
-        if (capacity <= limit / 2) {
-            std::lock_guard<std::mutex> lk(owner->pool.mu);
-            owner->pool.free_blocks.emplace(capacity, p);
-            owner->pool.cached_bytes += capacity;
-            pool_trim_locked(owner->pool, limit);
-            return;
+     * not worth holding on to (a voxel table). The liveness check and the insertion happen under g_ctx_mutex, which
+     * tm_ctx_destroy takes before it unlists and deletes a context: a block released by another thread (a local dbuf,
+     * garbage collection in arbitrary order) can no longer reach a context that is being torn down. */
+    if (owner) {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        if (!g_exiting && g_ctx_live.count(owner) != 0 && owner->opt.pool_mib > 0) {
+            const size_t limit = (size_t)owner->opt.pool_mib << 20;
+            if (capacity <= limit / 2) {
+                std::lock_guard<std::mutex> pl(owner->pool.mu);
+                owner->pool.free_blocks.emplace(capacity, p);
+                owner->pool.cached_bytes += capacity;
+                pool_trim_locked(owner->pool, limit);
+                return;
+            }
         }
     }
     (void)hipFree(p);
@@ -168,22 +188,15 @@ struct opt_entry {
 static const opt_entry kOptions[] = {
     {"ablate", &options::ablate, 0, 255},
     {"debug_stats", &options::debug_stats, 0, 1},
-    {"debug_items", &options::debug_items, 0, 1},
     {"debug_times", &options::debug_times, 0, 1},
     {"debug_ed", &options::debug_ed, 0, 1},
     {"score_grouped", &options::score_grouped, 0, 1},
     {"ball_ungrouped", &options::ball_ungrouped, 0, 1},
     {"group_hyps", &options::group_hyps, 16, 32},
-    {"item_static", &options::item_static, 0, 1},
-    {"item_nosteal", &options::item_nosteal, 0, 1},
-    {"item_run", &options::item_run, -1, 30},
     {"score_item_wgs", &options::score_item_wgs, 0, 1 << 20},
-    {"score_parts", &options::score_parts, 1, 64},
     {"item_sort", &options::item_sort, -1, 6},
     {"score_slot_mib", &options::score_slot_mib, 1, 1 << 16},
     {"near_metric", &options::near_metric, 0, 2},
-    {"model_morton", &options::model_morton, 0, 1},
-    {"scene_morton", &options::scene_morton, 0, 1},
     {"voxel_bruteforce", &options::voxel_bruteforce, 0, 1},
     {"voxel_packet", &options::voxel_packet, 0, 1},
     {"voxel_seed", &options::voxel_seed, 0, 1},
@@ -191,7 +204,6 @@ static const opt_entry kOptions[] = {
     {"model_host_build", &options::model_host_build, 0, 1},
     {"ed_one_kernel", &options::ed_one_kernel, 0, 1},
     {"ed_narrow", &options::ed_narrow, 0, 1},
-    {"ed_wide", &options::ed_wide, 0, 1},
     {"ed_bruteforce", &options::ed_bruteforce, 0, 1},
     {"ed_unfused", &options::ed_unfused, 0, 1},
     {"search_segment", &options::search_segment, -1, 1 << 24},

@@ -826,6 +826,14 @@ __global__ __launch_bounds__(256) void k_ed_hist_list(ed_args a, const float4* _
     uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(s_h);
     const uint32_t e_base = blockIdx.x * kEdListChunk;
     const uint32_t run = (n_rows + gridDim.y - 1u) / gridDim.y; /* consecutive rows per workgroup */
+    /* The rows are in visit order, so a workgroup's consecutive rows are mostly hypotheses of ONE first point: the same
+     * neighbourhood list. A lane's entries of that list (scene index, scan position, the point itself) stay in its
+     * registers from one row to the next and are fetched again only when the neighbourhood changes: the two dependent
+     * loads at the head of every row's chain (list entry -> scene position) are paid once per neighbourhood. */
+    uint32_t staged_slot = 0xFFFFFFFFu;
+    uint32_t sidx[kEdListRounds][kEdNT], pos[kEdListRounds][kEdNT];
+    f3 pt[kEdListRounds][kEdNT];
+    bool live[kEdListRounds][kEdNT];
     for (uint32_t row = blockIdx.y * run; row < min(n_rows, (blockIdx.y + 1u) * run); ++row) {
         if (!ed_row_selected(a, row0 + row)) continue;
         const uint32_t hl = pending[row0 + row];
@@ -842,41 +850,46 @@ __global__ __launch_bounds__(256) void k_ed_hist_list(ed_args a, const float4* _
         }
         __syncthreads();
         const float per_pos = S ? 20.f / (float)S : 0.f;
-        const uint2* bl = a.ball.blist + (size_t)slot * a.ball.blist_stride;
+        if (slot != staged_slot) { /* uniform: the whole workgroup changes neighbourhood together */
+            const uint2* bl = a.ball.blist + (size_t)slot * a.ball.blist_stride;
+#pragma unroll
+            for (uint32_t r = 0; r < kEdListRounds; ++r) {
+                uint2 en[kEdNT];
+#pragma unroll
+                for (int i = 0; i < kEdNT; ++i) {
+                    const uint32_t e = e_base + (r * (uint32_t)kEdNT + (uint32_t)i) * 256u + threadIdx.x;
+                    live[r][i] = e < n_e;
+                    en[i] = live[r][i] ? bl[e] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int i = 0; i < kEdNT; ++i) {
+                    const float4 P = live[r][i] ? spos[en[i].x] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sidx[r][i] = en[i].x;
+                    pos[r][i] = en[i].y;
+                    pt[r][i] = make3(P.x, P.y, P.z);
+                }
+            }
+            staged_slot = slot;
+        }
+#pragma unroll
         for (uint32_t r = 0; r < kEdListRounds; ++r) {
-            uint32_t sidx[kEdNT], pos[kEdNT];
-            f3 pt[kEdNT];
-            bool live[kEdNT], tail[kEdNT], corr[kEdNT];
+            bool tail[kEdNT], corr[kEdNT];
             long long fx[kEdNT];
-            uint2 en[kEdNT];
-#pragma unroll
-            for (int i = 0; i < kEdNT; ++i) {
-                const uint32_t e = e_base + (r * (uint32_t)kEdNT + (uint32_t)i) * 256u + threadIdx.x;
-                live[i] = e < n_e;
-                en[i] = live[i] ? bl[e] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int i = 0; i < kEdNT; ++i) {
-                const float4 P = live[i] ? spos[en[i].x] : make_float4(0.f, 0.f, 0.f, 0.f);
-                sidx[i] = en[i].x;
-                pos[i] = en[i].y;
-                pt[i] = make3(P.x, P.y, P.z);
-            }
-            eval_points_staged<kEdNT>(a.sc, [&](int) -> const pose12& { return T; }, pt, sidx, live, tail, corr, fx);
+            eval_points_staged<kEdNT>(a.sc, [&](int) -> const pose12& { return T; }, pt[r], sidx[r], live[r], tail, corr, fx);
 #pragma unroll
             for (int i = 0; i < kEdNT; ++i) {
                 if (!tail[i]) continue;
                 /* interval of pos: j = #{k : x_k <= pos}; the guess is exact up to the rounding of tests[] */
-                uint32_t j = min(18u, (uint32_t)((float)(pos[i] + 1u) * per_pos));
-                while (j < 18u && s_x[j] <= pos[i]) ++j;
-                while (j > 0u && s_x[j - 1u] > pos[i]) --j;
+                uint32_t j = min(18u, (uint32_t)((float)(pos[r][i] + 1u) * per_pos));
+                while (j < 18u && s_x[j] <= pos[r][i]) ++j;
+                while (j > 0u && s_x[j - 1u] > pos[r][i]) --j;
                 if (corr[i]) {
                     atomicAdd(&s_cnt[j], 1u);
                     atomicAdd(&s_h[kEdHistFx + j], (unsigned long long)fx[i]);
                     if ((unsigned long long)fx[i] >> 41) atomicAdd(&s_cnt[19], 1u);
                 }
                 if (j > 0u) {
-                    const unsigned long long key = ((unsigned long long)pos[i] << 42) | (corr[i] ? 0ull : 1ull << 41) |
+                    const unsigned long long key = ((unsigned long long)pos[r][i] << 42) | (corr[i] ? 0ull : 1ull << 41) |
                                                    (corr[i] ? ((unsigned long long)fx[i] & ((1ull << 41) - 1ull)) : 0ull);
                     if (key < s_h[kEdHistMin + j - 1u]) atomicMin(&s_h[kEdHistMin + j - 1u], key);
                 }
@@ -1660,6 +1673,8 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
         /* rows side by side: a search step has a few dozen pending rows per wave, the whole batch over a thousand */
+        /* (fewer, longer workgroups — 128 / 64 / 32 — reuse more of a neighbourhood's registers and are 2 / 5 / 12 %
+         * slower on the whole batch; 512 and 1024 measure the same as 256) */
         const uint32_t gy = std::min(n_hyp, check ? 64u : 256u);
         hipLaunchKernelGGL(k_ed_hist_init, dim3((uint32_t)(((size_t)n_hyp * kEdHistWords + 255) / 256)), dim3(256), 0,
                            c->stream, s->ed_hist.p, d_n, 0u, n_hyp, fb_n);
@@ -2242,7 +2257,7 @@ static int ed_ball_core(tm_scene* s, tm_model* m, const float* d_poses, uint32_t
          * pays for the few rows of a segment (end-to-end search 0.030 against 0.034 s) */
         a.h0 = 0;
         TM_HIP_CHECK(launch_ed_fused(s, c, n_hyp, fused_lds, a, cu, o, accept_thresh, d_tests.p,
-                                     n_hyp <= 4096u || big_lds || c->opt.ed_wide ? chunk : 0u));
+                                     n_hyp <= 4096u || big_lds ? chunk : 0u));
         if (c->opt.debug_ed) { /* how many hypotheses the prefix kernel could not decide */
             uint32_t n_pend = 0;
             TM_HIP_CHECK(hipMemcpyAsync(&n_pend, s->ed_pending.p + n_hyp, 4, hipMemcpyDeviceToHost, c->stream));

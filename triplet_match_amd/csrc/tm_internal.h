@@ -99,17 +99,12 @@ constexpr int kTimedWords = 8; /* evaluations, passing, in-grid, near, staged it
 struct options {
     int ablate = 0;           /* TM_ABLATE (timing-experiments build only) */
     int debug_stats = 0;      /* per-launch stage counts on stderr */
-    int debug_items = 0;      /* + item statistics of the grouped kernel */
     int debug_times = 0;      /* laps of tm_cloud_curvature */
     int debug_ed = 0;         /* pending counts of the early-drop prefix kernel */
     int score_grouped = 1;    /* 0: the per-hypothesis kernel (k_score_culled) for every launch */
     int ball_ungrouped = 0;   /* 1: k_score_culled for ball-restricted scoring */
     int group_hyps = 16;      /* 16 or 32 hypotheses per group */
-    int item_static = 0;      /* 1: fixed item share per wave */
-    int item_nosteal = 0;     /* 1: no continuation in other XCDs' items */
-    int item_run = -1;        /* log2 of the run of items one XCD owns; -1 = from the item count */
     int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
-    int score_parts = 3;      /* workgroups per hypothesis of k_score_culled */
     int item_sort = -1;       /* the items of the grouped kernel binned by the model region they land in: cells of
                                  2^item_sort voxels (2..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and
                                  more against a voxel table of 256 MB and more (see score_device), 0 = never */
@@ -117,13 +112,12 @@ struct options {
     int score_off32 = 1;      /* 0: 64-bit addresses for the grouped kernel's gathers also when every table is below 4 GiB */
     int near_metric = 1;      /* brick filters under a plane2 / cylinder metric: 0 never, 1 when at least a tenth of
                                  the grid's bricks lies beyond the threshold (auto), 2 always */
-    int model_morton = 0, scene_morton = 0; /* Morton instead of Hilbert order */
     int voxel_bruteforce = 0; /* exhaustive voxel NN kernel */
     int voxel_packet = 1;     /* 0: kd descent per voxel on per-thread stacks instead of one packet per brick */
     int voxel_seed = 1;       /* 0: the packet walk of the voxel grid starts without a candidate */
     int curv_groups = 1;      /* 0: the curvature pass's neighbour lists one thread per query (lists in LDS) instead of eight lanes per query */
     int model_host_build = 0; /* 1: tm_model_create sorts the cloud and builds a median kd-tree on the host (cross-check) */
-    int ed_one_kernel = 0, ed_narrow = 0, ed_wide = 0, ed_bruteforce = 0, ed_unfused = 0;
+    int ed_one_kernel = 0, ed_narrow = 0, ed_bruteforce = 0, ed_unfused = 0;
     int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
     int ed_prefix_list = 1;   /* 0: the first step of the early-drop rule walks the neighbourhood list (scan order)
                                  instead of the same positions in the scene's curve order */
@@ -327,6 +321,8 @@ struct tm_scene {
      * points, and the drop-in search never reads it */
     mutable std::vector<float> h_cloud;
     tmx::mask_mirror h_tmask, h_mask;
+    tmx::dbuf<uint32_t> w_mask_idx; /* tm_scene_mask_add: the listed indices on the device */
+    bool h_mask_stale = false; /* tm_scene_mask_add changed d_mask only: h_mask is refreshed on its next read (scene_host_mask) */
     /* A projected scene (tm_scene_create_projected) keeps its host mirror SPARSE: the host side of the search only
      * ever reads the surfels of tangent points (sample filters), so only those come back from the device — 1.7 MB
      * instead of 48 MB per projector at 1M points. h_tan_idx ascending, h_tan_rows 12 floats each; h_cloud stays
@@ -491,6 +487,7 @@ inline int scene_pinned_ensure(tm_scene* s, size_t need) {
 int scene_mirror(const tm_scene* s);
 /* host mirror row of point i (12 floats), or null for a point a sparse mirror does not hold */
 const float* scene_row(const tm_scene* s, uint32_t i);
+int scene_host_mask(const tm_scene* s);
 }
 
 #endif /* TM_INTERNAL_H_ */

@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void k_knn_groups(const float4* __restrict__ k
     }
     while (sp > 0) {
         --sp;
+        /* lane 0 of the group wrote the entry, all eight read it: an LDS hand-over inside the wave, fenced so that
+         * the compiler keeps the write before the reads (no workgroup barrier: the groups of a wave diverge) */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t node = st_node[sp][grp];
         if (st_bound[sp][grp] > wd) continue;
         for (;;) {

@@ -1076,7 +1076,7 @@ int tm_model_create(tm_ctx* ctx, const float* surfels, uint32_t n, float resolut
      * space are neighbours in the arrays, so the scoring kernel's gathers of model points share lines.
      * TM_MODEL_MORTON=1 selects the plain Morton order (timing comparisons). */
     {
-        const bool hilbert = !ctx->opt.model_morton;
+        const bool hilbert = true;
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (uint32_t i = 0; i < n; ++i) {
             const float* s = surfels + (size_t)i * 12;
@@ -1572,7 +1572,7 @@ static int model_arrays_on_device(tm_model* m, const float* surfels) {
     }
     hipError_t e = hipMemcpyAsync(d_cloud.p, surfels, (size_t)n * 48, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        rc = curve_order(c, d_cloud.p, n, !c->opt.model_morton, d_bounds.p, d_keys, d_order);
+        rc = curve_order(c, d_cloud.p, n, true, d_bounds.p, d_keys, d_order);
         if (rc) {
             cleanup();
             return rc;

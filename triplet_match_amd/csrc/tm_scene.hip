@@ -410,9 +410,7 @@ struct group_args {
     const uint32_t* items;  /* slots with a non-zero mask */
     const uint32_t* n_items;
     const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
-    uint32_t* heads;        /* per XCD (128 bytes apart): next item of its range, or null = static shares */
-    uint32_t steal;         /* 1 = a wave whose XCD's range is exhausted continues in the other XCDs' ranges */
-    uint32_t run_shift;     /* log2 of the run of consecutive items one XCD owns; 0xFFFFFFFF = from n_items */
+    uint32_t* heads;        /* per XCD (128 bytes apart): the next item of its runs */
 };
 
 struct nonzero_mask {
@@ -420,15 +418,17 @@ struct nonzero_mask {
 };
 
 /* per hypothesis: Frobenius norm of the rotation block and the absolute rounding slack of the sphere tests */
+__device__ __forceinline__ float2 pose_aux(const pose12& T, float coord_max) {
+    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
+                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
+                              T.r22 * T.r22);
+    return make_float2(rnorm, 1e-6f * (3.f * rnorm * coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f));
+}
 __global__ __launch_bounds__(256) void k_pose_aux(const float* __restrict__ poses, uint32_t n_hyp, float coord_max,
                                                   float2* __restrict__ aux) {
     const uint32_t h = blockIdx.x * 256 + threadIdx.x;
     if (h >= n_hyp) return;
-    const pose12 T = load_pose(poses + (size_t)h * 16);
-    const float rnorm = sqrtf(((T.r00 * T.r00 + T.r10 * T.r10) + (T.r20 * T.r20 + T.r01 * T.r01)) +
-                              ((T.r11 * T.r11 + T.r21 * T.r21) + (T.r02 * T.r02 + T.r12 * T.r12)) +
-                              T.r22 * T.r22);
-    aux[h] = make_float2(rnorm, 1e-6f * (3.f * rnorm * coord_max + fabsf(T.tx) + fabsf(T.ty) + fabsf(T.tz) + 1.f));
+    aux[h] = pose_aux(load_pose(poses + (size_t)h * 16), coord_max);
 }
 
 /* One workgroup per (group, 256 super-tiles of 8 chunks). Phase 1: a thread = a super-tile, its sphere under each of the
@@ -621,10 +621,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
     const uint32_t n_items = *ga.n_items;
     /* XCD-aware split (speed only): blocks b and b + 8 share an L2; consecutive items belong to the same
      * group of hypotheses, whose voxel neighbourhoods overlap: give each XCD a contiguous range of items */
-    const uint32_t xcd = blockIdx.x & 7u, waves_per_xcd = (gridDim.x >> 3) * 4u;
-    const uint32_t wave_in_xcd = (blockIdx.x >> 3) * 4u + wave;
-    const uint32_t lo = (uint32_t)(((unsigned long long)n_items * xcd) >> 3);
-    const uint32_t hi = (uint32_t)(((unsigned long long)n_items * (xcd + 1u)) >> 3);
+    const uint32_t xcd = blockIdx.x & 7u;
     uint32_t evals = 0, pass = 0, n_in = 0, n_near = 0;
     float* pts = reinterpret_cast<float*>(s_raw[wave]);                                   /* 512 x packed xyz */
     float4* poses = reinterpret_cast<float4*>(s_raw[wave] + 6144);                        /* 3 float4 per pose */
@@ -642,12 +639,11 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
      * consecutive items handed out in order, so the waves of one L2 work on neighbouring items at any time
      * (one counter for the whole chip: 11.7 ms); runs of 8192 and one contiguous range per XCD measure the
      * same, shorter runs lose locality (128: 9.95 ms). */
-    const uint32_t run_shift =
-        ga.run_shift != 0xFFFFFFFFu ? ga.run_shift : min(13u, max(6u, 31u - (uint32_t)__clz((int)((n_items >> 6) | 1u))));
-    uint32_t it = lo + wave_in_xcd, victim = 0, pend = 0;
-    if (ga.heads && lane == 0) pend = atomicAdd(ga.heads + 32u * xcd, 1u);
+    const uint32_t run_shift = min(13u, max(6u, 31u - (uint32_t)__clz((int)((n_items >> 6) | 1u))));
+    uint32_t it = 0, victim = 0, pend = 0;
+    if (lane == 0) pend = atomicAdd(ga.heads + 32u * xcd, 1u);
     for (;;) {
-        if (ga.heads) {
+        {
             /* own items first, then those of the XCDs after this one (the tail of the kernel only); the
              * counter is read one item ahead so its round trip to the fabric is off the item's path */
             const uint32_t x = (xcd + victim) & 7u;
@@ -655,13 +651,11 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             /* the n-th item of XCD x: runs of 2^run_shift consecutive items go round the XCDs */
             it = ((((nxt >> run_shift) << 3) + x) << run_shift) + (nxt & ((1u << run_shift) - 1u));
             if (it >= n_items) {
-                if (++victim == 8u || ga.steal == 0u) break;
+                if (++victim == 8u) break;
                 if (lane == 0) pend = atomicAdd(ga.heads + 32u * ((xcd + victim) & 7u), 1u);
                 continue;
             }
             if (lane == 0) pend = atomicAdd(ga.heads + 32u * x, 1u);
-        } else if (it >= hi) {
-            break;
         }
         const uint32_t slot = ga.items[it];
         const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
@@ -769,10 +763,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 ent[o++] = (unsigned short)((g << 5) | lane);
             }
         }
-        if (n == 0u || TM_ABLATE_EQ(a, 10)) { /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
-            if (!ga.heads) it += waves_per_xcd;
-            continue;
-        }
+        if (n == 0u || TM_ABLATE_EQ(a, 10)) continue; /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -911,7 +902,6 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                 acc[lane] = 0ull;
             }
         }
-        if (!ga.heads) it += waves_per_xcd;
     }
     if (!STATS) return;
     for (int off = 32; off > 0; off >>= 1) {
@@ -942,7 +932,7 @@ template <bool STATS>
 static items_kernel_t items_kernel(bool l2, uint32_t group_hyps, bool ball, bool near_metric, bool w32) {
     if (near_metric)
         return ball               ? k_score_items<false, 4, 16, true, true, false, STATS>
-               : group_hyps == 16u ? k_score_items<false, 4, 16, false, true, false, STATS>
+               : group_hyps == 16u ? (w32 ? k_score_items<false, 4, 16, false, true, true, STATS> : k_score_items<false, 4, 16, false, true, false, STATS>)
                                    : k_score_items<false, 4, 32, false, true, false, STATS>;
     if (ball) return l2 ? k_score_items<true, 4, 16, true, true, false, STATS> : k_score_items<false, 4, 16, true, false, false, STATS>;
     if (group_hyps == 16u) {
@@ -1516,16 +1506,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             ga.items = s->w_items.p;
             ga.n_items = s->w_items.p + n_slots_g;
             d_n_items = ga.n_items;
-            ga.heads = nullptr;
-            ga.steal = 0;
-            ga.run_shift = 0;
-            if (!c->opt.item_static) { /* dynamic hand-out of the items: eight head words, 128 B apart */
-                TM_FORWARD(s->w_heads.ensure(8 * 32));
-                TM_HIP_CHECK(hipMemsetAsync(s->w_heads.p, 0, 8 * 32 * 4, c->stream));
-                ga.heads = s->w_heads.p;
-                ga.steal = c->opt.item_nosteal ? 0u : 1u;
-                ga.run_shift = c->opt.item_run >= 0 ? (uint32_t)c->opt.item_run : 0xFFFFFFFFu;
-            }
+            /* dynamic hand-out of the items: eight head words (one per XCD), 128 B apart */
+            TM_FORWARD(s->w_heads.ensure(8 * 32));
+            TM_HIP_CHECK(hipMemsetAsync(s->w_heads.p, 0, 8 * 32 * 4, c->stream));
+            ga.heads = s->w_heads.p;
             hipLaunchKernelGGL(k_group_cull, dim3(ga.n_groups, ((ga.n_chunks + 7) / 8 + 255) / 256), dim3(256), 0, c->stream,
                                a, ca, ga);
             size_t tmp = 0;
@@ -1592,23 +1576,10 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             if (c->opt.debug_stats)
                 fprintf(stderr, "[tm] grouped: %u persistent workgroups (%d per CU)\n", wgs, per_cu);
             hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, c->stream, a, ca, ga);
-            if (c->opt.debug_stats && c->opt.debug_items) {
-                std::vector<group_mask_t> hm(n_slots_g);
-                TM_HIP_CHECK(hipMemcpyAsync(hm.data(), s->w_masks.p, n_slots_g * sizeof(group_mask_t), hipMemcpyDeviceToHost,
-                                            c->stream));
-                TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-                unsigned long long items = 0, steps = 0;
-                for (group_mask_t v : hm) {
-                    items += v != 0;
-                    steps += (unsigned)__builtin_popcount(v);
-                }
-                fprintf(stderr, "[tm] grouped: %u groups x %u chunks, %llu items, %llu (item, hypothesis) steps\n",
-                        ga.n_groups, ga.n_chunks, items, steps);
-            }
         } else {
-        /* split every hypothesis over `parts` workgroups (rounds of 1024 tiles taken in turn): shorter
-         * workgroups even out the tail of the launch; TM_SCORE_PARTS overrides (1 = no split) */
-        uint32_t parts = (uint32_t)std::max(1, c->opt.score_parts);
+        /* split every hypothesis over three workgroups (rounds of 1024 tiles taken in turn): shorter
+         * workgroups even out the tail of the launch */
+        uint32_t parts = 3u;
         parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, (s->n_tiles + kCullChunk - 1) / kCullChunk));
         if (parts > 1) TM_HIP_CHECK(hipMemsetAsync(s->w_stats.p, 0, n_slots * sizeof(uint4), c->stream));
         const dim3 cgrid(n_hyp, parts);
@@ -1903,6 +1874,7 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_pairs.release();
     s->w_words.release();
     s->w_corr.release();
+    s->w_mask_idx.release();
     s->w_active_sorted.release();
     s->ed_subset.release();
     s->ed_dropped.release();
@@ -1939,9 +1911,39 @@ int tm_scene_set_mask(tm_scene* s, const int32_t* mask) {
         TM_HIP_CHECK(hipMemcpyAsync(s->d_mask.p, static_cast<const tmx::mask_mirror&>(s->h_mask).data(), (size_t)s->n * 4,
                                     hipMemcpyHostToDevice, s->ctx->stream));
     } else {
-        s->h_mask.assign(s->n, 0);
+        if (!s->h_mask_stale && s->h_mask.all_zero() && s->h_mask.size() == s->n && s->n_sorted) return TM_OK; /* clear already */
+        s->h_mask.assign(s->n, 0); /* calloc: zero pages nobody touches until a helper writes */
         TM_HIP_CHECK(hipMemsetAsync(s->d_mask.p, 0, (size_t)s->n * 4, s->ctx->stream));
     }
+    s->h_mask_stale = false;
+    return scene_build(s, false);
+}
+
+/* mask_[idx] = 1 for the listed points (include/impl/scene.hpp:87-90: the accepted matches' correspondences), on
+ * top of the mask the scene holds: the indices go up (4 bytes each) instead of the whole mask (4 bytes per scene
+ * point, twice: host mirror and upload), the device sets its words and derives the masked arrays again. */
+__global__ __launch_bounds__(256) void k_mask_set(const uint32_t* __restrict__ idx, uint32_t n, int32_t* __restrict__ mask) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) mask[idx[t]] = 1;
+}
+int tm_scene_mask_add(tm_scene* s, const uint32_t* indices, uint32_t n_idx) {
+    TM_GUARD(s);
+    TM_REQUIRE(s && (indices || n_idx == 0), TM_ERR_INVALID, "tm_scene_mask_add: null argument");
+    if (n_idx == 0) return TM_OK;
+    uint32_t mx = 0;
+    for (uint32_t k = 0; k < n_idx; ++k) mx = std::max(mx, indices[k]);
+    TM_REQUIRE(mx < s->n, TM_ERR_INVALID, "tm_scene_mask_add: index out of range");
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    /* the host mirror of mask_ is not touched here (it would be one scattered write per index into a 4 n-byte array):
+     * the helpers that read it (tm_pair_is_valid_sample, the live count) fetch it from the device when it is stale */
+    s->h_mask_stale = true;
+    TM_FORWARD(tmx::scene_pinned_ensure(s, (size_t)n_idx * 4));
+    memcpy(s->h_pinned, indices, (size_t)n_idx * 4);
+    TM_FORWARD(s->w_mask_idx.ensure(n_idx));
+    TM_HIP_CHECK(hipMemcpyAsync(s->w_mask_idx.p, s->h_pinned, (size_t)n_idx * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_mask_set, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, s->w_mask_idx.p, n_idx, s->d_mask.p);
+    TM_HIP_CHECK(hipGetLastError());
     return scene_build(s, false);
 }
 
@@ -2026,9 +2028,15 @@ int tm_pair_is_valid_sample(const tm_scene* s, const tm_model* m, uint32_t i, ui
                             float maxf) {
     TM_GUARD(s);
     if (!s || !m || !m->pairs_ready || i >= s->n || j >= s->n || i == j) return 0;
+    if (tmx::scene_host_mask(s) != TM_OK) return TM_ERR_HIP;
     if (s->h_mask[i] || !s->h_tmask[j] || s->h_mask[j]) return 0;
-    /* a sparse mirror holds the tangent points: i is a first sample, hence one of them */
-    return tm_pair_valid_raw(scene_row(s, i), scene_row(s, j), m->diameter, minf, maxf, m->bmin, m->bmax);
+    /* a sparse mirror holds the tangent points: i is a first sample, hence one of them. A full mirror is fetched from
+     * the device on first use (48 bytes per point + a stream synchronise): if that copy fails the answer is an error
+     * code (negative), not "invalid sample" — a search must not degrade silently */
+    const float* ri = scene_row(s, i);
+    const float* rj = scene_row(s, j);
+    if (!s->h_sparse && (!ri || !rj)) return TM_ERR_HIP; /* scene_mirror has set the error text */
+    return tm_pair_valid_raw(ri, rj, m->diameter, minf, maxf, m->bmin, m->bmax);
 }
 
 int tm_generate_hypotheses_dev(tm_scene* s, tm_model* m, const uint32_t* d_ij_pairs, uint32_t n_pairs,
@@ -2117,6 +2125,7 @@ int tm_score_hypotheses(tm_scene* s, tm_model* m, int traits_kind, const float* 
             TM_REQUIRE(subset[k] >= 0 && (uint32_t)subset[k] < s->n, TM_ERR_INVALID,
                        "tm_score_hypotheses: subset index out of range");
         if (s->h_act.size() != s->n) s->h_act.assign(s->n, 0);
+        TM_FORWARD(tmx::scene_host_mask(s));
         std::vector<unsigned char>& act = s->h_act;
         for (uint32_t k = 0; k < n_subset; ++k) {
             const uint32_t i = (uint32_t)subset[k];

@@ -469,7 +469,7 @@ int scene_build(tm_scene* s, bool resort) {
     hipLaunchKernelGGL(k_scene_original, grid_n, blk, 0, c->stream, s->d_cloud.p, s->d_tmask.p, s->d_mask.p, n,
                        s->opos.p, s->otan.p, s->oref.p);
     if (resort) {
-        TM_FORWARD(curve_order(c, s->d_cloud.p, n, !c->opt.scene_morton, bnd, s->d_keys, s->d_order));
+        TM_FORWARD(curve_order(c, s->d_cloud.p, n, true, bnd, s->d_keys, s->d_order));
     } else {
         TM_HIP_CHECK(hipMemsetAsync(&bnd->live, 0, 4, c->stream));
     }
@@ -597,6 +597,22 @@ int tmx::scene_mirror(const tm_scene* s) {
         set_error("scene mirror: %s", hipGetErrorString(e));
         return TM_ERR_HIP;
     }
+    return TM_OK;
+}
+
+/* the host mirror of mask_, brought up to date from the device copy when tm_scene_mask_add has changed that one */
+int tmx::scene_host_mask(const tm_scene* cs) {
+    tm_scene* s = const_cast<tm_scene*>(cs);
+    if (!s->h_mask_stale) return TM_OK;
+    TM_HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->h_mask.resize(s->n);
+    hipError_t e = hipMemcpyAsync(s->h_mask.data(), s->d_mask.p, (size_t)s->n * 4, hipMemcpyDeviceToHost, s->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->ctx->stream);
+    if (e != hipSuccess) {
+        set_error("scene mask mirror: %s", hipGetErrorString(e));
+        return TM_ERR_HIP;
+    }
+    s->h_mask_stale = false;
     return TM_OK;
 }
 

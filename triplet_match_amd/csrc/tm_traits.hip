@@ -302,6 +302,7 @@ int tm_scene_create_projected(tm_scene* src, int kind, const float* state, tm_sc
          * tangent points only, so only those travel: the ascending tangent index list (kept on the device for the
          * neighbourhood views as well), the gathered rows, and tangent_mask rebuilt from the list — 1.7 MB instead of
          * 52 MB per projector at a million points with 4 % tangent points. */
+        if (tmx::scene_host_mask(src) != TM_OK) e = hipErrorUnknown;
         t->h_mask = src->h_mask;
         t->h_sparse = true;
         if (e != hipSuccess) {
