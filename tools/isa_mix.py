@@ -3,6 +3,7 @@
 
   hipcc <build flags> --cuda-device-only -S -gline-tables-only triplet_match_amd/csrc/tm_scene.hip -o /tmp/tm_scene.s
   python tools/isa_mix.py /tmp/tm_scene.s ILb1ELi4ELi16ELb0ELb1ELb1ELb0E > profiles/rNN/isa_mix_k_score_items.md
+(run from the repo root: the stage boundaries are looked up by anchor text in the source the assembly was made from)
 
 Every instruction of the kernel is attributed to the source line of its innermost `.loc` (inlined helpers count for
 the stage that calls them: the stage table below maps file:line ranges to stages) and classified VALU / SALU / LDS /
@@ -12,28 +13,54 @@ import collections
 import re
 import sys
 
-path, want = sys.argv[1], sys.argv[2]
+path, want = sys.argv[1], sys.argv[2]  # [3] = the source file the anchors are looked up in
+SRC = sys.argv[3] if len(sys.argv) > 3 else "triplet_match_amd/csrc/tm_scene.hip"
+_src = open(SRC).read().split("\n")
+
+
+def _line(text, after=0):
+    """1-based number of the first source line containing `text` at or after line `after`"""
+    for i in range(after, len(_src)):
+        if text in _src[i]:
+            return i + 1
+    raise SystemExit("anchor not found in %s: %r" % (SRC, text))
+
+
+# stage boundaries are found by anchor text in the source, so the table survives edits of the file
+_k = _line("void k_score_items(score_args a, cull_args ca, group_args ga)")
+_stage = _line("/* stage the chunk", _k)
+_probe = _line("/* quarter-tile tests, two hypotheses per round", _k)
+_list = _line("/* Entry list in quarter-major order", _k)
+_turn = _line("auto turn = [&]", _k)
+_xf = _line("const float4* pp = poses + 3u * gk[k];", _turn)
+_addr = _line("uint32_t ix = in[k] ?", _turn)
+_near = _line("near[k] = in[k] & (code[k] <= a.code_max);", _turn)
+_model = _line("/* the model position and, for the near points", _turn)
+_orient = _line("/* orientation term (:441-488)", _turn)
+_flush = _line("/* flush the item's sums", _turn)
+_stats = _line("if (!STATS) return;", _flush)
+_end = _line("using items_kernel_t", _stats)
 STAGES = [  # (file suffix, first line, last line, stage, per)
-    ("tm_scene.hip", 626, 674, "hand-out / set-up", "item"),
-    ("tm_scene.hip", 675, 713, "staging (chunk + poses -> LDS)", "item"),
-    ("tm_scene.hip", 714, 757, "quarter-tile probes", "item"),
-    ("tm_scene.hip", 758, 788, "entry list", "item"),
-    ("tm_scene.hip", 789, 800, "entry decode", "iteration"),
-    ("tm_scene.hip", 801, 813, "transform + in-grid test", "iteration"),
-    ("tm_scene.hip", 814, 820, "voxel address + brick code", "iteration"),
-    ("tm_scene.hip", 821, 832, "near test + voxel gather", "iteration"),
-    ("tm_scene.hip", 833, 857, "model gather + distance", "iteration"),
-    ("tm_scene.hip", 858, 904, "orientation + reduction", "iteration"),
-    ("tm_scene.hip", 905, 919, "flush", "item"),
-    ("tm_scene.hip", 920, 941, "stats epilogue", "kernel"),
+    ("tm_scene.hip", _k, _stage - 1, "hand-out / set-up", "item"),
+    ("tm_scene.hip", _stage, _probe - 1, "staging (chunk + poses -> LDS)", "item"),
+    ("tm_scene.hip", _probe, _list - 1, "quarter-tile probes", "item"),
+    ("tm_scene.hip", _list, _turn - 1, "entry list", "item"),
+    ("tm_scene.hip", _turn, _xf - 3, "entry decode", "iteration"),
+    ("tm_scene.hip", _xf - 2, _addr - 1, "transform + in-grid test", "iteration"),
+    ("tm_scene.hip", _addr, _near - 3, "voxel address + brick code", "iteration"),
+    ("tm_scene.hip", _near - 2, _model - 1, "near test + voxel gather", "iteration"),
+    ("tm_scene.hip", _model, _orient - 1, "model + orientation records, distance", "iteration"),
+    ("tm_scene.hip", _orient, _flush - 1, "orientation term + LDS atomic", "iteration"),
+    ("tm_scene.hip", _flush, _stats - 1, "flush", "item"),
+    ("tm_scene.hip", _stats, _end - 1, "stats epilogue", "kernel"),
 ]
-HELPERS = {  # inlined helpers by function-ish line ranges
-    ("tm_scene.hip", 575, 581): ("orientation + reduction", "iteration"),   # row16_sum
-    ("tm_scene.hip", 589, 596): ("quarter-tile probes", "item"),            # lds_pose
-    ("tm_scene.hip", 597, 601): ("transform + in-grid test", "iteration"),  # lds_xform_point
-    ("tm_scene.hip", 602, 606): ("orientation + reduction", "iteration"),   # lds_xform_dir
-    ("tm_scene.hip", 611, 615): ("gather addressing (ld_off32)", "iteration"),
-    ("tm_scene.hip", 100, 160): ("quarter-tile probes", "item"),            # tile_probe / tile_decide
+_h = lambda t: _line(t)
+HELPERS = {  # inlined helpers by their own line ranges
+    ("tm_scene.hip", _h("pose12 lds_pose(const float4* p)"), _h("f3 lds_xform_point(") - 1): ("quarter-tile probes", "item"),
+    ("tm_scene.hip", _h("f3 lds_xform_point("), _h("f3 lds_xform_dir(") - 1): ("transform + in-grid test", "iteration"),
+    ("tm_scene.hip", _h("f3 lds_xform_dir("), _h("T ld_off32(") - 8): ("orientation term + LDS atomic", "iteration"),
+    ("tm_scene.hip", _h("T ld_off32(") - 1, _h("T ld_off32(") + 4): ("gather addressing (ld_off32)", "iteration"),
+    ("tm_scene.hip", _h("tile_probe_t tile_probe("), _h("bool tile_decide(") + 4): ("quarter-tile probes", "item"),
 }
 
 

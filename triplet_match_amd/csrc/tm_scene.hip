@@ -768,14 +768,14 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (STATS) evals += n * 16u / 64u + ((lane < (n * 16u) % 64u) ? 1u : 0u); /* sums to 16 n over the wave */
-        for (uint32_t i = 0; i < n; i += 4u * NC) {
+        auto turn = [&](const uint32_t i, const uint32_t n_end) {
             f3 q[NC];
             uint32_t pidx[NC], gk[NC], lin[NC], mi[NC], brick[NC], code[NC];
             bool near[NC], in[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const uint32_t e = i + 4u * k + (lane >> 4);
-                in[k] = e < n;
+                in[k] = e < n_end;
                 const uint32_t en = ent[in[k] ? e : i];
                 gk[k] = en >> 5;
                 pidx[k] = (en & 31u) * 16u + (lane & 15u);
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             if (TM_ABLATE_EQ(a, 1) || TM_ABLATE_EQ(a, 7) || TM_ABLATE_EQ(a, 12) || TM_ABLATE_EQ(a, 13) || TM_ABLATE_BIT(a, 1)) {
 #pragma unroll
                 for (int k = 0; k < NC; ++k) pass += ok[k] ? 1u : 0u; /* timing experiments: no orientation stage */
-                continue;
+                return;
             }
             /* orientation term (:441-488): every correspondence adds count << 52 | 2^-40 fixed-point term to its
              * hypothesis' sum in LDS, one atomic per lane (the 16-lane DPP reductions of two dwords that used to stand
@@ -888,7 +888,8 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     }
                 }
             }
-        }
+        };
+        for (uint32_t i = 0; i < n; i += 4u * NC) turn(i, n);
         /* flush the item's sums: one pair of atomics per hypothesis with correspondences */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
