@@ -74,7 +74,7 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 /* Switches of a context (cross-check kernels, timing comparisons; none changes a result). Every switch NAME is
  * read once from the environment variable TM_<NAME IN UPPER CASE> inside tm_ctx_create; afterwards only these
  * calls change it — no call of the path reads the environment. Names: debug_stats, debug_times, debug_ed,
- * score_grouped, ball_ungrouped, group_hyps, score_item_wgs, score_slot_mib, item_sort, near_metric, voxel_bruteforce,
+ * score_grouped, ball_ungrouped, score_item_wgs, score_slot_mib, item_sort, near_metric, voxel_bruteforce,
  * voxel_packet, voxel_seed, curv_groups, model_host_build, ed_one_kernel, ed_narrow, ed_bruteforce, ed_unfused,
  * search_segment, search_per_range, search_step_check, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
  * ed_prefix_group, score_off32, pool_mib (DESIGN.md section 6 says what each selects).

@@ -1255,7 +1255,7 @@ def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
 
 
 def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case):
-    """The grouped kernel (16 or 32 hypotheses share the scene chunks they reach) against the exhaustive kernel
+    """The grouped kernel (16 hypotheses share the scene chunks they reach) against the exhaustive kernel
     and the oracle at the sizes where its bookkeeping has edges: fewer hypotheses than a group, one more than a
     group, a last partial group; a scene smaller than one 512-point chunk; a masked scene."""
     g, s = gpu_small["model"], gpu_small["scene"]
@@ -1263,12 +1263,10 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
     cb, sb = s.score_hypotheses(g, poses, DT, mode=capi.SCORE_BRUTEFORCE)
     co, so, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT, threads=8)
     assert np.array_equal(cb, co)
-    for group in (16, 32):
-        with gpu_ctx.option("group_hyps", group):
-            for n in (1, 15, 16, 17, 31, 32, 33, 100):
-                cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
-                assert np.array_equal(cg, cb[:n]), (group, n)
-                assert np.array_equal(sg, sb[:n]), (group, n)  # fixed-point sums: identical, not merely close
+    for n in (1, 15, 16, 17, 31, 32, 33, 100):
+        cg, sg = s.score_hypotheses(g, poses[:n], DT, mode=capi.SCORE_CULLED)
+        assert np.array_equal(cg, cb[:n]), n
+        assert np.array_equal(sg, sb[:n]), n  # fixed-point sums: identical, not merely close
     # the items binned by the model region they land in (default for large batches only): same sums in any order
     for shift in (0, 3, 4, 6):
         with gpu_ctx.option("item_sort", shift):
@@ -1278,7 +1276,7 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
     # beyond 4 GiB takes), a fixed item share per wave, no continuation in other XCDs' items, short runs per XCD, a small
     # persistent grid — same integers every way
     for opts in ({"score_off32": 0}, {"item_sort": 4},
-                 {"score_item_wgs": 8}, {"score_off32": 0, "group_hyps": 32}):
+                 {"score_item_wgs": 8}, {"score_off32": 0, "item_sort": 3}):
         old = {k: gpu_ctx.get_option(k) for k in opts}
         for k, v in opts.items():
             gpu_ctx.set_option(k, v)
@@ -1321,14 +1319,14 @@ def test_grouped_scoring_edge_sizes(gpu_ctx, gpu_small, oracle_small, small_case
             "from triplet_match_amd import capi\n"
             "try:\n"
             "    c = capi.Context(0)\n"
-            "    print('created', c.get_option('ablate'), c.get_option('group_hyps'))\n"
+            "    print('created', c.get_option('ablate'), c.get_option('item_sort'))\n"
             "except capi.TmError as e:\n"
             "    print('refused', e.code)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, TM_ABLATE="1", TM_GROUP_HYPS="32"))
-    assert r.returncode == 0 and r.stdout.split() == ["created", "0", "32"] and "TM_ABLATE=1 ignored" in r.stderr, r
+                       env=dict(os.environ, TM_ABLATE="1", TM_ITEM_SORT="3"))
+    assert r.returncode == 0 and r.stdout.split() == ["created", "0", "3"] and "TM_ABLATE=1 ignored" in r.stderr, r
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, TM_GROUP_HYPS="17"))
+                       env=dict(os.environ, TM_ITEM_SORT="17"))
     assert r.returncode == 0 and r.stdout.split() == ["refused", str(capi.ERR_INVALID)], r
     # a scene of 300 points: less than one chunk
     sc = small_case["scene"]

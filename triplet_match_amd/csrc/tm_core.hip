@@ -192,7 +192,6 @@ static const opt_entry kOptions[] = {
     {"debug_ed", &options::debug_ed, 0, 1},
     {"score_grouped", &options::score_grouped, 0, 1},
     {"ball_ungrouped", &options::ball_ungrouped, 0, 1},
-    {"group_hyps", &options::group_hyps, 16, 32},
     {"score_item_wgs", &options::score_item_wgs, 0, 1 << 20},
     {"item_sort", &options::item_sort, -1, 6},
     {"score_slot_mib", &options::score_slot_mib, 1, 1 << 16},
@@ -226,7 +225,7 @@ int tm_ctx_set_option(tm_ctx* c, const char* name, int value) {
     TM_REQUIRE(c && name, TM_ERR_INVALID, "tm_ctx_set_option: null argument");
     for (const opt_entry& o : kOptions) {
         if (strcmp(o.name, name) != 0) continue;
-        if (value < o.lo || value > o.hi || (o.field == &options::group_hyps && value != 16 && value != 32)) {
+        if (value < o.lo || value > o.hi) {
             set_error("tm_ctx_set_option: %s = %d is out of range [%d, %d]", name, value, o.lo, o.hi);
             return TM_ERR_INVALID;
         }

@@ -103,7 +103,6 @@ struct options {
     int debug_ed = 0;         /* pending counts of the early-drop prefix kernel */
     int score_grouped = 1;    /* 0: the per-hypothesis kernel (k_score_culled) for every launch */
     int ball_ungrouped = 0;   /* 1: k_score_culled for ball-restricted scoring */
-    int group_hyps = 16;      /* 16 or 32 hypotheses per group */
     int score_item_wgs = 0;   /* persistent grid of the item kernel; 0 = what is resident */
     int item_sort = -1;       /* the items of the grouped kernel binned by the model region they land in: cells of
                                  2^item_sort voxels (2..6); -1 = 16-voxel cells for batches of 8,192 hypotheses and

@@ -696,71 +696,86 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        /* quarter-tile tests, two hypotheses per round (lanes 0-31 / 32-63): the level-3 test of
-         * k_score_culled; survivors are appended to the entry list */
-        uint32_t hm = 0; /* lane q < 32: which hypotheses of the group reach quarter-tile q */
+        /* Which (hypothesis, quarter-tile) pairs are evaluated — two levels. Level 1: the chunk's eight 64-point tiles
+         * under the group's sixteen poses, sphere against the voxel box (lane = (tile & 3) * 16 + hypothesis, two
+         * rounds): 128 cheap tests. Level 2: only the quarter-tiles of tiles that passed are probed (sphere against the
+         * box AND the distance field at its centre), densely: the candidates are listed in quarter-major order and taken
+         * 64 at a time. The survivors — the same pairs the one-level scheme of 512 probes per item kept, minus those
+         * whose whole tile cannot reach the grid — are compacted in place into the entry list. */
+        static_assert(G == 16, "the two-level probe is laid out for groups of 16");
+        const uint32_t ql = lane & 31u;
+        uint32_t n = 0;
         {
-            /* rounds of two hypotheses (lanes 0-31 / 32-63): the level-3 test of k_score_culled */
-            const uint32_t ql = lane & 31u;
+            unsigned long long tb[2];
 #pragma unroll
-            for (int r0 = 0; r0 < G / 2; r0 += 8) { /* eight rounds' brick-code loads in flight together */
-                tile_probe_t pr[8];
-                uint32_t code[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint32_t g = 2u * (r0 + r) + (lane >> 5);
-                    const pose12 T = lds_pose(poses + 3u * g);
-                    const float2 ax = auxl[g];
-                    const float rnorm = ax.x, abs_eps = ax.y;
-                    if (NEAR) {
-                        pr[r] = tile_probe(a, T, rnorm, abs_eps, ca.tcode, ca.inv_q, qs);
-                    } else {
-                        pr[r].hit = sphere_hits_box(a, T, rnorm, abs_eps, qs);
-                        pr[r].need = false;
-                        pr[r].brick = 0u;
-                        pr[r].lim = 0.f;
-                    }
-                    pr[r].hit = pr[r].hit & (((m >> g) & 1u) != 0u);
-                    if (BALL) {
-                        const float4 C = cen[g];
-                        pr[r].hit = pr[r].hit && !(len(make3(qs.x, qs.y, qs.z) - make3(C.x, C.y, C.z)) >
-                                                   ca.ball_r + qs.w * 1.00001f + ball_margin);
-                    }
-                    pr[r].need = pr[r].need & pr[r].hit;
-                    if (!pr[r].need) pr[r].brick = 0u;
-                    __builtin_amdgcn_sched_barrier(0); /* one pose in registers at a time */
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t g = lane & 15u;
+                const float4 ts = ca.tiles[(size_t)chunk * 8u + 4u * r + (lane >> 4)];
+                const pose12 T = lds_pose(poses + 3u * g);
+                const float2 ax = auxl[g];
+                bool hit = sphere_hits_box(a, T, ax.x, ax.y, ts) & (((m >> g) & 1u) != 0u);
+                if (BALL) {
+                    const float4 C = cen[g];
+                    hit = hit && !(len(make3(ts.x, ts.y, ts.z) - make3(C.x, C.y, C.z)) > ca.ball_r + ts.w * 1.00001f + ball_margin);
                 }
+                tb[r] = __ballot(hit);
+            }
+            /* lane q < 32: the hypotheses whose tile q >> 2 passed = a 16-bit field of the round's ballot */
+            const uint32_t t = ql >> 2;
+            uint32_t cm = (uint32_t)((t & 4u ? tb[1] : tb[0]) >> (16u * (t & 3u))) & 0xFFFFu;
+            if (lane >= 32u) cm = 0u;
+            const uint32_t mine = (uint32_t)__popc(cm);
+            uint32_t incl = mine;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) code[r] = NEAR ? (uint32_t)a.bcode_tile[pr[r].brick] : 0u;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const unsigned long long qm = __ballot(tile_decide(pr[r], code[r]));
-                    hm |= ((uint32_t)(qm >> ql) & 1u) << (2 * (r0 + r));
-                    hm |= ((uint32_t)(qm >> (32u + ql)) & 1u) << (2 * (r0 + r) + 1);
+            for (int off = 1; off < 32; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off);
+                if (lane >= (uint32_t)off) incl += u;
+            }
+            const uint32_t nc = __shfl(incl, 31);
+            {
+                uint32_t o = incl - mine, b = cm;
+                while (b) {
+                    const uint32_t g = (uint32_t)__builtin_ctz(b);
+                    b &= b - 1u;
+                    ent[o++] = (unsigned short)((g << 5) | lane);
                 }
             }
-        }
-        /* Entry list in quarter-major order: the lane groups of consecutive gather instructions then hold the
-         * same scene points under consecutive hypotheses of the group. Consecutive hypotheses of a sample pair
-         * come from neighbouring model pairs (the table is sorted), i.e. nearly the same pose: they land in the
-         * same voxel lines and share them inside the instruction and through L1. L2 turns over every few
-         * microseconds here, so what is not re-used at once is fetched again: hypothesis-major order fetched
-         * 8.7e8 lines per batch, tiles of 4 quarter-tiles x 4 hypotheses 6.4e8, this order 5.2e8. */
-        if (lane >= 32u) hm = 0u;
-        const uint32_t mine = (uint32_t)__popc(hm);
-        uint32_t incl = mine; /* inclusive prefix sum over the lanes */
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (lane >= (uint32_t)off) incl += t;
-        }
-        const uint32_t n = __shfl(incl, 31);
-        {
-            uint32_t o = incl - mine, b = hm;
-            while (b) {
-                const uint32_t g = (uint32_t)__builtin_ctz(b);
-                b &= b - 1u;
-                ent[o++] = (unsigned short)((g << 5) | lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t i = 0; i < nc; i += 64u) {
+                const uint32_t e = i + lane;
+                const bool live = e < nc;
+                const uint32_t en = ent[live ? e : i];
+                const uint32_t g = en >> 5, q = en & 31u;
+                const float4 qq = make_float4(__shfl(qs.x, (int)q), __shfl(qs.y, (int)q), __shfl(qs.z, (int)q), __shfl(qs.w, (int)q));
+                const pose12 T = lds_pose(poses + 3u * g);
+                const float2 ax = auxl[g];
+                tile_probe_t pr;
+                if (NEAR) {
+                    pr = tile_probe(a, T, ax.x, ax.y, ca.tcode, ca.inv_q, qq);
+                } else {
+                    pr.hit = sphere_hits_box(a, T, ax.x, ax.y, qq);
+                    pr.need = false;
+                    pr.brick = 0u;
+                    pr.lim = 0.f;
+                }
+                pr.hit = pr.hit & live;
+                if (BALL) {
+                    const float4 C = cen[g];
+                    pr.hit = pr.hit && !(len(make3(qq.x, qq.y, qq.z) - make3(C.x, C.y, C.z)) > ca.ball_r + qq.w * 1.00001f + ball_margin);
+                }
+                pr.need = pr.need & pr.hit;
+                if (!pr.need) pr.brick = 0u;
+                const uint32_t code = NEAR ? (uint32_t)a.bcode_tile[pr.brick] : 0u;
+                const bool keep = tile_decide(pr, code);
+                const unsigned long long sv = __ballot(keep);
+                /* in place: the survivors so far are no more than the candidates read so far, and every lane holds its
+                 * own candidate in a register before any lane writes */
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (keep) ent[n + (uint32_t)__popcll(sv & ((1ull << lane) - 1ull))] = (unsigned short)en;
+                n += (uint32_t)__popcll(sv);
             }
         }
         if (n == 0u || TM_ABLATE_EQ(a, 10)) continue; /* nothing survives (ablate 10 = timing experiment: staging and culling only) */
@@ -930,17 +945,14 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
 /* the instantiation for a launch: metric filter / neighbourhood restriction / group size / 32-bit gathers */
 using items_kernel_t = void (*)(score_args, cull_args, group_args);
 template <bool STATS>
-static items_kernel_t items_kernel(bool l2, uint32_t group_hyps, bool ball, bool near_metric, bool w32) {
+static items_kernel_t items_kernel(bool l2, bool ball, bool near_metric, bool w32) {
     if (near_metric)
-        return ball               ? k_score_items<false, 4, 16, true, true, false, STATS>
-               : group_hyps == 16u ? (w32 ? k_score_items<false, 4, 16, false, true, true, STATS> : k_score_items<false, 4, 16, false, true, false, STATS>)
-                                   : k_score_items<false, 4, 32, false, true, false, STATS>;
+        return ball ? k_score_items<false, 4, 16, true, true, false, STATS>
+               : w32 ? k_score_items<false, 4, 16, false, true, true, STATS>
+                     : k_score_items<false, 4, 16, false, true, false, STATS>;
     if (ball) return l2 ? k_score_items<true, 4, 16, true, true, false, STATS> : k_score_items<false, 4, 16, true, false, false, STATS>;
-    if (group_hyps == 16u) {
-        if (w32) return l2 ? k_score_items<true, 4, 16, false, true, true, STATS> : k_score_items<false, 4, 16, false, false, true, STATS>;
-        return l2 ? k_score_items<true, 4, 16, false, true, false, STATS> : k_score_items<false, 4, 16, false, false, false, STATS>;
-    }
-    return l2 ? k_score_items<true, 4, 32, false, true, false, STATS> : k_score_items<false, 4, 32, false, false, false, STATS>;
+    if (w32) return l2 ? k_score_items<true, 4, 16, false, true, true, STATS> : k_score_items<false, 4, 16, false, false, true, STATS>;
+    return l2 ? k_score_items<true, 4, 16, false, true, false, STATS> : k_score_items<false, 4, 16, false, false, false, STATS>;
 }
 
 /* <<< scoring kernels */
@@ -1375,7 +1387,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
      * hypothesis, so the split changes nothing in the results. */
     const size_t slot_budget = (size_t)c->opt.score_slot_mib * (1u << 20) / (2 * sizeof(uint32_t));
     if (mode != TM_SCORE_BRUTEFORCE && !d_active && c->opt.score_grouped && !(d_centers && c->opt.ball_ungrouped)) {
-        const uint32_t gh = (c->opt.group_hyps == 32 && !d_centers) ? 32u : 16u;
+        const uint32_t gh = 16u;
         const size_t n_chunks = s->n_sorted / kChunkPts;
         const size_t groups = (n_hyp + gh - 1) / gh;
         const size_t groups_per = n_chunks ? slot_budget / n_chunks : groups;
@@ -1489,7 +1501,6 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
          * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
          * as that saves: 13.05 ms against 12.90 ms in the same run. */
         ga.group_hyps = 16u;
-        if (c->opt.group_hyps == 32 && !d_centers) ga.group_hyps = 32u;
         ga.n_groups = (n_hyp + ga.group_hyps - 1) / ga.group_hyps;
         const size_t n_slots_g = (size_t)ga.n_groups * ga.n_chunks;
         /* slots are addressed with 32 bits and the chunks ride in blockIdx.y: beyond that (billions of points,
@@ -1562,8 +1573,8 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
             const bool w32 = c->opt.score_off32 && m->voxel_slots < (1ull << 30) && s->n_sorted < (1u << 28) && m->n < (1u << 28);
             /* nobody reads the stage counters outside a measurement window with counters: the kernel does not keep them */
             const bool stats = c->timing_mode == 1 || c->opt.debug_stats != 0;
-            auto kern = stats ? items_kernel<true>(l2, ga.group_hyps, d_centers != nullptr, near_metric, w32)
-                              : items_kernel<false>(l2, ga.group_hyps, d_centers != nullptr, near_metric, w32);
+            auto kern = stats ? items_kernel<true>(l2, d_centers != nullptr, near_metric, w32)
+                              : items_kernel<false>(l2, d_centers != nullptr, near_metric, w32);
             stats_kept = stats;
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0);
