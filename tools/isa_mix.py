@@ -29,8 +29,8 @@ def _line(text, after=0):
 # stage boundaries are found by anchor text in the source, so the table survives edits of the file
 _k = _line("void k_score_items(score_args a, cull_args ca, group_args ga)")
 _stage = _line("/* stage the chunk", _k)
-_probe = _line("/* quarter-tile tests, two hypotheses per round", _k)
-_list = _line("/* Entry list in quarter-major order", _k)
+_probe = _line("/* Which (hypothesis, quarter-tile) pairs are evaluated", _k)
+_list = _line("if (n == 0u || TM_ABLATE_EQ(a, 10)) continue;", _k)
 _turn = _line("auto turn = [&]", _k)
 _xf = _line("const float4* pp = poses + 3u * gk[k];", _turn)
 _addr = _line("uint32_t ix = in[k] ?", _turn)
@@ -43,8 +43,8 @@ _end = _line("using items_kernel_t", _stats)
 STAGES = [  # (file suffix, first line, last line, stage, per)
     ("tm_scene.hip", _k, _stage - 1, "hand-out / set-up", "item"),
     ("tm_scene.hip", _stage, _probe - 1, "staging (chunk + poses -> LDS)", "item"),
-    ("tm_scene.hip", _probe, _list - 1, "quarter-tile probes", "item"),
-    ("tm_scene.hip", _list, _turn - 1, "entry list", "item"),
+    ("tm_scene.hip", _probe, _list - 1, "two-level probe + entry list", "item"),
+    ("tm_scene.hip", _list, _turn - 1, "loop set-up", "item"),
     ("tm_scene.hip", _turn, _xf - 3, "entry decode", "iteration"),
     ("tm_scene.hip", _xf - 2, _addr - 1, "transform + in-grid test", "iteration"),
     ("tm_scene.hip", _addr, _near - 3, "voxel address + brick code", "iteration"),
@@ -56,11 +56,11 @@ STAGES = [  # (file suffix, first line, last line, stage, per)
 ]
 _h = lambda t: _line(t)
 HELPERS = {  # inlined helpers by their own line ranges
-    ("tm_scene.hip", _h("pose12 lds_pose(const float4* p)"), _h("f3 lds_xform_point(") - 1): ("quarter-tile probes", "item"),
+    ("tm_scene.hip", _h("pose12 lds_pose(const float4* p)"), _h("f3 lds_xform_point(") - 1): ("two-level probe + entry list", "item"),
     ("tm_scene.hip", _h("f3 lds_xform_point("), _h("f3 lds_xform_dir(") - 1): ("transform + in-grid test", "iteration"),
     ("tm_scene.hip", _h("f3 lds_xform_dir("), _h("T ld_off32(") - 8): ("orientation term + LDS atomic", "iteration"),
     ("tm_scene.hip", _h("T ld_off32(") - 1, _h("T ld_off32(") + 4): ("gather addressing (ld_off32)", "iteration"),
-    ("tm_scene.hip", _h("tile_probe_t tile_probe("), _h("bool tile_decide(") + 4): ("quarter-tile probes", "item"),
+    ("tm_scene.hip", _h("tile_probe_t tile_probe("), _h("bool tile_decide(") + 4): ("two-level probe + entry list", "item"),
 }
 
 
@@ -121,7 +121,7 @@ for ln in open(path):
         # instruction before it in the stream (the scheduler keeps a chain's stages together: sched_barrier per chain)
         base = f.split("/")[-1]
         if base == "tm_score.h":
-            stage = "quarter-tile probes"
+            stage = "two-level probe + entry list"
             per.setdefault(stage, "item")
         elif last_stage is not None:
             stage = last_stage

@@ -82,6 +82,7 @@ TM_HD void brick_coords(uint32_t brick, uint32_t bx, uint32_t by, uint32_t& bi, 
     bk = (sk << 2) | (loc >> 4);
 }
 
+
 TM_HD float len2(f3 a) { return (a.x * a.x + a.y * a.y) + a.z * a.z; }
 TM_HD float len(f3 a) { return sqrtf(len2(a)); }
 TM_HD f3 cross3(f3 a, f3 b) {

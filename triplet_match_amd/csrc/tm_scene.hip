@@ -404,6 +404,7 @@ constexpr int kItemWaves = 4; /* waves per SIMD the item kernel's register budge
 struct group_args {
     const float4* chunks;   /* bounding sphere per 512 sorted points */
     uint32_t n_chunks;
+    float inv_chunks;       /* 1 / n_chunks (split_slot) */
     uint32_t n_groups;
     uint32_t group_hyps;    /* hypotheses per group: 16 or 32 */
     group_mask_t* masks;    /* [group][chunk] */
@@ -412,6 +413,23 @@ struct group_args {
     const float2* aux;      /* per hypothesis: (rnorm, abs_eps) of the sphere tests */
     uint32_t* heads;        /* per XCD (128 bytes apart): the next item of its runs */
 };
+
+/* slot = group * n_chunks + chunk -> (group, chunk) without an integer division (~30 VALU instructions in a kernel that
+ * is bound by VALU issue): a float estimate of the quotient, off by one at most for slots below 2^31 / 8, put right by
+ * the remainder. */
+__device__ __forceinline__ void split_slot(uint32_t slot, uint32_t n_chunks, float inv_chunks, uint32_t& group, uint32_t& chunk) {
+    uint32_t g = (uint32_t)((float)slot * inv_chunks);
+    uint32_t r = slot - g * n_chunks; /* wraps when g is one too large */
+    if ((int32_t)r < 0) {
+        --g;
+        r += n_chunks;
+    } else if (r >= n_chunks) {
+        ++g;
+        r -= n_chunks;
+    }
+    group = g;
+    chunk = r;
+}
 
 struct nonzero_mask {
     __host__ __device__ bool operator()(group_mask_t m) const { return m != 0; }
@@ -515,7 +533,8 @@ __global__ __launch_bounds__(256) void k_item_bins(score_args a, group_args ga, 
     const uint32_t n_items = *ga.n_items;
     for (uint32_t it = blockIdx.x * 256 + threadIdx.x; it < n_items; it += gridDim.x * 256) {
         const uint32_t slot = ga.items[it];
-        const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
+        uint32_t group, chunk;
+        split_slot(slot, ga.n_chunks, ga.inv_chunks, group, chunk);
         const uint32_t m = (uint32_t)ga.masks[slot];
         const uint32_t h = min(group * ga.group_hyps + (uint32_t)__builtin_ctz(m | 0x80000000u), a.n_hyp - 1u);
         const pose12 T = load_pose(a.poses + (size_t)h * 16);
@@ -658,7 +677,8 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             if (lane == 0) pend = atomicAdd(ga.heads + 32u * x, 1u);
         }
         const uint32_t slot = ga.items[it];
-        const uint32_t group = slot / ga.n_chunks, chunk = slot - group * ga.n_chunks;
+        uint32_t group, chunk;
+        split_slot(slot, ga.n_chunks, ga.inv_chunks, group, chunk);
         uint32_t m = (uint32_t)ga.masks[slot];
         /* stage the chunk (1536 floats = six float4 per lane, contiguous) and the group's poses */
         {
@@ -1497,6 +1517,7 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
         group_args ga;
         ga.chunks = s->chunks.p;
         ga.n_chunks = s->n_sorted / kChunkPts;
+        ga.inv_chunks = 1.0f / (float)ga.n_chunks;
         /* 16 hypotheses per group. Groups of 32 (TM_GROUP_HYPS=32) let more near-identical poses meet in one
          * item and fetch fewer voxel lines (4.6e8 per batch against 5.2e8), but the larger item costs as much
          * as that saves: 13.05 ms against 12.90 ms in the same run. */
