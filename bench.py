@@ -61,7 +61,7 @@ def main():
                          "over gloo (RCCL refuses two ranks on one device); not a measurement")
     ap.add_argument("--ed-profile", action="store_true",
                     help="profiling aid: after the setup run only the device-resident early-drop scoring of the batch "
-                         "(three calls) and print its figure; tools/profile_round4.sh counts its fabric bytes")
+                         "(three calls) and print its figure; tools/profile_round5.sh counts its fabric bytes")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="plumbing check without a GPU: the ranks come up over gloo, exchange one synthetic best "
                          "record each and rank 0 prints a line with \"selftest\": true and no value (tests/)")
@@ -332,14 +332,22 @@ def main():
                 "physical_bytes_per_launch": phys_bytes, "achieved_physical": round(achieved_phys, 1),
                 "frac_physical": round(achieved_phys / HBM_PEAK_GBS, 4),
                 "measured_copy_GBs": copy_gbs}
-    # The two figures that actually bound this kernel (review of round 4): VALU issue and the rate of random lines.
-    #   valu_issue_frac = wave-level VALU instructions x 4 cycles (a wave64 op occupies its SIMD16 for four) over
-    #                     1024 SIMDs x shader cycles, both counted under the profiler;
+    # The figures that actually bound this kernel: VALU issue and the rate of random lines.
+    #   valu_issue_frac = wave-level VALU instructions of a launch (SQ_INSTS_VALU, PMC pass) x the measured issue cost of
+    #                     one — 4.9 cycles of the nominal 2.4 GHz clock per wave64 instruction and SIMD with two or more
+    #                     waves per SIMD (tools/ubench_valu.hip, profiles/r05/ubench_valu.txt: v_add / v_mul / v_cvt 4.5-4.9,
+    #                     v_pk_* 5.3-5.7, v_mad_u64_u32 5.6) — over 1024 SIMDs x THIS run's kernel time: the share of the
+    #                     kernel during which the SIMDs cannot issue anything more. Round 5 found this to be the bound
+    #                     (cutting instructions moves the time one for one; cutting gathers or dependent levels does not).
     #   line_rate_frac  = fabric lines per second of this run over the rate at which this chip delivers uniformly
     #                     random 128-B lines to all CUs (tools/ubench_l2.hip, profiles/r04/ubench_l2.txt): 3.12 ns per
     #                     line and CU out of an Infinity-Cache-resident table, 4.59 ns out of HBM.
-    if pmc and pmc.get("sq_insts_valu") and pmc.get("shader_cycles_per_launch"):
-        roofline["valu_issue_frac"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
+    if pmc and pmc.get("sq_insts_valu"):
+        roofline["valu_issue_frac"] = round(pmc["sq_insts_valu"] * (4.9 / 2.4e9) / (1024.0 * k_s), 4)
+        roofline["valu_issue_basis"] = ("SQ_INSTS_VALU per launch x 4.9 nominal cycles per wave instruction and SIMD "
+                                        "(tools/ubench_valu.hip) / (1024 SIMDs x kernel time)")
+        if pmc.get("shader_cycles_per_launch"):
+            roofline["valu_issue_frac_under_profiler"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
     if pmc and pmc.get("l2_fabric_read_requests"):
         lines_per_s = pmc["l2_fabric_read_requests"] / k_s
         roofline["line_rate_frac"] = round(lines_per_s / (256.0 / 3.12e-9), 4)
@@ -438,7 +446,7 @@ def prepare_workload(args, ctx_factory, rank, world, log):
     """Clouds, model(s) and scene on the device, and this rank's share of the scene sample pairs, for one of the
     BASELINE.json configurations. Returns dict(ctx, gs, scene (what is scored: surfels + tangent_mask, in the
     projector's uvw space for c3 / c4), units, description); a unit = one model: dict(name, gm, gs, K (traits kind),
-    radius, M (model cloud as scored), res, subset, pairs). tools/report_configs.py goes through here too."""
+    radius, M (model cloud as scored), res, subset, pairs)."""
     from triplet_match_amd import capi, synth
     from triplet_match_amd import dist as tmd
     H = args.hyp_per_batch

@@ -201,7 +201,7 @@ def test_product_does_not_touch_the_oracle():
 def test_committed_pmc_passes_belong_to_these_kernel_sources():
     """bench.py quotes roofline.traffic from the newest profiles/rNN/traffic.json whose hash matches the scoring kernels'
     sources (the marked region of csrc/tm_scene.hip + tm_score.h / tm_math.h / tm_table.h); without a match the line's
-    `frac` is null. This fails when the kernels were edited after the last PMC passes: run tools/profile_round4.sh on a
+    `frac` is null. This fails when the kernels were edited after the last PMC passes: run tools/profile_round5.sh on a
     GPU box (stages `pmc folded ed`) and commit the refreshed profiles/ files."""
     import json
     import os

@@ -39,7 +39,7 @@ for f in glob.glob(trace_dir + "/*/*_kernel_trace.csv"):
             disp += 1
 fig = json.loads(open(line).read().strip().splitlines()[-1])["early_drop_ball_dev"]
 res = {"what": "tm_score_hypotheses_early_drop_ball_dev on the bench's batch, one call",
-       "source": "tools/profile_round4.sh: rocprofv3 --pmc TCC_EA0_RDREQ_* and --kernel-trace of `python3 bench.py --ed-profile`",
+       "source": "tools/profile_round5.sh: rocprofv3 --pmc TCC_EA0_RDREQ_* and --kernel-trace of `python3 bench.py --ed-profile`",
        "source_hash": bench.ed_source_hash(), "hypotheses": fig["hypotheses"],
        "fabric_read_requests_per_call": n["TCC_EA0_RDREQ_sum"] / CALLS, "fabric_bytes_per_call": rd / CALLS,
        "kernel_busy_ms_per_call": busy / CALLS, "dispatches_per_call": disp / CALLS,

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_score_brute(score_args a) {
  * ---------------------------------------------------------------------------------------------- */
 /* >>> scoring kernels: bench.py ties the committed PMC passes (profiles/rNN/traffic.json) to a hash of the text between
  * this marker and its closing twin, plus tm_score.h / tm_math.h / tm_table.h — a change in here needs new passes
- * (tools/profile_round4.sh), a change elsewhere in this file does not */
+ * (tools/profile_round5.sh), a change elsewhere in this file does not */
 constexpr int kCullChunk = 1024; /* tiles culled per round; each may leave up to 4 sub-tiles in the 16 KiB list */
 
 struct cull_args {
