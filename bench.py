@@ -332,22 +332,26 @@ def main():
                 "physical_bytes_per_launch": phys_bytes, "achieved_physical": round(achieved_phys, 1),
                 "frac_physical": round(achieved_phys / HBM_PEAK_GBS, 4),
                 "measured_copy_GBs": copy_gbs}
-    # The figures that actually bound this kernel: VALU issue and the rate of random lines.
-    #   valu_issue_frac = wave-level VALU instructions of a launch (SQ_INSTS_VALU, PMC pass) x the measured issue cost of
-    #                     one — 4.9 cycles of the nominal 2.4 GHz clock per wave64 instruction and SIMD with two or more
-    #                     waves per SIMD (tools/ubench_valu.hip, profiles/r05/ubench_valu.txt: v_add / v_mul / v_cvt 4.5-4.9,
-    #                     v_pk_* 5.3-5.7, v_mad_u64_u32 5.6) — over 1024 SIMDs x THIS run's kernel time: the share of the
-    #                     kernel during which the SIMDs cannot issue anything more. Round 5 found this to be the bound
-    #                     (cutting instructions moves the time one for one; cutting gathers or dependent levels does not).
+    # Two figures that say more about this kernel than bytes do:
+    #   valu_issue_frac = wave-level VALU instructions of a launch (SQ_INSTS_VALU) x 4 shader cycles each (a wave64
+    #                     instruction occupies its SIMD for four cycles; tools/ubench_valu.hip reads 3.75-4.2 per
+    #                     instruction against s_memtime with two or more waves per SIMD) over 1024 SIMDs x the shader
+    #                     cycles of the launch (GRBM_GUI_ACTIVE / 8 XCDs): counters of the PMC passes only, i.e. under the
+    #                     profiler. `valu_issue_frac_this_run` scales it to this run's kernel time at the clock the
+    #                     profiled launch ran at. The rest of a SIMD's cycles its four waves wait (s_waitcnt: 60 % of the
+    #                     wave cycles, SQ_WAIT_ANY / SQ_WAVE_CYCLES).
     #   line_rate_frac  = fabric lines per second of this run over the rate at which this chip delivers uniformly
     #                     random 128-B lines to all CUs (tools/ubench_l2.hip, profiles/r04/ubench_l2.txt): 3.12 ns per
     #                     line and CU out of an Infinity-Cache-resident table, 4.59 ns out of HBM.
-    if pmc and pmc.get("sq_insts_valu"):
-        roofline["valu_issue_frac"] = round(pmc["sq_insts_valu"] * (4.9 / 2.4e9) / (1024.0 * k_s), 4)
-        roofline["valu_issue_basis"] = ("SQ_INSTS_VALU per launch x 4.9 nominal cycles per wave instruction and SIMD "
-                                        "(tools/ubench_valu.hip) / (1024 SIMDs x kernel time)")
-        if pmc.get("shader_cycles_per_launch"):
-            roofline["valu_issue_frac_under_profiler"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
+    if pmc and pmc.get("sq_insts_valu") and pmc.get("shader_cycles_per_launch"):
+        roofline["valu_issue_frac"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
+        roofline["valu_issue_basis"] = ("4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), both from the PMC passes "
+                                        "of the same command (under the profiler)")
+        if pmc.get("kernel_ms_under_profiler"):
+            clock = pmc["shader_cycles_per_launch"] / (pmc["kernel_ms_under_profiler"] * 1e-3)
+            roofline["valu_issue_frac_this_run"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * clock * k_s), 4)
+        if pmc.get("sq_wait_any") and pmc.get("sq_wave_cycles"):
+            roofline["wave_wait_frac"] = round(pmc["sq_wait_any"] / pmc["sq_wave_cycles"], 4)
     if pmc and pmc.get("l2_fabric_read_requests"):
         lines_per_s = pmc["l2_fabric_read_requests"] / k_s
         roofline["line_rate_frac"] = round(lines_per_s / (256.0 / 3.12e-9), 4)

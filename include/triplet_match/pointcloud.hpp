@@ -94,54 +94,73 @@ public:
         }
         if (stale) touch();
     }
-    /* 64-bit hash of the raw surfel bytes (eight interleaved multiply-xorshift lanes per slice, slices on the pool):
-     * scene<Point> keys its device copy on it, so an in-place edit of the points is never searched stale */
-    uint64_t content_hash() const {
+    /* 64-bit hash of the raw surfel bytes (eight interleaved multiply-xorshift lanes per slice of 128k words, slices on
+     * the pool, combined in slice order): scene<Point> keys its device copy on it, so an in-place edit of the points is
+     * never searched stale */
+    static constexpr size_t kHashSlice = (size_t)1 << 17;
+    size_t hash_slices() const {
+        const size_t n_words = points.size() * (sizeof(Point) / 8);
+        return std::max<size_t>(1, (n_words + kHashSlice - 1) / kHashSlice);
+    }
+    uint64_t hash_slice(size_t sl) const {
         const size_t n_words = points.size() * (sizeof(Point) / 8);
         const uint64_t* w = reinterpret_cast<const uint64_t*>(points.data());
-        /* slices of 1M words hashed on the worker pool (a 48 MB cloud: ~0.6 ms instead of ~4), combined in slice order */
-        const size_t slice = (size_t)1 << 20;
-        const size_t n_slices = std::max<size_t>(1, (n_words + slice - 1) / slice);
-        std::vector<uint64_t> part(n_slices, 0);
-        auto hash_slices = [&](size_t first, size_t step) {
-            for (size_t sl = first; sl < n_slices; sl += step) {
-                const size_t lo = sl * slice, hi = std::min(n_words, lo + slice);
-                /* eight independent lanes: a lane's xor - multiply - shift - xor chain is ~6 cycles per word, so four
-                 * lanes left the multiplier idle half of the time (0.74 -> 0.54 ms per 48 MB on the pool's threads) */
-                constexpr int kLanes = 8;
-                uint64_t h[kLanes] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull,
-                                      0x27D4EB2F165667C5ull, 0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull,
-                                      0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
-                size_t i = lo;
-                for (; i + kLanes <= hi; i += kLanes)
-                    for (int l = 0; l < kLanes; ++l) {
-                        uint64_t v;
-                        std::memcpy(&v, w + i + l, 8);
-                        h[l] = (h[l] ^ v) * 0xFF51AFD7ED558CCDull;
-                        h[l] ^= h[l] >> 29;
-                    }
-                for (; i < hi; ++i) {
-                    uint64_t v;
-                    std::memcpy(&v, w + i, 8);
-                    h[0] = (h[0] ^ v) * 0xFF51AFD7ED558CCDull;
-                    h[0] ^= h[0] >> 29;
-                }
-                uint64_t r = (uint64_t)(hi - lo);
-                for (int l = 0; l < kLanes; ++l) {
-                    r = (r ^ h[l]) * 0xC4CEB9FE1A85EC53ull;
-                    r ^= r >> 32;
-                }
-                part[sl] = r;
+        const size_t lo = sl * kHashSlice, hi = std::min(n_words, lo + kHashSlice);
+        /* eight independent lanes: a lane's xor - multiply - shift - xor chain is ~6 cycles per word, so four
+         * lanes left the multiplier idle half of the time (0.74 -> 0.54 ms per 48 MB on the pool's threads) */
+        constexpr int kLanes = 8;
+        uint64_t h[kLanes] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
+                              0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
+        size_t i = lo;
+        for (; i + kLanes <= hi; i += kLanes)
+            for (int l = 0; l < kLanes; ++l) {
+                uint64_t v;
+                std::memcpy(&v, w + i + l, 8);
+                h[l] = (h[l] ^ v) * 0xFF51AFD7ED558CCDull;
+                h[l] ^= h[l] >> 29;
             }
-        };
-        /* on the headers' worker pool (threads started per call cost a third of the 0.9 ms) */
-        detail::worker_pool::instance().run(n_slices, [&](size_t sl) { hash_slices(sl, n_slices); });
+        for (; i < hi; ++i) {
+            uint64_t v;
+            std::memcpy(&v, w + i, 8);
+            h[0] = (h[0] ^ v) * 0xFF51AFD7ED558CCDull;
+            h[0] ^= h[0] >> 29;
+        }
+        uint64_t r = (uint64_t)(hi > lo ? hi - lo : 0);
+        for (int l = 0; l < kLanes; ++l) {
+            r = (r ^ h[l]) * 0xC4CEB9FE1A85EC53ull;
+            r ^= r >> 32;
+        }
+        return r;
+    }
+    uint64_t hash_combine(const std::vector<uint64_t>& part) const {
         uint64_t r = (uint64_t)points.size();
         for (uint64_t pv : part) {
             r = (r ^ pv) * 0xC4CEB9FE1A85EC53ull;
             r ^= r >> 32;
         }
         return r;
+    }
+    uint64_t content_hash() const {
+        std::vector<uint64_t> part(hash_slices(), 0);
+        /* on the headers' worker pool (threads started per call cost a third of the 0.9 ms) */
+        detail::worker_pool::instance().run(part.size(), [&](size_t sl) { part[sl] = hash_slice(sl); });
+        return hash_combine(part);
+    }
+    /* The same hash as a background job of the pool: begun before a search that assumes the content unchanged, read
+     * when the search is over (scene<Point>::find_all_parallel) — the 0.6 ms per 48 MB leave the search's critical
+     * path. The points must not change between the two calls. */
+    struct hash_job {
+        std::vector<uint64_t> part;
+        detail::worker_pool::job job;
+    };
+    void content_hash_begin(hash_job& hj) const {
+        hj.part.assign(hash_slices(), 0);
+        uint64_t* part = hj.part.data();
+        detail::worker_pool::instance().begin_background(hj.job, hj.part.size(), [this, part](size_t sl) { part[sl] = hash_slice(sl); });
+    }
+    uint64_t content_hash_end(hash_job& hj) const {
+        detail::worker_pool::instance().finish(hj.job);
+        return hash_combine(hj.part);
     }
 
     void set_resolution(float r) { /* a value supplied by the caller survives touch() */

@@ -24,7 +24,7 @@ namespace detail {
  * environment ONCE per process, on first use — never inside the search loops. */
 struct search_switches {
     bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods,
-        host_curvature_tree, sequential_sampling;
+        host_curvature_tree, sequential_sampling, hash_first;
 };
 inline const search_switches& env_once() {
     static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
@@ -34,7 +34,8 @@ inline const search_switches& env_once() {
                                        std::getenv("TM_ICP_PER_CANDIDATE") != nullptr,
                                        std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr,
                                        std::getenv("TM_HOST_CURVATURE_TREE") != nullptr,
-                                       std::getenv("TM_SEQUENTIAL_SAMPLING") != nullptr};
+                                       std::getenv("TM_SEQUENTIAL_SAMPLING") != nullptr,
+                                       std::getenv("TM_HASH_FIRST") != nullptr};
     return sw;
 }
 
@@ -480,7 +481,38 @@ public:
     std::vector<match_t> find_all_parallel(model<Point>& m, float dist_thres, float model_match_factor,
                                            float early_out_factor, const sample_parameters& sample_params,
                                            uint32_t max_icp_iterations) {
+        /* The device copy is valid for the content it was made from (a hash of the cloud's bytes, ensure_scene). A
+         * second search over the same scene object does not wait 0.6 ms per 48 MB for that hash: it searches the
+         * device copy while the pool's idle workers hash the cloud, and compares when the search is over. Unequal —
+         * the points were edited in place since the last call — what was found belongs to the old points: the scene is
+         * prepared again and searched again. TM_HASH_FIRST=1: always hash before searching. */
+        if (h_ && cached_n_ == (uint32_t)cloud_->size() && cached_curv_k_ == curvature_k_ && cached_curv_ok_ == curvature_ok_ &&
+            !detail::env_once().hash_first) {
+            typename cloud_t::hash_job hj;
+            cloud_->content_hash_begin(hj);
+            std::vector<match_t> results;
+            std::exception_ptr failed;
+            try {
+                results = search_prepared(m, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
+            } catch (...) {
+                failed = std::current_exception();
+            }
+            const uint64_t hash = cloud_->content_hash_end(hj);
+            if (hash == cached_hash_) {
+                if (failed) std::rethrow_exception(failed);
+                return results;
+            }
+            ensure_scene(&hash);
+            return search_prepared(m, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
+        }
         ensure_scene();
+        return search_prepared(m, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
+    }
+
+protected:
+    /* the identity search over the prepared device scene (h_, cached_tmask_) */
+    std::vector<match_t> search_prepared(model<Point>& m, float dist_thres, float model_match_factor, float early_out_factor,
+                                         const sample_parameters& sample_params, uint32_t max_icp_iterations) {
         const std::vector<int32_t>& tangent_mask = cached_tmask_; /* tangent_mask_ (:46-54), kept with the device scene */
         detail::hip_backend<Point> be;
         be.s = h_;
@@ -495,21 +527,27 @@ public:
         std::vector<search::candidate_t> found;
         /* the backend's staging vectors (correspondence lists of a round's candidates, neighbourhood views: a few MB)
          * outlive the call: a search does not allocate and zero them again */
-        be.sc_scratch.swap(keep_sc_);
-        be.mc_scratch.swap(keep_mc_);
-        be.t_pairs.swap(keep_pairs_);
-        be.batch_stride = keep_stride_;
-        if (comm_ && tm_comm_world(comm_) > 1) {
-            detail::hip_exchange hx{comm_};
-            found = search::find_all(be, tangent_mask, be.p, hx, nullptr, &keep_ws_);
-        } else {
-            search::single_rank one;
-            found = search::find_all(be, tangent_mask, be.p, one, nullptr, &keep_ws_);
+        struct lend { /* ... and go back whichever way the search ends */
+            detail::hip_backend<Point>& be;
+            scene& sc;
+            lend(detail::hip_backend<Point>& b, scene& s) : be(b), sc(s) { swap(); be.batch_stride = sc.keep_stride_; }
+            ~lend() { swap(); sc.keep_stride_ = be.batch_stride; }
+            void swap() {
+                be.sc_scratch.swap(sc.keep_sc_);
+                be.mc_scratch.swap(sc.keep_mc_);
+                be.t_pairs.swap(sc.keep_pairs_);
+            }
+        };
+        {
+            lend lent(be, *this);
+            if (comm_ && tm_comm_world(comm_) > 1) {
+                detail::hip_exchange hx{comm_};
+                found = search::find_all(be, tangent_mask, be.p, hx, nullptr, &keep_ws_);
+            } else {
+                search::single_rank one;
+                found = search::find_all(be, tangent_mask, be.p, one, nullptr, &keep_ws_);
+            }
         }
-        be.sc_scratch.swap(keep_sc_);
-        be.mc_scratch.swap(keep_mc_);
-        be.t_pairs.swap(keep_pairs_);
-        keep_stride_ = be.batch_stride;
         std::vector<match_t> results;
         for (auto& c : found) {
             match_t r;
@@ -523,6 +561,7 @@ public:
         return results;
     }
 
+public:
     /* One match of a projected search: `match` lives in uvw space (transform = uvw model -> uvw scene,
      * scene_corrs = indices into this scene's cloud, model_corrs = indices into the ORIGINAL model cloud);
      * `projector` is the scene projector it was found under. A model point x appears in the scene at
@@ -792,11 +831,11 @@ protected:
      * so an in-place edit of the points between two calls must be seen; the searches reset mask_ themselves */
     /* a copy of tangent_mask_ for a caller that edits it (the projected searches) */
     void ensure_scene(std::vector<int32_t>& tangent_mask) {
-        ensure_scene();
+        ensure_scene(nullptr);
         tangent_mask = cached_tmask_;
     }
     /* the device scene and tangent_mask_ (cached_tmask_) for the cloud's current content */
-    void ensure_scene() {
+    void ensure_scene(const uint64_t* known_hash = nullptr) {
         const uint32_t n = (uint32_t)cloud_->size();
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { /* set_verbose(true): where the scene preparation's time goes */
@@ -805,7 +844,7 @@ protected:
             std::fprintf(stderr, "[scene] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
             t_last = now;
         };
-        const uint64_t hash = cloud_->content_hash();
+        const uint64_t hash = known_hash ? *known_hash : cloud_->content_hash();
         lap("content hash");
         cloud_->sync(hash); /* curvature computed for other content is forgotten */
         if (h_ && hash != cached_hash_) invalidate();

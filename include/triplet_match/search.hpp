@@ -1077,6 +1077,11 @@ struct find_all_workspace {
     std::vector<int32_t> mask, fp_mask;
     std::vector<uint32_t> tangent_indices;
     bool tangent_indices_valid = false;
+    /* what the last search set in the two masks: mask_ at `mask_set` (the accepted matches' points), fp_mask_ only at
+     * tangent points (first points are drawn from tangent_indices). While `sparse_reset` holds, the next search over
+     * the same tangent mask clears those entries instead of 8 MB per million points. */
+    std::vector<uint32_t> mask_set;
+    bool sparse_reset = false;
 };
 
 /* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
@@ -1094,10 +1099,17 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     find_all_workspace local;
     find_all_workspace& ws = keep ? *keep : local;
     std::vector<int32_t>&mask = ws.mask, &fp_mask = ws.fp_mask;
-    mask.assign(n, 0);
-    fp_mask.assign(n, 0);
-    if (initial_mask) mask = *initial_mask;
     std::vector<uint32_t>& tangent_indices = ws.tangent_indices;
+    if (keep && ws.sparse_reset && ws.tangent_indices_valid && mask.size() == n && fp_mask.size() == n) {
+        for (uint32_t idx : ws.mask_set) mask[idx] = 0;
+        for (uint32_t idx : tangent_indices) fp_mask[idx] = 0;
+    } else {
+        mask.assign(n, 0);
+        fp_mask.assign(n, 0);
+    }
+    ws.sparse_reset = false; /* until this search has ended in the ordinary way */
+    ws.mask_set.clear();
+    if (initial_mask) mask = *initial_mask;
     if (!ws.tangent_indices_valid) {
         tangent_indices.clear();
         for (uint32_t i = 0; i < n; ++i)
@@ -1132,7 +1144,9 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             results.push_back(std::move(mt));
         }
         detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
+        if (keep) ws.mask_set.insert(ws.mask_set.end(), added.begin(), added.end());
     }
+    ws.sparse_reset = keep != nullptr && initial_mask == nullptr;
     return results;
 }
 

@@ -107,6 +107,51 @@ int main() {
         });
         if (total.load() != 160 * 159 / 2) ++failures;
     }
+    {   // a background job (the cloud's hash under a search): every index once, foreground batches opened meanwhile
+        // complete first or side by side, finish() waits for all; with and without foreground work; a job object reused
+        for (int rep = 0; rep < 200; ++rep) {
+            const size_t n = (size_t)(1 + rep % 50);
+            std::vector<std::atomic<int>> hit(n);
+            for (auto& h : hit) h.store(0);
+            worker_pool::job j;
+            for (int twice = 0; twice < 2; ++twice) {
+                pool.begin_background(j, n, [&](size_t i) { hit[i].fetch_add(1); });
+                if (!j.pending()) ++failures;
+                if (rep % 3) {
+                    std::atomic<long> s{0};
+                    pool.run(20, [&](size_t i) { s.fetch_add((long)i); });
+                    if (s.load() != 190) ++failures;
+                }
+                pool.finish(j);
+                if (j.pending()) ++failures;
+                for (size_t i = 0; i < n; ++i)
+                    if (hit[i].load() != twice + 1) ++failures;
+            }
+        }
+        // a background task that throws: finish() rethrows, the pool goes on
+        worker_pool::job j;
+        bool caught = false;
+        pool.begin_background(j, 32, [&](size_t i) {
+            if (i == 5) throw std::runtime_error("bg");
+        });
+        try {
+            pool.finish(j);
+        } catch (const std::runtime_error& e) {
+            caught = std::string(e.what()) == "bg";
+        }
+        if (!caught) ++failures;
+        std::atomic<int> after{0};
+        pool.run(64, [&](size_t) { after.fetch_add(1); });
+        if (after.load() != 64) ++failures;
+        // begun inside a pooled task: runs inline at finish()
+        std::atomic<long> total{0};
+        pool.run(8, [&](size_t i) {
+            worker_pool::job in;
+            pool.begin_background(in, 10, [&](size_t k) { total.fetch_add((long)(i * 10 + k)); });
+            pool.finish(in);
+        });
+        if (total.load() != 80 * 79 / 2) ++failures;
+    }
     std::printf("%zu workers; %s (%d failures)\n", pool.size(), failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }

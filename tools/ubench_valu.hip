@@ -20,7 +20,7 @@
 #define REP8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_issue(uint32_t iters, float* out) {
+__global__ __launch_bounds__(256) void k_issue(uint32_t iters, float* out, unsigned long long* clk) {
     __shared__ float4 s_pose[64];
     __shared__ unsigned long long s_acc[16];
     if (threadIdx.x < 64) s_pose[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t iters, float* out) {
         d[k] = (double)a[k];
     }
     const f2 pb = f2{b, b};
+    /* s_memtime (shader clock) against s_memrealtime (100 MHz): the clock this kernel really ran at */
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     for (uint32_t it = 0; it < iters; ++it) {
         if (KIND == 0) {
 #define OP(k) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
@@ -109,6 +111,8 @@ __global__ __launch_bounds__(256) void k_issue(uint32_t iters, float* out) {
 #undef OP
         }
     }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0, clk[1] = r1 - r0;
     float r = c;
     for (int k = 0; k < 8; ++k) r += a[k] + p[k].x + p[k].y + (float)u[k] + (float)w[k] + (float)d[k];
     if (r == 0.12345f) out[threadIdx.x] = r + (float)s_acc[0];
@@ -126,10 +130,12 @@ static void run(const char* name, int waves_per_simd) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_issue<KIND>, grid, dim3(256), 0, 0, 100u, d_out);
+    unsigned long long* d_clk;
+    CK(hipMalloc(&d_clk, 16));
+    hipLaunchKernelGGL(k_issue<KIND>, grid, dim3(256), 0, 0, 100u, d_out, (unsigned long long*)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_issue<KIND>, grid, dim3(256), 0, 0, iters, d_out);
+    hipLaunchKernelGGL(k_issue<KIND>, grid, dim3(256), 0, 0, iters, d_out, d_clk);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -138,9 +144,15 @@ static void run(const char* name, int waves_per_simd) {
     CK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0));
     // SIMD cycles per wave-instruction = time * clock / (instructions per SIMD) ; instructions per SIMD = iters * 8 * waves
     const double cyc = (double)ms * 1e-3 * (double)khz * 1e3 / ((double)iters * 8.0 * waves_per_simd);
-    printf("%-44s %d wave(s)/SIMD  %8.3f ms  %6.2f cycles of the nominal %d MHz clock per wave-instruction and SIMD\n", name,
-           waves_per_simd, ms, cyc, khz / 1000);
+    unsigned long long h_clk[2] = {0, 0};
+    CK(hipMemcpy(h_clk, d_clk, 16, hipMemcpyDeviceToHost));
+    /* one wave's view: shader-clock ticks per instruction of all waves of its SIMD, and the shader clock itself */
+    const double own = (double)h_clk[0] / ((double)iters * 8.0 * waves_per_simd);
+    const double mhz = h_clk[1] ? (double)h_clk[0] / (double)h_clk[1] * 100.0 : 0.0;
+    printf("%-44s %d wave(s)/SIMD  %8.3f ms  %6.2f cycles of the nominal %d MHz clock per wave-instruction and SIMD; s_memtime: %.2f ticks, %.0f MHz\n", name,
+           waves_per_simd, ms, cyc, khz / 1000, own, mhz);
     CK(hipFree(d_out));
+    CK(hipFree(d_clk));
 }
 
 #define ALL(K, NAME) \
