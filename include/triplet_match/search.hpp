@@ -795,68 +795,76 @@ inline candidate_t icp(Backend& be, const candidate_t& match, const params_t& p)
 /* The arbitration of find_parallel, include/impl/scene.hpp:193-237: candidates sorted by their number of
  * correspondences (descending, stable), then accepted greedily: a candidate keeps only the scene points no
  * accepted candidate holds yet, and is accepted when at least min_points of those are tangent points and
- * at least min_points_all in total; a rejected candidate gives its points back (used_copy, :203). */
+ * at least min_points_all in total; a rejected candidate gives its points back (used_copy, :203).
+ *
+ * One pass over a candidate's list decides it: `owner` holds, per scene point, the number of the last candidate that
+ * claimed it (0 = nobody); a point is free when its owner is nobody or a REJECTED candidate (a 1-entry-per-candidate
+ * table says which), and a free point is claimed on the spot — a rejected candidate's claims simply stop counting,
+ * nothing is given back by hand. An accepted candidate that lost points to earlier ones is compacted in a second pass
+ * (its own number marks what it kept). Mark = the owner's type: a byte for up to 254 candidates. */
+namespace detail {
+template <class Mark>
+inline std::vector<candidate_t> arbitrate_marks(std::vector<candidate_t>& cands, uint32_t n_scene_points,
+                                                const std::vector<int32_t>& tangent_mask, uint32_t min_points,
+                                                uint32_t min_points_all, bool verbose) {
+    std::vector<candidate_t> result;
+    static thread_local std::vector<Mark> owner; /* kept per thread: a fresh array per round is page faults */
+    owner.assign(n_scene_points, Mark(0));
+    std::vector<unsigned char> accepted(cands.size() + 1, 0);
+    Mark* const own = owner.data();
+    for (size_t ci = 0; ci < cands.size(); ++ci) { /* greedy disjoint accept, :200-237 */
+        candidate_t& cand = cands[ci];
+        const Mark me = (Mark)(ci + 1);
+        const size_t n_c = cand.scene_corrs.size();
+        const uint32_t* sc = cand.scene_corrs.data();
+        uint32_t score = 0, kept = 0;
+        for (size_t k = 0; k < n_c; ++k) {
+            const uint32_t idx = sc[k];
+            if (accepted[own[idx]]) continue; /* an accepted candidate holds it */
+            own[idx] = me;
+            ++kept;
+            score += tangent_mask[idx] ? 1u : 0u;
+        }
+        const uint32_t score_all = kept;
+        if (verbose)
+            fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
+                    n_c, score_all, score, min_points, score_all, min_points_all);
+        if (score < min_points || score_all < min_points_all) continue; /* :227: its claims stop counting */
+        accepted[me] = 1;
+        candidate_t out;
+        out.transform = cand.transform;
+        out.signed_score = cand.signed_score;
+        if (kept == n_c) { /* overlaps nothing accepted: the candidate keeps its lists as they are */
+            out.scene_corrs = std::move(cand.scene_corrs);
+            out.model_corrs = std::move(cand.model_corrs);
+        } else {
+            const uint32_t* mc = cand.model_corrs.data();
+            out.scene_corrs.resize(kept);
+            out.model_corrs.resize(kept);
+            uint32_t at = 0;
+            for (size_t k = 0; k < n_c; ++k) {
+                const uint32_t idx = sc[k];
+                if (own[idx] != me) continue;
+                out.scene_corrs[at] = idx;
+                out.model_corrs[at] = mc[k];
+                ++at;
+            }
+        }
+        result.push_back(std::move(out));
+    }
+    return result;
+}
+}  // namespace detail
+
 inline std::vector<candidate_t> arbitrate(std::vector<candidate_t> cands, uint32_t n_scene_points,
                                           const std::vector<int32_t>& tangent_mask, uint32_t min_points,
                                           uint32_t min_points_all, bool verbose = false) {
     std::stable_sort(cands.begin(), cands.end(), [](const candidate_t& a, const candidate_t& b) {
         return a.scene_corrs.size() > b.scene_corrs.size(); /* :193-195 */
     });
-    std::vector<candidate_t> result;
-    std::vector<unsigned char> used(n_scene_points, 0); /* the reference's std::set<uint32_t> used, :198 */
-    /* the tangent points among each candidate's correspondences do not depend on the order of acceptance: counted side
-     * by side (the gathers from a 4 MB mask are most of the greedy loop's time); the loop below then only asks
-     * `used`, and counts again only for a candidate that overlaps an accepted one */
-    std::vector<uint32_t> tangent_of(cands.size(), 0);
-    ::triplet_match::detail::worker_pool::instance().run(cands.size(), [&](size_t c) {
-        uint32_t t = 0;
-        for (uint32_t idx : cands[c].scene_corrs) t += tangent_mask[idx] ? 1u : 0u;
-        tangent_of[c] = t;
-    });
-    for (size_t ci = 0; ci < cands.size(); ++ci) { /* greedy disjoint accept, :200-237 */
-        candidate_t& cand = cands[ci];
-        candidate_t out;
-        out.transform = cand.transform;
-        out.signed_score = cand.signed_score;
-        /* the points no accepted candidate holds yet, and how many of them are tangent points; `used` is only
-         * written once the candidate is accepted (a rejected one gives its points back, used_copy :203) */
-        const size_t n_c = cand.scene_corrs.size();
-        uint32_t score = 0, kept = 0;
-        const uint32_t* sc = cand.scene_corrs.data();
-        const uint32_t* mc = cand.model_corrs.data();
-        for (size_t k = 0; k < n_c; ++k) kept += used[sc[k]] ? 0u : 1u;
-        if (kept == n_c) {
-            score = tangent_of[ci]; /* overlaps nothing: every correspondence counts */
-        } else {
-            for (size_t k = 0; k < n_c; ++k) {
-                const uint32_t idx = sc[k];
-                if (!used[idx]) score += tangent_mask[idx] ? 1u : 0u;
-            }
-        }
-        if (kept == n_c) { /* ... and the candidate keeps its lists as they are */
-            out.scene_corrs = std::move(cand.scene_corrs);
-            out.model_corrs = std::move(cand.model_corrs);
-        } else {
-            out.scene_corrs.resize(kept);
-            out.model_corrs.resize(kept);
-            uint32_t at = 0;
-            for (size_t k = 0; k < n_c; ++k) {
-                const uint32_t idx = sc[k];
-                if (used[idx]) continue;
-                out.scene_corrs[at] = idx;
-                out.model_corrs[at] = mc[k];
-                ++at;
-            }
-        }
-        const uint32_t score_all = kept;
-        if (verbose)
-            fprintf(stderr, "[search] candidate: %zu corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
-                    n_c, score_all, score, min_points, score_all, min_points_all);
-        if (score < min_points || score_all < min_points_all) continue; /* :227 */
-        for (uint32_t idx : out.scene_corrs) used[idx] = 1;
-        result.push_back(std::move(out));
-    }
-    return result;
+    if (cands.size() <= 254)
+        return detail::arbitrate_marks<unsigned char>(cands, n_scene_points, tangent_mask, min_points, min_points_all, verbose);
+    return detail::arbitrate_marks<uint32_t>(cands, n_scene_points, tangent_mask, min_points, min_points_all, verbose);
 }
 
 /* find_parallel, include/impl/scene.hpp:108-240 */
@@ -1132,19 +1140,36 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
         auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p, ex);
         if (matches.empty()) break;
         TM_TIMED(mask);
-        added.clear();
+        /* :88-90 for every accepted match (on this thread: the matches' indices interleave in the cloud's order, and
+         * threads writing into the same cache lines cost more than they share); `added` = the lists one after another,
+         * what the backend's mask takes */
         {
             size_t total = 0;
             for (const auto& mt : matches) total += mt.scene_corrs.size();
+            added.clear();
             added.reserve(total);
         }
-        for (auto& mt : matches) {
-            for (uint32_t idx : mt.scene_corrs) mask[idx] = 1; /* :88-90 */
+        auto t_m = std::chrono::steady_clock::now();
+        auto lap_m = [&](const char* what) {
+            if (!p.verbose) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[mask] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_m).count());
+            t_m = now;
+        };
+        for (const auto& mt : matches) {
+            for (uint32_t idx : mt.scene_corrs) mask[idx] = 1;
             added.insert(added.end(), mt.scene_corrs.begin(), mt.scene_corrs.end());
-            results.push_back(std::move(mt));
         }
+        lap_m("host mask + list");
+        for (auto& mt : matches) results.push_back(std::move(mt));
         detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
-        if (keep) ws.mask_set.insert(ws.mask_set.end(), added.begin(), added.end());
+        lap_m("backend mask_add");
+        if (keep) {
+            if (ws.mask_set.empty())
+                ws.mask_set.swap(added);
+            else
+                ws.mask_set.insert(ws.mask_set.end(), added.begin(), added.end());
+        }
     }
     ws.sparse_reset = keep != nullptr && initial_mask == nullptr;
     return results;

@@ -97,6 +97,17 @@ static int run_arbitrate() {
     /* equal sizes keep their input order (stable sort; the reference's std::sort leaves it unspecified) */
     auto r4 = search::arbitrate({cand(7, {0, 2, 4, 6}), cand(8, {0, 2, 4, 6})}, 20, tmask, 2, 4);
     CHECK(r4.size() == 1 && r4[0].transform.m[0] == 7.f, "of two identical candidates the first wins, the second is emptied");
+    /* more candidates than a byte numbers (the wide owner marks): 300 one-point candidates over 150 points, every
+     * point offered twice — the first 150 are accepted, their twins find the point held */
+    {
+        std::vector<search::candidate_t> many;
+        std::vector<int32_t> all_tangent(150, 1);
+        for (int k = 0; k < 300; ++k) many.push_back(cand(k, {(uint32_t)(k % 150)}));
+        auto rm = search::arbitrate(many, 150, all_tangent, 1, 1);
+        bool ok = rm.size() == 150;
+        for (size_t k = 0; k < rm.size() && ok; ++k) ok = rm[k].transform.m[0] == (float)k && rm[k].scene_corrs == std::vector<uint32_t>({(uint32_t)k});
+        CHECK(ok, "300 candidates: the first of every pair is accepted");
+    }
     printf("%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures);
     return failures ? 1 : 0;
 }

@@ -295,6 +295,7 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
         }
     }
     auto undo = [&](int rc) {
+        if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -305,6 +306,7 @@ int tm_ctx_create(int device_id, tm_ctx** out) {
     hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreate(&c->ev0);
     if (he == hipSuccess) he = hipEventCreate(&c->ev1);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming);
     if (he != hipSuccess) {
         set_error("tm_ctx_create: stream / event creation failed: %s", hipGetErrorString(he));
         return undo(TM_ERR_HIP);
@@ -344,6 +346,7 @@ int tm_ctx_destroy(tm_ctx* c) {
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -169,6 +169,7 @@ struct tm_ctx {
     int timing_mode = 0;     /* tm_ctx_enable_timing: 0 off, 1 events + stage counters, 2 events only */
     tmx::options opt;        /* switches, see tmx::options */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_copy = nullptr; /* behind an upload from a pinned staging buffer whose kernels the call does not wait for */
     std::vector<hipEvent_t> ev_ring;      /* 2 * kTimedRing, created on first use */
     uint64_t n_timed = 0;                 /* timed launches since tm_ctx_enable_timing(ctx, 1) */
     uint64_t timed_hyp[tmx::kTimedRing];  /* per ring row: hypotheses of the launch */
@@ -336,7 +337,8 @@ struct tm_scene {
     tmx::dbuf<unsigned long long> d_keys; /* the sorted slots' curve keys (63 bits, an octree cell per 3-bit prefix step;
                                              non-finite points ~0): what tm_scene_curvature_subset builds its tree from */
     tmx::dbuf<unsigned char> d_bounds; /* tmx::scene_bounds (tm_scene_build.hip) */
-    uint64_t n_live = 0;              /* finite and unmasked points */
+    uint64_t n_live = 0;              /* finite and unmasked points (scene_live_count: read back on demand while live_pending) */
+    bool live_pending = false;        /* a mask change recounted it on the device; nobody has asked since */
     /* original order (hypothesis generation addresses points by original index) */
     tmx::dbuf<float4> opos;  /* xyz, w = tangent_mask ? 1 : 0 */
     tmx::dbuf<float4> otan;  /* raw tangent xyz, w = masked ? 1 : 0 */
@@ -487,6 +489,8 @@ int scene_mirror(const tm_scene* s);
 /* host mirror row of point i (12 floats), or null for a point a sparse mirror does not hold */
 const float* scene_row(const tm_scene* s, uint32_t i);
 int scene_host_mask(const tm_scene* s);
+/* n_live, fetched from the device if a mask change left it there (a search changes the mask twice and never asks) */
+int scene_live_count(const tm_scene* s, uint64_t* live);
 }
 
 #endif /* TM_INTERNAL_H_ */

@@ -1026,16 +1026,24 @@ __global__ void k_finalize_scores(const unsigned long long* __restrict__ fx, uin
  * count and fixed-point score sum in count_fx[2 k] / [2 k + 1] */
 __global__ __launch_bounds__(256) void k_extract_batch(score_args a, uint32_t n_pad, uint32_t n,
                                                        uint32_t* __restrict__ match_of_orig,
-                                                       unsigned long long* __restrict__ count_fx) {
+                                                       unsigned long long* __restrict__ count_fx,
+                                                       const float4* __restrict__ tiles = nullptr, float coord_max = 0.f) {
     __shared__ unsigned long long s_fx[4];
     __shared__ uint32_t s_cnt[4];
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     const uint32_t k = blockIdx.y;
-    const float4 v = s < n_pad ? a.spos[s] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+    const pose12 T = load_pose(a.poses + 16 * (size_t)k);
+    /* a wave = a 64-point tile: one that cannot reach the model's voxel box under this pose holds no match */
+    bool reach = s < n_pad;
+    if (reach && tiles) {
+        const float2 ax = pose_aux(T, coord_max);
+        reach = sphere_hits_box(a, T, ax.x, ax.y, tiles[s >> 6]);
+    }
+    if (!__syncthreads_or(reach ? 1 : 0)) return; /* none of the workgroup's four tiles: nothing to add either */
+    const float4 v = reach ? a.spos[s] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
     long long fx = 0;
     uint32_t hit = 0;
     if (v.x == v.x) {
-        const pose12 T = load_pose(a.poses + 16 * (size_t)k);
         uint32_t pass = 0, m = 0xFFFFFFFFu;
         hit = eval_point(a, T, make3(v.x, v.y, v.z), s, fx, pass, &m);
         if (hit) match_of_orig[(size_t)k * n + __float_as_uint(v.w)] = m;
@@ -1092,7 +1100,8 @@ __global__ __launch_bounds__(256) void k_extract_scatter_batch(const uint32_t* _
  * fixed-point sums and the count are integers, so thread-local accumulation, the wave shuffles, the LDS
  * step and the final pass may add them in any order. Each block stores its 16 partials; k_icp_finalize
  * adds the blocks (no atomics: sixteen same-line atomics per wave serialise in one L2 channel). */
-constexpr int kIcpBlocks = 512;
+constexpr int kIcpBlocks = 128; /* per candidate: 512 waves deal the scene's tiles among themselves; the epilogue (16 64-bit sums
+                                 * through the wave, 400 cross-lane moves) is paid per wave, and was most of the kernel with 2048 */
 
 struct icp_state;
 __device__ __forceinline__ const uint32_t* icp_done_word(const icp_state* st, uint32_t cand);
@@ -1101,7 +1110,8 @@ __device__ __forceinline__ const uint32_t* icp_done_word(const icp_state* st, ui
  * pose a.poses + 16 y, partials [y][gridDim.x][16], loop state st[y] (null on the first pass) */
 __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n_pad,
                                                         unsigned long long* __restrict__ partials /* [cand][grid][16] */,
-                                                        const icp_state* __restrict__ st = nullptr) {
+                                                        const icp_state* __restrict__ st = nullptr,
+                                                        const float4* __restrict__ tiles = nullptr, float coord_max = 0.f) {
     __shared__ long long s_acc[4][16];
     const uint32_t cand = blockIdx.y;
     if (st && *icp_done_word(st, cand)) return; /* tm_icp_refine: this candidate's loop has ended */
@@ -1111,7 +1121,13 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(score_args a, uint32_t n
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0;
     const pose12 T = load_pose(a.poses);
+    const float2 ax = pose_aux(T, coord_max);
+    /* a wave = a 64-point tile of the sorted scene at a time, tiles dealt round the waves of the grid: a tile whose
+     * bounding sphere cannot reach the model's voxel box under this pose (the conservative test of the scoring kernels)
+     * holds no in-grid point and is passed over — a candidate touches a tenth of the scene, and its tiles, neighbours in
+     * the curve order, spread evenly over the waves */
     for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < n_pad; s += gridDim.x * 256) {
+        if (tiles && !sphere_hits_box(a, T, ax.x, ax.y, tiles[s >> 6])) continue;
         float4 v = a.spos[s];
         if (!(v.x == v.x)) continue;
         long long fx = 0;
@@ -1663,7 +1679,11 @@ static int score_device(tm_scene* s, tm_model* m, int traits_kind, const float* 
     return TM_OK;
 }
 
-static uint64_t count_active(const tm_scene* s) { return s->n_live; }
+static uint64_t count_active(const tm_scene* s) {
+    uint64_t live = s->n_live;
+    (void)tmx::scene_live_count(s, &live); /* fetched now if the last mask change left it on the device */
+    return live;
+}
 
 static int generate_device(tm_scene* s, tm_model* m, const uint2* d_ij, uint32_t n_pairs, float minf,
                            float maxf, int force_up, int query_limit, float* d_poses, uint4* d_prov,
@@ -1975,9 +1995,12 @@ int tm_scene_mask_add(tm_scene* s, const uint32_t* indices, uint32_t n_idx) {
     memcpy(s->h_pinned, indices, (size_t)n_idx * 4);
     TM_FORWARD(s->w_mask_idx.ensure(n_idx));
     TM_HIP_CHECK(hipMemcpyAsync(s->w_mask_idx.p, s->h_pinned, (size_t)n_idx * 4, hipMemcpyHostToDevice, c->stream));
+    TM_HIP_CHECK(hipEventRecord(c->ev_copy, c->stream));
     hipLaunchKernelGGL(k_mask_set, dim3((n_idx + 255) / 256), dim3(256), 0, c->stream, s->w_mask_idx.p, n_idx, s->d_mask.p);
     TM_HIP_CHECK(hipGetLastError());
-    return scene_build(s, false);
+    const int rc = scene_build(s, false); /* queued, not waited for */
+    TM_HIP_CHECK(hipEventSynchronize(c->ev_copy)); /* the staging buffer is free again; the kernels run on */
+    return rc;
 }
 
 int tm_scene_set_tangent_mask(tm_scene* s, const int32_t* tangent_mask) {
@@ -1995,7 +2018,9 @@ int tm_scene_set_tangent_mask(tm_scene* s, const int32_t* tangent_mask) {
 uint32_t tm_scene_size(const tm_scene* s) {
     TM_GUARD(s); return s ? s->n : 0; }
 uint64_t tm_scene_live_count(const tm_scene* s) {
-    TM_GUARD(s); return s ? s->n_live : 0; }
+    TM_GUARD(s);
+    return s ? count_active(s) : 0;
+}
 
 int tm_scene_download(const tm_scene* s, float* surfels, int32_t* tangent_mask) {
     TM_GUARD(s);
@@ -2278,7 +2303,7 @@ static int extract_batch_on_device(tm_scene* s, tm_model* m, const float* d_pose
     a.by = m->bdim[1];
     a.code_max = 255u;
     hipLaunchKernelGGL(k_extract_batch, dim3(s->n_sorted / 256, n), dim3(256), 0, c->stream, a, s->n_sorted, s->n, s->w_u32a.p,
-                       d_count_fx);
+                       d_count_fx, (const float4*)s->tiles.p, s->coord_max);
     /* ordered compaction on the device: only the correspondences travel back */
     hipLaunchKernelGGL(k_extract_count_batch, dim3(n_blocks, n), dim3(256), 0, c->stream, s->w_u32a.p, s->n, n_waves,
                        s->w_u32b.p);
@@ -2401,7 +2426,7 @@ int tm_icp_accumulate(tm_scene* s, tm_model* m, const float pose16[16], float di
     score_args a;
     icp_score_args(s, m, dist_thres, a);
     hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks), dim3(256), 0, c->stream, a, s->n_sorted,
-                       s->w_scores_fx.p + 16);
+                       s->w_scores_fx.p + 16, (const icp_state*)nullptr, (const float4*)s->tiles.p, s->coord_max);
     hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(kIcpFinalizeThreads), 0, c->stream, s->w_scores_fx.p + 16, icp_blocks,
                        s->w_scores_fx.p, 0);
     TM_HIP_CHECK(hipGetLastError());
@@ -2444,7 +2469,7 @@ int tm_icp_refine_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t
     icp_score_args(s, m, dist_thres, a);
     for (uint32_t pass = 0; pass <= max_iterations; ++pass) {
         hipLaunchKernelGGL(k_icp_accumulate, dim3(icp_blocks, n), dim3(256), 0, c->stream, a, s->n_sorted, partials,
-                           pass ? st : (const icp_state*)nullptr);
+                           pass ? st : (const icp_state*)nullptr, (const float4*)s->tiles.p, s->coord_max);
         hipLaunchKernelGGL(k_icp_finalize, dim3(n), dim3(kIcpFinalizeThreads), 0, c->stream, partials, icp_blocks, sums, pass ? 1 : 0,
                            s->w_poses.p, st, max_iterations, pass == 0 ? 1 : 0);
     }

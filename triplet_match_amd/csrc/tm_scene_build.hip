@@ -484,6 +484,14 @@ int scene_build(tm_scene* s, bool resort) {
     hipLaunchKernelGGL(k_scene_supers, dim3(n_super), blk, 0, c->stream, s->spos.p, n_pad, 4096u, s->supers.p);
     hipLaunchKernelGGL(k_scene_supers, dim3(n_pad / 512), blk, 0, c->stream, s->spos.p, n_pad, 512u, s->chunks.p);
     TM_HIP_CHECK(hipGetLastError());
+    if (!resort && s->n_sorted == n_pad) {
+        /* only mask_ changed: the arrays are patched in stream order, and the one number the host keeps (the live
+         * count, read by the full-scene scoring calls) stays on the device until somebody asks — a search changes the
+         * mask twice and waited here for six small kernels each time */
+        s->live_pending = true;
+        s->n_tiles = n_tiles;
+        return TM_OK;
+    }
     scene_bounds h;
     TM_HIP_CHECK(hipMemcpyAsync(&h, bnd, sizeof h, hipMemcpyDeviceToHost, c->stream));
     TM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -493,8 +501,24 @@ int scene_build(tm_scene* s, bool resort) {
         return f;
     }() : 0.f;
     s->n_live = h.live;
+    s->live_pending = false;
     s->n_sorted = n_pad;
     s->n_tiles = n_tiles;
+    return TM_OK;
+}
+
+int scene_live_count(const tm_scene* cs, uint64_t* live) {
+    tm_scene* s = const_cast<tm_scene*>(cs);
+    if (s->live_pending) {
+        tm_ctx* c = s->ctx;
+        TM_HIP_CHECK(hipSetDevice(c->device));
+        scene_bounds h;
+        TM_HIP_CHECK(hipMemcpyAsync(&h, s->d_bounds.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        s->n_live = h.live;
+        s->live_pending = false;
+    }
+    *live = s->n_live;
     return TM_OK;
 }
 
