@@ -337,9 +337,9 @@ def main():
     #                     instruction occupies its SIMD for four cycles; tools/ubench_valu.hip reads 3.75-4.2 per
     #                     instruction against s_memtime with two or more waves per SIMD) over 1024 SIMDs x the shader
     #                     cycles of the launch (GRBM_GUI_ACTIVE / 8 XCDs): counters of the PMC passes only, i.e. under the
-    #                     profiler. `valu_issue_frac_this_run` scales it to this run's kernel time at the clock the
-    #                     profiled launch ran at. The rest of a SIMD's cycles its four waves wait (s_waitcnt: 60 % of the
-    #                     wave cycles, SQ_WAIT_ANY / SQ_WAVE_CYCLES).
+    #                     profiler (the launch is slower there and its clock is not this run's: the figure is not
+    #                     rescaled to this run). `wave_wait_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of its resident
+    #                     cycles a wave spends in s_waitcnt (four waves per SIMD).
     #   line_rate_frac  = fabric lines per second of this run over the rate at which this chip delivers uniformly
     #                     random 128-B lines to all CUs (tools/ubench_l2.hip, profiles/r04/ubench_l2.txt): 3.12 ns per
     #                     line and CU out of an Infinity-Cache-resident table, 4.59 ns out of HBM.
@@ -347,9 +347,6 @@ def main():
         roofline["valu_issue_frac"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * pmc["shader_cycles_per_launch"]), 4)
         roofline["valu_issue_basis"] = ("4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), both from the PMC passes "
                                         "of the same command (under the profiler)")
-        if pmc.get("kernel_ms_under_profiler"):
-            clock = pmc["shader_cycles_per_launch"] / (pmc["kernel_ms_under_profiler"] * 1e-3)
-            roofline["valu_issue_frac_this_run"] = round(4.0 * pmc["sq_insts_valu"] / (1024.0 * clock * k_s), 4)
         if pmc.get("sq_wait_any") and pmc.get("sq_wave_cycles"):
             roofline["wave_wait_frac"] = round(pmc["sq_wait_any"] / pmc["sq_wave_cycles"], 4)
     if pmc and pmc.get("l2_fabric_read_requests"):

@@ -65,7 +65,7 @@ int tm_device_alloc(tm_ctx* ctx, uint64_t bytes, void** d_ptr);
 int tm_device_free(tm_ctx* ctx, void* d_ptr);
 /* The context's cache of released device blocks (work buffers of the calls, the arrays of destroyed scenes and
  * models): a block goes to the next request of its size class instead of hipFree + hipMalloc, in stream order on the
- * context's one stream. Budget = option "pool_mib" (default 1024 MiB, 0 = no cache; a smaller value trims at once).
+ * context's one stream. Budget = option "pool_mib" (default 4096 MiB, 0 = no cache; a smaller value trims at once; a release past the budget trims to three quarters of it).
  * cached_bytes = held right now, reused / allocated = requests served from the cache / by hipMalloc so far. The
  * reference has no counterpart (host vectors, include/impl/scene.hpp:424-430). */
 int tm_ctx_pool_stats(const tm_ctx* ctx, uint64_t* cached_bytes, uint64_t* reused, uint64_t* allocated);

@@ -1638,7 +1638,7 @@ def test_block_cache_of_a_context(small_case):
         return out
     want = one_round()
     cached0, reused0, alloc0 = ctx.pool_stats()
-    assert cached0 > 0 and ctx.get_option("pool_mib") == 1024
+    assert cached0 > 0 and ctx.get_option("pool_mib") == 4096
     for _ in range(3):
         got = one_round()
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])

@@ -2,7 +2,7 @@
 # round-5 evidence run on the GPU box: kernel stats of the default bench command, the PMC passes the roofline line
 # quotes for every workload (profiles/r05/traffic.json for c2 with the voxel-index-folded pass of the timing-experiments
 # build; traffic_c3.json / _c4 / _c5 from passes 1, 3, 5, 7), the early-drop batch, and the bench lines themselves.
-# usage (repo root): tools/profile_round5.sh   (STAGES="stats pmc folded wl ed bench" selects)
+# usage (repo root): tools/profile_round5.sh   (STAGES="stats pmc folded wl ed search bench" selects)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r05_final
 mkdir -p $out profiles/r05
@@ -41,8 +41,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/ed_trace -- python3
 python3 tools/make_ed_traffic_json.py $out/ed_pmc $out/ed_trace $out/ed_plain.json $out/early_drop_traffic.json > /dev/null
 cp $out/ed_trace/*/*_kernel_stats.csv $out/early_drop_kernel_stats.csv; rm -rf $out/ed_pmc $out/ed_trace
 fi
+if want search; then
+echo "search" >> $out/progress.log
+tools/search_time.sh 30 > $out/search_time.txt 2>&1
+tools/search_trace.sh $out/search_trace > $out/search_timeline.txt 2>&1; rm -rf $out/search_trace
+fi
 if want bench; then
 echo "bench" >> $out/progress.log
+# the lines quote the passes made above (same sources, same box): put them where bench.py looks
+cp $out/traffic*.json $out/early_drop_traffic.json profiles/r05/ 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 > $out/bench_n1.json 2> $out/bench_n1.log
 for wl in c3 c4 c5; do python3 bench.py --workload $wl --steps 10 --warmup 2 > $out/bench_$wl.json 2> $out/bench_$wl.log; done
 cut -c1-600 $out/bench_n1.json

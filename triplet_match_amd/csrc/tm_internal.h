@@ -132,7 +132,8 @@ struct options {
     int search_per_range = 0; /* 1: the batches of tm_search_batches run their segments one batch after the other */
     int search_step_check = 1; /* 0: every segment step of a merged round is queued; 1: the batches' stop words are read
                                   back after the first step and every third one, and a settled round queues no more */
-    int pool_mib = 1024;      /* released device blocks the context keeps for reuse, in MiB (0: hipFree at once) */
+    int pool_mib = 4096;      /* released device blocks the context keeps for reuse, in MiB (0: hipFree at once); 288 GB per
+                                 device: 1 GiB was reached by 25 bench steps, and every release past it cost a hipFree */
 };
 
 /* released device blocks of one context by capacity (see device_take) */
