@@ -257,6 +257,10 @@ def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
         gpu_small["scene"].mask_add(np.r_[more[len(more) // 2:], more[:3]])
         mask2 = mask.copy()
         mask2[more] = 1
+        # the live count (finite, unmasked points) stays on the device after a mask change until it is asked for
+        finite = np.isfinite(small_case["scene"]["surfels"][:, 0:3]).all(axis=1)
+        assert gpu_small["scene"].live_count() == int(np.count_nonzero(finite & (mask2 == 0)))
+        assert gpu_small["scene"].live_count() == int(np.count_nonzero(finite & (mask2 == 0)))  # asked twice: kept
         oracle_small["scene"].set_mask(mask2)
         co2, so2, _ = oracle_small["scene"].score_hypotheses(oracle_small["model"], poses, 0.5, DT)
         ca, sa = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
@@ -265,8 +269,10 @@ def test_inlier_counts_subset_and_mask(gpu_small, oracle_small, small_case):
         cb, sb = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
         assert np.array_equal(ca, cb) and np.array_equal(sa, sb)
         gpu_small["scene"].set_mask(None)
+        assert gpu_small["scene"].live_count() == int(np.count_nonzero(finite))
         gpu_small["scene"].set_mask(None)  # clearing a clear mask is a no-op
         gpu_small["scene"].mask_add(np.flatnonzero(mask2).astype(np.uint32))
+        assert gpu_small["scene"].live_count() == int(np.count_nonzero(finite & (mask2 == 0)))
         cc, sc_ = gpu_small["scene"].score_hypotheses(gpu_small["model"], poses, DT)
         assert np.array_equal(cc, cb) and np.array_equal(sc_, sb)
     finally:
