@@ -264,6 +264,9 @@ int tm_scene_set_mask(tm_scene* scene, const int32_t* mask);
  * over an accepted match's scene_corrs): same state as tm_scene_set_mask with the updated mask, without moving 4 bytes
  * per scene point up and down for a few correspondences' worth of change. */
 int tm_scene_mask_add(tm_scene* scene, const uint32_t* indices, uint32_t n);
+/* ... the scene points of rows `rows` of the LAST tm_extract_correspondences_batch / tm_extract_arbitrate_batch call on
+ * this scene, whose lists are still on the device (the accepted matches of a find_parallel round, :87-90) */
+int tm_scene_mask_add_extracted(tm_scene* scene, const uint32_t* rows, uint32_t n_rows);
 uint32_t tm_scene_size(const tm_scene* scene);
 
 /* nn = cloud_->radius_search_inclusive(radius, p1) as used at include/impl/scene.hpp:273
@@ -428,6 +431,18 @@ int tm_extract_correspondences(tm_scene* scene, tm_model* model, const float pos
 int tm_extract_correspondences_batch(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n,
                                      float dist_thres, uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride,
                                      uint32_t* counts, double* scores);
+
+/* The same, and the arbitration of find_parallel over the n candidates these poses are (include/impl/scene.hpp:
+ * 193-237) while their lists are still on the device: sorted by number of correspondences (descending, stable), a
+ * candidate keeps the scene points no ACCEPTED earlier candidate holds and is accepted when at least min_points of
+ * them are tangent points (the scene's tangent mask) and at least min_points_all in total (:114-115, :227).
+ * verdict[k] = 1 accepted, 0 rejected (its rows are not written), kept[k] / tangent_kept[k] = its two counts (either
+ * may be null). verdict = -1 for EVERY k when the host has to decide: an accepted candidate would lose points to an
+ * earlier one (its lists need trimming), or n > 254 — all rows are then written, as by the call above. */
+int tm_extract_arbitrate_batch(tm_scene* scene, tm_model* model, const float* poses16, uint32_t n, float dist_thres,
+                               uint32_t min_points, uint32_t min_points_all, uint32_t* scene_corrs,
+                               uint32_t* model_corrs, uint32_t stride, uint32_t* counts, double* scores,
+                               int32_t* verdict, uint32_t* kept, uint32_t* tangent_kept);
 
 /* One ICP accumulation pass (reference icp_, include/impl/scene.hpp:385-393 + icp_correlation,
  * opencl/icp.cl:55-86): finds the correspondences of `pose16` exactly like finish_find (all points) and

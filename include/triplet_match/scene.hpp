@@ -24,7 +24,7 @@ namespace detail {
  * environment ONCE per process, on first use — never inside the search loops. */
 struct search_switches {
     bool search_unfused, search_per_chunk, subset_general, icp_host_loop, icp_per_candidate, dense_neighbourhoods,
-        host_curvature_tree, sequential_sampling, hash_first;
+        host_curvature_tree, sequential_sampling, hash_first, host_arbitration;
 };
 inline const search_switches& env_once() {
     static const search_switches sw = {std::getenv("TM_SEARCH_UNFUSED") != nullptr,
@@ -35,7 +35,8 @@ inline const search_switches& env_once() {
                                        std::getenv("TM_DENSE_NEIGHBOURHOODS") != nullptr,
                                        std::getenv("TM_HOST_CURVATURE_TREE") != nullptr,
                                        std::getenv("TM_SEQUENTIAL_SAMPLING") != nullptr,
-                                       std::getenv("TM_HASH_FIRST") != nullptr};
+                                       std::getenv("TM_HASH_FIRST") != nullptr,
+                                       std::getenv("TM_HOST_ARBITRATION") != nullptr};
     return sw;
 }
 
@@ -370,6 +371,63 @@ struct hip_backend {
         });
     }
     size_t batch_stride = 0;
+    /* finish_find of a round's candidates AND their arbitration (include/impl/scene.hpp:193-237) where the lists are
+     * (tm_extract_arbitrate_batch): only the accepted candidates' lists come back, the greedy pass over half a million
+     * list entries does not run on this side, and the accepted points reach the device's mask_ without going up again
+     * (add_extracted_to_mask). Set by scene<Point>'s identity search, whose tangent mask IS the device scene's;
+     * TM_HOST_ARBITRATION=1 keeps search::arbitrate. false = not decided here: the caller extracts and arbitrates. */
+    bool device_arbitration = false;
+    bool extract_arbitrate(const std::vector<search::pose_t>& Ts, float dist_thres, uint32_t min_points, uint32_t min_points_all,
+                           std::vector<search::candidate_t>& accepted, bool verbose) {
+        accepted.clear();
+        if (!device_arbitration || env_once().host_arbitration) return false;
+        const uint32_t n = (uint32_t)Ts.size();
+        if (n == 0) return true;
+        std::vector<uint32_t> counts(n), kept(n), tan(n);
+        std::vector<double> scores(n);
+        std::vector<int32_t> verdict(n, -1);
+        size_t stride = batch_stride ? batch_stride : std::max<size_t>(1024, mcloud ? mcloud->size() + mcloud->size() / 4 : 0);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (sc_scratch.size() < stride * n) sc_scratch.resize(stride * n);
+            if (mc_scratch.size() < stride * n) mc_scratch.resize(stride * n);
+            const int rc = tm_extract_arbitrate_batch(s, m, &Ts[0].m[0], n, dist_thres, min_points, min_points_all, sc_scratch.data(),
+                                                      mc_scratch.data(), (uint32_t)stride, counts.data(), scores.data(),
+                                                      verdict.data(), kept.data(), tan.data());
+            if (rc == TM_ERR_CAPACITY && attempt == 0) {
+                size_t mx = 1;
+                for (uint32_t cnt : counts) mx = std::max<size_t>(mx, cnt);
+                stride = batch_stride = mx + mx / 8;
+                continue;
+            }
+            check(rc, "tm_extract_arbitrate_batch");
+            break;
+        }
+        for (int32_t v : verdict)
+            if (v < 0) return false; /* an accepted candidate would have to be trimmed: the host's pass does that */
+        std::vector<uint32_t> order(n);
+        for (uint32_t k = 0; k < n; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return counts[x] > counts[y]; }); /* :193-195 */
+        std::vector<uint32_t> take;
+        for (uint32_t k : order) {
+            if (verbose)
+                std::fprintf(stderr, "[search] candidate: %u corrs (%u after overlap removal), tangent inliers %u (need %u), all %u (need %u)\n",
+                             counts[k], kept[k], tan[k], min_points, kept[k], min_points_all);
+            if (verdict[k] == 1) take.push_back(k);
+        }
+        accepted.resize(take.size());
+        ::triplet_match::detail::worker_pool::instance().run(take.size(), [&](size_t a) {
+            const uint32_t k = take[a];
+            accepted[a].transform = Ts[k];
+            accepted[a].signed_score = scores[k];
+            accepted[a].device_row = (int32_t)k;
+            accepted[a].scene_corrs.assign(sc_scratch.begin() + k * stride, sc_scratch.begin() + k * stride + counts[k]);
+            accepted[a].model_corrs.assign(mc_scratch.begin() + k * stride, mc_scratch.begin() + k * stride + counts[k]);
+        });
+        return true;
+    }
+    void add_extracted_to_mask(const std::vector<uint32_t>& rows) {
+        check(tm_scene_mask_add_extracted(s, rows.data(), (uint32_t)rows.size()), "tm_scene_mask_add_extracted");
+    }
     /* the whole ICP loop on the device (tm_icp_refine); TM_ICP_HOST_LOOP=1: one call per pass, fits on the host */
     bool supports_icp_refine() const { return !env_once().icp_host_loop; }
     search::pose_t icp_refine(const search::pose_t& T, float dist_thres, uint32_t max_iterations) {
@@ -522,6 +580,7 @@ protected:
         be.n_t = m.point_count();
         be.diam = m.diameter();
         be.raw_rows = tm_model_get_feature_bounds(be.m, be.bmin, be.bmax) == TM_OK; /* the device scene = this cloud's rows */
+        be.device_arbitration = true; /* tangent_mask below is the one the device scene was made with */
         stats_ = search::stats_t();
         fill_params(be.p, dist_thres, model_match_factor, early_out_factor, sample_params, max_icp_iterations);
         std::vector<search::candidate_t> found;

@@ -52,6 +52,7 @@ struct candidate_t { /* match_t with the scene->model transform (inverted once a
     pose_t transform;
     std::vector<uint32_t> scene_corrs, model_corrs;
     double signed_score = 0.0;
+    int32_t device_row = -1; /* >= 0: the backend still holds these lists (row of its last batched extraction) */
 };
 
 /* wall-clock seconds per phase of a search, filled when params_t::stats points at one */
@@ -493,6 +494,35 @@ template <class B>
 inline void mask_add(B& be, const std::vector<int32_t>&, const std::vector<uint32_t>& added, std::true_type) { be.add_to_mask(added); }
 template <class B>
 inline void mask_add(B& be, const std::vector<int32_t>& mask, const std::vector<uint32_t>&, std::false_type) { be.set_mask(mask); }
+
+/* does the backend extract AND arbitrate the candidates of a round where their lists are (hip_backend:
+ * tm_extract_arbitrate_batch)? true = `accepted` is what arbitrate() would return for these poses, in its order, with
+ * device_row set; false = not decided there (unsupported, switched off, or an accepted candidate needs trimming) */
+template <class B, class = void>
+struct has_extract_arbitrate : std::false_type {};
+template <class B>
+struct has_extract_arbitrate<B, decltype(void(std::declval<B&>().extract_arbitrate(std::declval<const std::vector<pose_t>&>(), 0.f, 0u, 0u,
+                                                                                    std::declval<std::vector<candidate_t>&>(), false)))>
+    : std::true_type {};
+template <class B>
+inline bool extract_arbitrate(B& be, const std::vector<pose_t>& Ts, float dist_thres, uint32_t min_points, uint32_t min_points_all,
+                              std::vector<candidate_t>& accepted, bool verbose, std::true_type) {
+    return be.extract_arbitrate(Ts, dist_thres, min_points, min_points_all, accepted, verbose);
+}
+template <class B>
+inline bool extract_arbitrate(B&, const std::vector<pose_t>&, float, uint32_t, uint32_t, std::vector<candidate_t>&, bool, std::false_type) {
+    return false;
+}
+/* ... and set mask_ at the points of rows of that extraction? */
+template <class B, class = void>
+struct has_mask_add_extracted : std::false_type {};
+template <class B>
+struct has_mask_add_extracted<B, decltype(void(std::declval<B&>().add_extracted_to_mask(std::declval<const std::vector<uint32_t>&>())))>
+    : std::true_type {};
+template <class B>
+inline void mask_add_extracted(B& be, const std::vector<uint32_t>& rows, std::true_type) { be.add_extracted_to_mask(rows); }
+template <class B>
+inline void mask_add_extracted(B&, const std::vector<uint32_t>&, std::false_type) {}
 
 /* does the backend run the whole ICP loop itself? (hip_backend: tm_icp_refine) */
 template <class B, class = void>
@@ -1043,6 +1073,13 @@ inline std::vector<candidate_t> find_parallel(Backend& be, const std::vector<uin
             batched = detail::device_icp_batch(be, starts, 2.f * p.dist_thres, p.max_icp_iterations, refined,
                                                detail::has_icp_refine_batch<Backend>{});
         }
+        if (batched && !tr) { /* finish_find and the arbitration below where the lists are, when the backend can */
+            TM_TIMED(extract);
+            std::vector<candidate_t> accepted;
+            if (detail::extract_arbitrate(be, refined, 2.f * p.dist_thres, min_points, min_points_all, accepted, p.verbose,
+                                          detail::has_extract_arbitrate<Backend>{}))
+                return accepted;
+        }
         if (batched) {
             TM_TIMED(extract);
             std::vector<candidate_t> got;
@@ -1088,7 +1125,7 @@ struct find_all_workspace {
     /* what the last search set in the two masks: mask_ at `mask_set` (the accepted matches' points), fp_mask_ only at
      * tangent points (first points are drawn from tangent_indices). While `sparse_reset` holds, the next search over
      * the same tangent mask clears those entries instead of 8 MB per million points. */
-    std::vector<uint32_t> mask_set;
+    std::vector<uint32_t> mask_set, added; /* `added`: a round's new indices (swapped with mask_set: neither is ever a fresh allocation) */
     bool sparse_reset = false;
 };
 
@@ -1134,7 +1171,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             detail::mask_clear(be, mask, detail::has_sparse_mask<Backend>{}); /* :41 */
     }
     std::vector<candidate_t> results;
-    std::vector<uint32_t> added;
+    std::vector<uint32_t>& added = ws.added;
     for (;;) {
         if (p.stats) ++p.stats->rounds;
         auto matches = find_parallel(be, tangent_indices, n_scene, mask, fp_mask, tangent_mask, p, ex);
@@ -1161,8 +1198,20 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             added.insert(added.end(), mt.scene_corrs.begin(), mt.scene_corrs.end());
         }
         lap_m("host mask + list");
-        for (auto& mt : matches) results.push_back(std::move(mt));
-        detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
+        /* the backend's copy of mask_: from the lists it still holds when every match came out of its own arbitration,
+         * else the indices go up */
+        std::vector<uint32_t> rows;
+        for (const auto& mt : matches)
+            if (mt.device_row >= 0) rows.push_back((uint32_t)mt.device_row);
+        const bool held = detail::has_mask_add_extracted<Backend>::value && rows.size() == matches.size();
+        for (auto& mt : matches) {
+            mt.device_row = -1; /* the rows belong to this round */
+            results.push_back(std::move(mt));
+        }
+        if (held)
+            detail::mask_add_extracted(be, rows, detail::has_mask_add_extracted<Backend>{});
+        else
+            detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
         lap_m("backend mask_add");
         if (keep) {
             if (ws.mask_set.empty())

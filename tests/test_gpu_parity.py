@@ -1232,6 +1232,73 @@ def test_extract_batch_equals_single_calls(gpu_small, small_case):
     assert hits >= 2
 
 
+def _arbitrate_numpy(lists, n_scene, tmask, min_points, min_points_all):
+    """the greedy accept of find_parallel (reference include/impl/scene.hpp:193-237) in plain numpy: order by list size
+    (descending, stable); a candidate keeps the points no ACCEPTED earlier candidate holds; accepted when enough of them
+    are tangent points and enough in all. Returns (verdict, kept, tangent_kept, needs_trimming)."""
+    order = sorted(range(len(lists)), key=lambda k: -len(lists[k]))
+    used = np.zeros(n_scene, bool)
+    verdict = np.zeros(len(lists), np.int32)
+    kept = np.zeros(len(lists), np.uint32)
+    tan = np.zeros(len(lists), np.uint32)
+    trimmed = False
+    for k in order:
+        idx = lists[k].astype(np.int64)
+        free = idx[~used[idx]]
+        kept[k], tan[k] = len(free), int(np.count_nonzero(tmask[free]))
+        if tan[k] >= min_points and kept[k] >= min_points_all:
+            verdict[k] = 1
+            used[free] = True
+            trimmed = trimmed or len(free) != len(idx)
+    return verdict, kept, tan, trimmed
+
+
+def test_extract_arbitrate_batch_equals_host_arbitration(gpu_small, small_case):
+    """tm_extract_arbitrate_batch: finish_find of several poses + the arbitration of find_parallel where the lists are.
+    Verdicts and both counts per candidate equal the greedy pass in numpy over the lists of the plain batch call — for
+    disjoint instances, for near-duplicates of an instance (rejected: an accepted one holds their points), for thresholds
+    that reject an early candidate whose points a later one then takes — and -1 for all when an accepted candidate would
+    have to be trimmed. tm_scene_mask_add_extracted then masks exactly the accepted rows' points."""
+    gm, gs = gpu_small["model"], gpu_small["scene"]
+    tmask = small_case["scene"]["tangent_mask"].astype(bool)
+    near = random_poses_near_truth(small_case, 6, seed=11)          # several poses per planted instance: overlaps
+    far = random_poses_near_truth(small_case, 3, seed=12, jitter=0.5)  # poor poses: short lists
+    poses = np.concatenate([np.asarray(near).reshape(-1, 16), np.asarray(far).reshape(-1, 16)])
+    plain = gs.extract_correspondences_batch(gm, poses, DT)
+    lists = [p[0] for p in plain]
+    sizes = sorted(len(l) for l in lists)
+    decided_cases = 0
+    for min_points, min_all in ((1, 1), (1, sizes[len(sizes) // 2]), (1, sizes[-1]), (10**9, 1), (1, sizes[-1] + 1),
+                                (max(1, int(np.count_nonzero(tmask)) // 50), sizes[len(sizes) // 3])):
+        want_v, want_k, want_t, trimmed = _arbitrate_numpy(lists, gs.n, tmask, min_points, min_all)
+        v, k, t, counts, got = gs.extract_arbitrate_batch(gm, poses, DT, min_points, min_all)
+        assert np.array_equal(counts, [len(l) for l in lists])
+        if trimmed:
+            assert (v == -1).all(), (min_points, min_all)  # the host has to trim an accepted candidate's lists
+            for g, p in zip(got, plain):
+                assert np.array_equal(g[0], p[0]) and np.array_equal(g[1], p[1])  # every row written, as by the plain call
+            continue
+        decided_cases += 1
+        assert np.array_equal(v, want_v), (min_points, min_all, v, want_v)
+        assert np.array_equal(k, want_k) and np.array_equal(t, want_t)
+        for j in range(len(poses)):
+            if v[j] == 1:
+                assert np.array_equal(got[j][0], plain[j][0]) and np.array_equal(got[j][1], plain[j][1]) and got[j][2] == plain[j][2]
+        # the accepted rows' points, and nothing else, reach mask_
+        acc = np.flatnonzero(v == 1).astype(np.uint32)
+        finite = np.isfinite(small_case["scene"]["surfels"][:, 0:3]).all(axis=1)
+        try:
+            gs.set_mask(None)
+            gs.mask_add_extracted(acc)
+            masked = np.zeros(gs.n, bool)
+            for j in acc:
+                masked[plain[j][0]] = True
+            assert gs.live_count() == int(np.count_nonzero(finite & ~masked))
+        finally:
+            gs.set_mask(None)
+    assert decided_cases >= 3
+
+
 def test_radius_lists_equal_single_queries(gpu_small, oracle_small, small_case):
     gs, os_ = gpu_small["scene"], oracle_small["scene"]
     diam = oracle_small["model"].diameter

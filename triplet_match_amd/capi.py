@@ -106,6 +106,9 @@ SIGNATURES = {
     "tm_scene_destroy": (C.c_int, [vp]),
     "tm_scene_set_mask": (C.c_int, [vp, i32p]),
     "tm_scene_mask_add": (C.c_int, [vp, u32p, C.c_uint32]),
+    "tm_scene_mask_add_extracted": (C.c_int, [vp, u32p, C.c_uint32]),
+    "tm_extract_arbitrate_batch": (C.c_int, [vp, vp, f32p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, u32p, u32p,
+                                             C.c_uint32, u32p, f64p, i32p, u32p, u32p]),
     "tm_scene_size": (C.c_uint32, [vp]),
     "tm_scene_create_projected": (C.c_int, [vp, C.c_int, f32p, C.POINTER(vp)]),
     "tm_scene_probe_projected": (C.c_int, [vp, C.c_int, f32p, C.c_float, u64p, u32p]),
@@ -1040,6 +1043,39 @@ class Scene:
                                                       mc.ctypes.data_as(u32p), stride, counts.ctypes.data_as(u32p),
                                                       scores.ctypes.data_as(f64p)))
         return [(sc[k, :counts[k]].copy(), mc[k, :counts[k]].copy(), float(scores[k])) for k in range(n)]
+
+    def extract_arbitrate_batch(self, model, poses16, dist_thres, min_points, min_points_all):
+        """(verdict, kept, tangent_kept, [(scene_corrs, model_corrs, score)] per pose) — lists of rejected candidates
+        are empty unless the verdict is -1 for all (the host decides)"""
+        P, pP = _f(np.asarray(poses16).reshape(-1, 16))
+        n = P.shape[0]
+        counts = np.zeros(n, np.uint32)
+        scores = np.zeros(n, np.float64)
+        _check(lib().tm_extract_correspondences_batch(self.h, model.h, pP, n, dist_thres, None, None, 0,
+                                                      counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p)))
+        stride = max(int(counts.max()), 1)
+        sc = np.full((n, stride), 0xFFFFFFFF, np.uint32)
+        mc = np.full((n, stride), 0xFFFFFFFF, np.uint32)
+        verdict = np.zeros(n, np.int32)
+        kept = np.zeros(n, np.uint32)
+        tan = np.zeros(n, np.uint32)
+        _check(lib().tm_extract_arbitrate_batch(self.h, model.h, pP, n, dist_thres, int(min_points), int(min_points_all),
+                                                sc.ctypes.data_as(u32p), mc.ctypes.data_as(u32p), stride,
+                                                counts.ctypes.data_as(u32p), scores.ctypes.data_as(f64p),
+                                                verdict.ctypes.data_as(i32p), kept.ctypes.data_as(u32p),
+                                                tan.ctypes.data_as(u32p)))
+        lists = []
+        for k in range(n):
+            if verdict[k] == 0:
+                assert (sc[k] == 0xFFFFFFFF).all()  # a rejected candidate's rows are not written
+                lists.append((np.zeros(0, np.uint32), np.zeros(0, np.uint32), float(scores[k])))
+            else:
+                lists.append((sc[k, :counts[k]].copy(), mc[k, :counts[k]].copy(), float(scores[k])))
+        return verdict, kept, tan, counts, lists
+
+    def mask_add_extracted(self, rows):
+        r = np.ascontiguousarray(rows, np.uint32)
+        _check(lib().tm_scene_mask_add_extracted(self.h, r.ctypes.data_as(u32p), r.size))
 
     def extract_correspondences(self, model, pose16, dist_thres):
         T, pT = _f(pose16)

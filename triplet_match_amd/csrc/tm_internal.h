@@ -396,6 +396,9 @@ struct tm_scene {
     tmx::dbuf<unsigned char> w_active;        /* subset flags in original order (tm_score_hypotheses) */
     std::vector<unsigned char> h_act;         /* host copy of the same, all zero between calls */
     tmx::dbuf<uint32_t> w_corr;            /* compacted (scene, model) correspondences, 2 x n */
+    std::vector<uint32_t> extract_counts;  /* entries per row of w_corr after the last tm_extract_*_batch (tm_scene_mask_add_extracted) */
+    tmx::dbuf<unsigned char> w_owner;      /* k_arb_claim: per scene point the number of the last candidate that claimed it */
+    tmx::dbuf<uint32_t> w_kept_tan;        /* ... and per candidate (kept, tangent points among them) */
     tmx::dbuf<unsigned long long> w_words; /* membership bits of tm_scene_radius_subset */
     std::vector<unsigned long long> h_words;
     void* h_pinned = nullptr; /* pinned staging memory of tm_scene_radius_lists */

@@ -1927,6 +1927,8 @@ int tm_scene_destroy(tm_scene* s) {
     s->w_pairs.release();
     s->w_words.release();
     s->w_corr.release();
+    s->w_owner.release();
+    s->w_kept_tan.release();
     s->w_mask_idx.release();
     s->w_active_sorted.release();
     s->ed_subset.release();
@@ -2323,10 +2325,50 @@ static int extract_batch_on_device(tm_scene* s, tm_model* m, const float* d_pose
  * the counts come back in one read-back, the lists in a second one through pinned memory (the reference calls
  * finish_find once per candidate, :361-364 and at the end of icp_, :401). scene_corrs / model_corrs = n rows of
  * `stride` entries; counts[k] entries of row k are valid. TM_ERR_CAPACITY (counts valid) if stride is too small. */
-int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
-                                     uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride, uint32_t* counts,
-                                     double* scores) {
-    TM_GUARD(s);
+/* The arbitration of find_parallel (include/impl/scene.hpp:193-237) over lists that are still on the device: candidate
+ * `me` (1-based, in arbitration order) claims the scene points of its list that no ACCEPTED earlier candidate holds —
+ * owner[idx] = number of the last candidate that claimed idx; whether that one was accepted follows from its two
+ * counts (kept >= min_points_all and tangent points among them >= min_points), final since its launch has ended — and
+ * counts them. One launch per candidate, in order; nothing is given back by hand (search.hpp arbitrate_marks is the
+ * same rule on the host). */
+__global__ __launch_bounds__(256) void k_arb_claim(const uint32_t* __restrict__ list, uint32_t count, uint32_t me,
+                                                   unsigned char* __restrict__ owner, uint32_t* __restrict__ kept_tan,
+                                                   const int32_t* __restrict__ tmask, uint32_t min_points,
+                                                   uint32_t min_points_all) {
+    __shared__ uint32_t s_k[4], s_t[4];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false, tan = false;
+    if (t < count) {
+        const uint32_t idx = list[t];
+        const uint32_t o = owner[idx];
+        const bool held = o != 0u && kept_tan[2u * o] >= min_points_all && kept_tan[2u * o + 1u] >= min_points;
+        if (!held) {
+            owner[idx] = (unsigned char)me;
+            keep = true;
+            tan = tmask[idx] != 0;
+        }
+    }
+    const uint32_t ck = (uint32_t)__popcll(__ballot(keep)), ct = (uint32_t)__popcll(__ballot(tan));
+    if ((threadIdx.x & 63u) == 0u) s_k[threadIdx.x >> 6] = ck, s_t[threadIdx.x >> 6] = ct;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t k = (s_k[0] + s_k[1]) + (s_k[2] + s_k[3]), tt = (s_t[0] + s_t[1]) + (s_t[2] + s_t[3]);
+        if (k) atomicAdd(&kept_tan[2u * me], k);
+        if (tt) atomicAdd(&kept_tan[2u * me + 1u], tt);
+    }
+}
+
+/* finish_find of several poses; with `arb` also the arbitration of the candidates these poses are (see k_arb_claim):
+ * verdict[k] = 1 accepted / 0 rejected, or -1 for every k when the decision needs the host (an accepted candidate
+ * would have lost points to an earlier one and must be compacted; more than 254 candidates; a projected scene) */
+struct arb_request {
+    uint32_t min_points, min_points_all;
+    int32_t* verdict;
+    uint32_t *kept, *tangent_kept; /* may be null */
+};
+static int extract_batch_impl(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
+                              uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride, uint32_t* counts,
+                              double* scores, const arb_request* arb) {
     TM_FORWARD(check_pair(s, m));
     if (n == 0) return TM_OK;
     TM_REQUIRE(poses16 && counts, TM_ERR_INVALID, "tm_extract_correspondences_batch: null argument");
@@ -2350,28 +2392,113 @@ int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* pose
         total += counts[k];
         mx = std::max(mx, counts[k]);
     }
-    if (!(scene_corrs || model_corrs) || total == 0) return TM_OK;
-    TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
-    const size_t need = total * 8;
-    TM_FORWARD(tmx::scene_pinned_ensure(s, need));
-    uint32_t* stage = (uint32_t*)s->h_pinned;
-    size_t off = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        if (!counts[k]) continue;
-        TM_HIP_CHECK(hipMemcpyAsync(stage + off, s->w_corr.p + 2 * (size_t)s->n * k, (size_t)counts[k] * 4,
-                                    hipMemcpyDeviceToHost, c->stream));
-        TM_HIP_CHECK(hipMemcpyAsync(stage + off + counts[k], s->w_corr.p + 2 * (size_t)s->n * k + s->n, (size_t)counts[k] * 4,
-                                    hipMemcpyDeviceToHost, c->stream));
-        off += 2 * (size_t)counts[k];
+    s->extract_counts.assign(counts, counts + n); /* rows of w_corr a later tm_scene_mask_add_extracted may name */
+    /* the arbitration, queued behind the lists: order = counts descending, stable (:193-195) */
+    std::vector<uint32_t> order, h_kt;
+    bool decide = arb != nullptr && n <= 254u && s->d_tmask.p != nullptr;
+    if (arb) {
+        for (uint32_t k = 0; k < n; ++k) arb->verdict[k] = -1;
     }
-    TM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    off = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        if (scene_corrs) memcpy(scene_corrs + (size_t)k * stride, stage + off, (size_t)counts[k] * 4);
-        if (model_corrs) memcpy(model_corrs + (size_t)k * stride, stage + off + counts[k], (size_t)counts[k] * 4);
-        off += 2 * (size_t)counts[k];
+    if (decide) {
+        order.resize(n);
+        for (uint32_t k = 0; k < n; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return counts[x] > counts[y]; });
+        TM_FORWARD(s->w_owner.ensure(s->n));
+        TM_FORWARD(s->w_kept_tan.ensure(2 * ((size_t)n + 1)));
+        TM_HIP_CHECK(hipMemsetAsync(s->w_owner.p, 0, s->n, c->stream));
+        TM_HIP_CHECK(hipMemsetAsync(s->w_kept_tan.p, 0, 2 * ((size_t)n + 1) * 4, c->stream));
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint32_t k = order[r];
+            if (!counts[k]) continue;
+            hipLaunchKernelGGL(k_arb_claim, dim3((counts[k] + 255) / 256), dim3(256), 0, c->stream,
+                               s->w_corr.p + 2 * (size_t)s->n * k, counts[k], r + 1u, s->w_owner.p, s->w_kept_tan.p,
+                               s->d_tmask.p, arb->min_points, arb->min_points_all);
+        }
+        TM_HIP_CHECK(hipGetLastError());
+        h_kt.resize(2 * ((size_t)n + 1));
+        TM_HIP_CHECK(hipMemcpyAsync(h_kt.data(), s->w_kept_tan.p, h_kt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    const bool lists = (scene_corrs || model_corrs) && total != 0;
+    if (lists) TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
+    uint32_t* stage = nullptr;
+    if (lists) {
+        const size_t need = total * 8;
+        TM_FORWARD(tmx::scene_pinned_ensure(s, need));
+        stage = (uint32_t*)s->h_pinned;
+        size_t off = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!counts[k]) continue;
+            TM_HIP_CHECK(hipMemcpyAsync(stage + off, s->w_corr.p + 2 * (size_t)s->n * k, (size_t)counts[k] * 4,
+                                        hipMemcpyDeviceToHost, c->stream));
+            TM_HIP_CHECK(hipMemcpyAsync(stage + off + counts[k], s->w_corr.p + 2 * (size_t)s->n * k + s->n, (size_t)counts[k] * 4,
+                                        hipMemcpyDeviceToHost, c->stream));
+            off += 2 * (size_t)counts[k];
+        }
+    }
+    if (lists || decide) TM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (decide) {
+        bool compaction = false;
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint32_t k = order[r], kept = h_kt[2 * ((size_t)r + 1)], tan = h_kt[2 * ((size_t)r + 1) + 1];
+            const bool acc = tan >= arb->min_points && kept >= arb->min_points_all;
+            arb->verdict[k] = acc ? 1 : 0;
+            if (arb->kept) arb->kept[k] = kept;
+            if (arb->tangent_kept) arb->tangent_kept[k] = tan;
+            compaction = compaction || (acc && kept != counts[k]);
+        }
+        if (compaction)
+            for (uint32_t k = 0; k < n; ++k) arb->verdict[k] = -1; /* the host's arbitration trims the lists */
+    }
+    if (lists) {
+        size_t off = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const bool wanted = !arb || arb->verdict[k] != 0; /* a rejected candidate's lists are not copied out */
+            if (wanted && scene_corrs) memcpy(scene_corrs + (size_t)k * stride, stage + off, (size_t)counts[k] * 4);
+            if (wanted && model_corrs) memcpy(model_corrs + (size_t)k * stride, stage + off + counts[k], (size_t)counts[k] * 4);
+            off += 2 * (size_t)counts[k];
+        }
     }
     return TM_OK;
+}
+
+int tm_extract_correspondences_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
+                                     uint32_t* scene_corrs, uint32_t* model_corrs, uint32_t stride, uint32_t* counts,
+                                     double* scores) {
+    TM_GUARD(s);
+    return extract_batch_impl(s, m, poses16, n, dist_thres, scene_corrs, model_corrs, stride, counts, scores, nullptr);
+}
+
+int tm_extract_arbitrate_batch(tm_scene* s, tm_model* m, const float* poses16, uint32_t n, float dist_thres,
+                               uint32_t min_points, uint32_t min_points_all, uint32_t* scene_corrs, uint32_t* model_corrs,
+                               uint32_t stride, uint32_t* counts, double* scores, int32_t* verdict, uint32_t* kept,
+                               uint32_t* tangent_kept) {
+    TM_GUARD(s);
+    TM_REQUIRE(verdict || n == 0, TM_ERR_INVALID, "tm_extract_arbitrate_batch: null argument");
+    arb_request arb{min_points, min_points_all, verdict, kept, tangent_kept};
+    return extract_batch_impl(s, m, poses16, n, dist_thres, scene_corrs, model_corrs, stride, counts, scores, &arb);
+}
+
+/* mask_ |= the scene points of rows `rows` of the last tm_extract_*_batch call on this scene (their lists are still on
+ * the device): what find_all does with the accepted matches (:87-90), without the lists travelling back up */
+int tm_scene_mask_add_extracted(tm_scene* s, const uint32_t* rows, uint32_t n_rows) {
+    TM_GUARD(s);
+    TM_REQUIRE(s && (rows || n_rows == 0), TM_ERR_INVALID, "tm_scene_mask_add_extracted: null argument");
+    if (n_rows == 0) return TM_OK;
+    tm_ctx* c = s->ctx;
+    TM_HIP_CHECK(hipSetDevice(c->device));
+    for (uint32_t r = 0; r < n_rows; ++r)
+        TM_REQUIRE(rows[r] < s->extract_counts.size(), TM_ERR_INVALID, "tm_scene_mask_add_extracted: no such row in the last extraction");
+    s->h_mask_stale = true;
+    bool any = false;
+    for (uint32_t r = 0; r < n_rows; ++r) {
+        const uint32_t cnt = s->extract_counts[rows[r]];
+        if (!cnt) continue;
+        hipLaunchKernelGGL(k_mask_set, dim3((cnt + 255) / 256), dim3(256), 0, c->stream,
+                           s->w_corr.p + 2 * (size_t)s->n * rows[r], cnt, s->d_mask.p);
+        any = true;
+    }
+    TM_HIP_CHECK(hipGetLastError());
+    return any ? scene_build(s, false) : TM_OK;
 }
 
 int tm_extract_correspondences(tm_scene* s, tm_model* m, const float pose16[16], float dist_thres,
