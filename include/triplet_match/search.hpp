@@ -1127,6 +1127,7 @@ struct find_all_workspace {
      * the same tangent mask clears those entries instead of 8 MB per million points. */
     std::vector<uint32_t> mask_set, added; /* `added`: a round's new indices (swapped with mask_set: neither is ever a fresh allocation) */
     bool sparse_reset = false;
+    bool mask_tracked = true; /* false: a round's indices were not listed (the backend took them from its own rows): mask_ is cleared whole */
 };
 
 /* find_all_parallel, include/impl/scene.hpp:39-98. Returned transforms map scene -> model; the caller
@@ -1146,12 +1147,16 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     std::vector<int32_t>&mask = ws.mask, &fp_mask = ws.fp_mask;
     std::vector<uint32_t>& tangent_indices = ws.tangent_indices;
     if (keep && ws.sparse_reset && ws.tangent_indices_valid && mask.size() == n && fp_mask.size() == n) {
-        for (uint32_t idx : ws.mask_set) mask[idx] = 0;
+        if (ws.mask_tracked)
+            for (uint32_t idx : ws.mask_set) mask[idx] = 0;
+        else
+            mask.assign(n, 0);
         for (uint32_t idx : tangent_indices) fp_mask[idx] = 0;
     } else {
         mask.assign(n, 0);
         fp_mask.assign(n, 0);
     }
+    ws.mask_tracked = true;
     ws.sparse_reset = false; /* until this search has ended in the ordinary way */
     ws.mask_set.clear();
     if (initial_mask) mask = *initial_mask;
@@ -1178,14 +1183,13 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
         if (matches.empty()) break;
         TM_TIMED(mask);
         /* :88-90 for every accepted match (on this thread: the matches' indices interleave in the cloud's order, and
-         * threads writing into the same cache lines cost more than they share); `added` = the lists one after another,
-         * what the backend's mask takes */
-        {
-            size_t total = 0;
-            for (const auto& mt : matches) total += mt.scene_corrs.size();
-            added.clear();
-            added.reserve(total);
-        }
+         * threads writing into the same cache lines cost more than they share). The backend's copy of mask_: from the lists it still holds when every match came out of its own arbitration
+         * (nothing goes up, and the indices are not even listed: the next search clears mask_ whole), else the indices
+         * go up */
+        std::vector<uint32_t> rows;
+        for (const auto& mt : matches)
+            if (mt.device_row >= 0) rows.push_back((uint32_t)mt.device_row);
+        const bool held = detail::has_mask_add_extracted<Backend>::value && rows.size() == matches.size();
         auto t_m = std::chrono::steady_clock::now();
         auto lap_m = [&](const char* what) {
             if (!p.verbose) return;
@@ -1193,17 +1197,21 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             fprintf(stderr, "[mask] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_m).count());
             t_m = now;
         };
-        for (const auto& mt : matches) {
-            for (uint32_t idx : mt.scene_corrs) mask[idx] = 1;
-            added.insert(added.end(), mt.scene_corrs.begin(), mt.scene_corrs.end());
+        added.clear();
+        if (held) {
+            if (keep) ws.mask_tracked = false;
+            for (const auto& mt : matches)
+                for (uint32_t idx : mt.scene_corrs) mask[idx] = 1;
+        } else {
+            size_t total = 0;
+            for (const auto& mt : matches) total += mt.scene_corrs.size();
+            added.reserve(total);
+            for (const auto& mt : matches) {
+                for (uint32_t idx : mt.scene_corrs) mask[idx] = 1;
+                added.insert(added.end(), mt.scene_corrs.begin(), mt.scene_corrs.end());
+            }
         }
-        lap_m("host mask + list");
-        /* the backend's copy of mask_: from the lists it still holds when every match came out of its own arbitration,
-         * else the indices go up */
-        std::vector<uint32_t> rows;
-        for (const auto& mt : matches)
-            if (mt.device_row >= 0) rows.push_back((uint32_t)mt.device_row);
-        const bool held = detail::has_mask_add_extracted<Backend>::value && rows.size() == matches.size();
+        lap_m("host mask");
         for (auto& mt : matches) {
             mt.device_row = -1; /* the rows belong to this round */
             results.push_back(std::move(mt));
@@ -1212,7 +1220,7 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
             detail::mask_add_extracted(be, rows, detail::has_mask_add_extracted<Backend>{});
         else
             detail::mask_add(be, mask, added, detail::has_sparse_mask<Backend>{});
-        lap_m("backend mask_add");
+        lap_m("backend mask");
         if (keep) {
             if (ws.mask_set.empty())
                 ws.mask_set.swap(added);
