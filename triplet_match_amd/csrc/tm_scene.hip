@@ -807,6 +807,10 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
             f3 q[NC];
             uint32_t pidx[NC], gk[NC], lin[NC], mi[NC], brick[NC], code[NC];
             bool near[NC], in[NC];
+            /* the half of a turn that ends in gathers runs at a raised priority, the arithmetic that follows them at the
+             * normal one: a wave that can put loads in flight goes before one that is adding up terms (-1 %, same-run,
+             * gpurun_out/r05_prio*; 1 / 2 / 3 alike, the reverse assignment nothing) */
+            __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
                 const uint32_t e = i + 4u * k + (lane >> 4);
@@ -887,6 +891,7 @@ __global__ __launch_bounds__(256, kItemWaves) void k_score_items(score_args a, c
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             bool ok[NC];
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
