@@ -739,9 +739,9 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tools", "e2e_demo.cpp"), "-o", exe, "-L" + libdir, "-ltm_hip",
                                "-Wl,-rpath," + libdir, "-pthread"])
-        # early drop on, 10 ICP iterations, the search repeated once on the kept scene, two frames with a new cloud, then
+        # early drop on, 10 ICP iterations, the search repeated twelve times on the kept scene, two frames with a new cloud, then
         # a stream of new clouds on 1..4 host threads with a context each
-        r = subprocess.run([exe, fx, "1", "10", "1", "0", "2", "6"], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, fx, "1", "10", "12", "0", "2", "6"], capture_output=True, text=True, timeout=300)
         os.unlink(fx)
         os.unlink(exe)
         import re
@@ -752,6 +752,8 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                 "model_init_s": float(m1.group(1)), "find_all_parallel_s": float(m1.group(2)),
                 "matches": int(m1.group(3)), "planted": int(len(scene["poses_scene_to_model"])),
                 "second_call_s": float(m2.group(1)) if m2 else None,
+                "steady_call_s": (lambda v: sorted(v)[len(v) // 2] if v else None)(
+                    [float(x) for x in re.findall(r"further call ([0-9.]+) s", r.stdout)]),
                 "new_cloud_frame_s": (lambda v: min(v) if v else None)(
                     [float(x) for x in re.findall(r"new cloud \d+: ([0-9.]+) s", r.stdout)]),
                 "stream_frames_per_s": {int(t): float(f) for t, f in
@@ -760,7 +762,9 @@ def run_extras(args, model, res, scene, gm, gs, ctx, pairs, d_poses, d_prov, n_h
                 "note": "drop-in scene<Point>::find_all_parallel, early drop on, 10 ICP iterations, curvature masks on; "
                         "model_init_s is the process's first use of the library: it includes the HIP start-up behind the first "
                         "context (~0.1 s; a further model<Point>::init is extras.preprocessing's 14 ms); "
-                        "second call = the same search again with the prepared scene kept on the device; new_cloud_frame_s = "
+                        "second call = the same search again with the prepared scene kept on the device (the first call that takes "
+                        "the kept-scene route: its one-time allocations are in it); steady_call_s = median of eleven further calls; "
+                        "new_cloud_frame_s = "
                         "new cloud + new scene object + search (upload, curve order, tangent_mask_ on the device); "
                         "stream_frames_per_s = such frames worked off by 1..6 host threads with a context (stream) each"}
         else:
