@@ -2398,12 +2398,15 @@ static int extract_batch_impl(tm_scene* s, tm_model* m, const float* poses16, ui
         mx = std::max(mx, counts[k]);
     }
     s->extract_counts.assign(counts, counts + n); /* rows of w_corr a later tm_scene_mask_add_extracted may name */
-    /* the arbitration, queued behind the lists: order = counts descending, stable (:193-195) */
-    std::vector<uint32_t> order, h_kt;
-    bool decide = arb != nullptr && n <= 254u && s->d_tmask.p != nullptr;
+    const bool lists = (scene_corrs || model_corrs) && total != 0;
     if (arb) {
         for (uint32_t k = 0; k < n; ++k) arb->verdict[k] = -1;
     }
+    /* before anything else is queued: the caller comes back with room for the longest list */
+    if (lists) TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
+    /* the arbitration, queued behind the lists: order = counts descending, stable (:193-195) */
+    std::vector<uint32_t> order, h_kt;
+    const bool decide = arb != nullptr && n <= 254u && s->d_tmask.p != nullptr;
     if (decide) {
         order.resize(n);
         for (uint32_t k = 0; k < n; ++k) order[k] = k;
@@ -2423,8 +2426,6 @@ static int extract_batch_impl(tm_scene* s, tm_model* m, const float* poses16, ui
         h_kt.resize(2 * ((size_t)n + 1));
         TM_HIP_CHECK(hipMemcpyAsync(h_kt.data(), s->w_kept_tan.p, h_kt.size() * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    const bool lists = (scene_corrs || model_corrs) && total != 0;
-    if (lists) TM_REQUIRE(stride >= mx, TM_ERR_CAPACITY, "tm_extract_correspondences_batch: stride smaller than a list");
     uint32_t* stage = nullptr;
     if (lists) {
         const size_t need = total * 8;
