@@ -937,6 +937,12 @@ protected:
             detail::check(rc, "tm_scene_auto_tangent_mask");
             cand.resize(n_cand);
             rows.resize(5 * (size_t)n_cand);
+            /* the tangent points are among the candidates of the |tangent| test (ascending): the search's list of them
+             * comes from those few per cent of the cloud instead of a pass over the whole mask */
+            keep_ws_.tangent_indices.clear();
+            for (uint32_t i : cand)
+                if (tangent_mask[i]) keep_ws_.tangent_indices.push_back(i);
+            keep_ws_.tangent_indices_valid = keep_ws_.tangent_indices.size() == n_tan;
             if (curvature_k_) cloud_->store_curvature(curvature_k_, std::move(cand), std::move(rows), hash);
             lap("tangent_mask_ on the device");
         } else {

@@ -350,6 +350,7 @@ int tm_ctx_destroy(tm_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->pinned_spare) (void)hipHostFree(c->pinned_spare);
     for (hipEvent_t e : c->ev_ring) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -171,6 +171,10 @@ struct tm_ctx {
     tmx::options opt;        /* switches, see tmx::options */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_copy = nullptr; /* behind an upload from a pinned staging buffer whose kernels the call does not wait for */
+    /* one pinned staging buffer kept for the next scene (scene_pinned_ensure / scene_pinned_give): a scene per frame of a
+     * stream otherwise pins and unpins a few megabytes two or three times per frame, a millisecond each */
+    void* pinned_spare = nullptr;
+    size_t pinned_spare_bytes = 0;
     std::vector<hipEvent_t> ev_ring;      /* 2 * kTimedRing, created on first use */
     uint64_t n_timed = 0;                 /* timed launches since tm_ctx_enable_timing(ctx, 1) */
     uint64_t timed_hyp[tmx::kTimedRing];  /* per ring row: hypotheses of the launch */
@@ -477,13 +481,33 @@ int curve_order(tm_ctx* c, const float* d_cloud, uint32_t n, bool hilbert, void*
 /* ascending indices of the points with tangent_mask set (s->d_tangent_idx, s->n_tangent), built once per scene */
 int scene_tangent_index(tm_scene* s);
 /* the scene's pinned staging buffer (s->h_pinned) with room for at least `need` bytes; grown with a quarter of head
- * room and never below 1 MiB, so the small read-backs of a search do not reallocate it */
+ * room and never below 4 MiB, so the read-backs of a search do not reallocate it; taken from the context's spare when that fits */
+/* a scene's staging buffer goes back to its context (the larger of the two stays, the other is unpinned); callers hold
+ * the context's mutex (TM_GUARD) */
+inline void scene_pinned_give(tm_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    if (c && bytes > c->pinned_spare_bytes) {
+        if (c->pinned_spare) (void)hipHostFree(c->pinned_spare);
+        c->pinned_spare = p;
+        c->pinned_spare_bytes = bytes;
+        return;
+    }
+    (void)hipHostFree(p);
+}
 inline int scene_pinned_ensure(tm_scene* s, size_t need) {
     if (s->h_pinned_bytes >= need && s->h_pinned) return TM_OK;
-    if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    tm_ctx* c = s->ctx;
+    scene_pinned_give(c, s->h_pinned, s->h_pinned_bytes);
     s->h_pinned = nullptr;
     s->h_pinned_bytes = 0;
-    const size_t bytes = std::max(need + need / 4, (size_t)1 << 20);
+    if (c->pinned_spare && c->pinned_spare_bytes >= need) { /* what the last scene of this context left */
+        s->h_pinned = c->pinned_spare;
+        s->h_pinned_bytes = c->pinned_spare_bytes;
+        c->pinned_spare = nullptr;
+        c->pinned_spare_bytes = 0;
+        return TM_OK;
+    }
+    const size_t bytes = std::max(need + need / 4, (size_t)4 << 20);
     TM_HIP_CHECK(hipHostMalloc(&s->h_pinned, bytes, hipHostMallocDefault));
     s->h_pinned_bytes = bytes;
     return TM_OK;

@@ -1886,7 +1886,8 @@ int tm_scene_destroy(tm_scene* s) {
     TM_GUARD(s);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    tmx::scene_pinned_give(s->ctx, s->h_pinned, s->h_pinned_bytes);
+    s->h_pinned = nullptr;
     s->d_cloud.release();
     s->d_tmask.release();
     s->d_tangent_idx.release();
