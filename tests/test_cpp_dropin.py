@@ -75,6 +75,14 @@ def test_worker_pool():
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
 
 
+def test_content_hash_background_form():
+    """the cloud's content hash as a background job of the pool (what a search on a kept scene runs under itself)
+    equals the blocking call; any changed bit changes it"""
+    exe = _compile("test_content_hash")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
 def test_cylinder_init_from_model_fits_the_cylinder(tmp_path):
     """cylinder_traits::init_from_model = PCL's MSAC cylinder fit restated (reference include/impl/cylinder_traits.hpp:
     5-50; PCL itself is not in the reference tree): on a noisy cylinder with 15 % outliers and wrong normals among the
