@@ -1170,10 +1170,14 @@ inline std::vector<candidate_t> find_all(Backend& be, const std::vector<int32_t>
     TM_TIMED(total);
     {
         TM_TIMED(mask);
+        const auto t_c = std::chrono::steady_clock::now();
         if (initial_mask)
             be.set_mask(mask);
         else
             detail::mask_clear(be, mask, detail::has_sparse_mask<Backend>{}); /* :41 */
+        if (p.verbose)
+            fprintf(stderr, "[mask] backend mask cleared %.3f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c).count());
     }
     std::vector<candidate_t> results;
     std::vector<uint32_t>& added = ws.added;
