@@ -209,6 +209,7 @@ static const opt_entry kOptions[] = {
     {"ed_bruteforce", &options::ed_bruteforce, 0, 1},
     {"ed_unfused", &options::ed_unfused, 0, 1},
     {"search_segment", &options::search_segment, -1, 1 << 24},
+    {"ed_bound_first", &options::ed_bound_first, 0, 1},
     {"search_per_range", &options::search_per_range, 0, 1},
     {"search_step_check", &options::search_step_check, 0, 1},
     {"ed_wave_rows", &options::ed_wave_rows, 0, 1 << 19},

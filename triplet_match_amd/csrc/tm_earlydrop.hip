@@ -152,6 +152,10 @@ struct ed_args {
     const uint32_t* rng_starts;
     const uint32_t* rng_stop;
     uint32_t seg_len, seg_step;
+    /* k_ed_prefix_group in a search (only the FIRST SUFFICIENT hypothesis of a batch is reported, and with sufficient >=
+     * the rule's threshold that is never a dropped one): 1 = a hypothesis whose count of NEAR points (brick code: an upper bound of its correspondences) already
+     * fails the first checkpoint is dropped without its voxel / model gathers */
+    uint32_t bound_first = 0;
     /* The continuation in waves (k_pending_sort): the pending rows are in visit order, row_info[row] = position of
      * the row among its batch's pending rows | batch << 20; a launch takes the rows with ord_lo <= position < ord_hi
      * whose batch has no sufficient hypothesis yet. Only the FIRST sufficient hypothesis of a batch counts
@@ -1307,6 +1311,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
     __shared__ float s_pose[kEdPG * 16];
     __shared__ uint32_t s_q[kEdPQ];
     __shared__ uint32_t s_qn;
+    __shared__ uint32_t s_near[kEdPG], s_tpos[kEdPG], s_done[kEdPG]; /* bound_first: near points before x0, test position, settled */
     if (ed_stopped(a)) return;
     uint32_t h_first, h_end;
     if (a.rng_starts) { /* merged step: batch blockIdx.y, the step's segment of it */
@@ -1327,6 +1332,9 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
         s_over[threadIdx.x] = 0u;
         s_fx[threadIdx.x] = 0ull;
         s_min[threadIdx.x] = ~0ull;
+        s_near[threadIdx.x] = 0u;
+        s_tpos[threadIdx.x] = 0xFFFFFFFFu;
+        s_done[threadIdx.x] = 0u;
         s_slot[threadIdx.x] = threadIdx.x < n_g ? a.ball.slot_of_hyp[a.h0 + h_first + threadIdx.x] : 0xFFFFFFFFu;
     }
     if (threadIdx.x < n_g * 16u) s_pose[threadIdx.x] = a.sc.poses[(size_t)(a.h0 + h_first) * 16 + threadIdx.x];
@@ -1391,6 +1399,68 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
             if (threadIdx.x == 0) s_qn = 0u;
             __syncthreads();
         };
+        if (a.bound_first) {
+            /* The bound pass: transform + in-grid test + brick code only (the code array stays in L2; no voxel, model
+             * or record line is touched). Per hypothesis: U = its NEAR points before x0 — every correspondence is a near
+             * point — and the test position, the first in-grid position at or after x0 (what the exact pass finds too).
+             * early_drop_upper is non-decreasing in the count, so upper(pos + 1, S, U + 1) below the threshold means
+             * the exact count drops it at this checkpoint as well: settled, and with nothing of a dropped hypothesis
+             * reported in a search, its exact count is never needed. The others take the exact pass below. */
+            for (uint32_t e0 = 0; e0 < n_e; e0 += 256u * kEdPK) {
+                float4 P[kEdPK];
+                uint32_t pos[kEdPK];
+#pragma unroll
+                for (uint32_t k = 0; k < kEdPK; ++k) {
+                    const uint32_t e = e0 + k * 256u + threadIdx.x;
+                    pos[k] = 0xFFFFFFFFu;
+                    P[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < n_e) {
+                        P[k] = pp[e];
+                        const uint32_t q = pl[e].y;
+                        if (q < n_pos) pos[k] = q;
+                    }
+                }
+                for (uint32_t g = g0; g < g1; ++g) {
+                    const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + h_first + g) * 16);
+                    uint32_t near_w = 0u, tp = 0xFFFFFFFFu;
+#pragma unroll
+                    for (uint32_t k = 0; k < kEdPK; ++k) {
+                        f3 q;
+                        uint32_t brick, lin;
+                        const bool in = ev_grid(a.sc, T, make3(P[k].x, P[k].y, P[k].z), q, brick, lin) && pos[k] != 0xFFFFFFFFu;
+                        bool near = in && !(sbits && !((sbits[brick >> 11] >> ((brick >> 6) & 31u)) & 1u));
+                        if (near && a.sc.bcode) near = (uint32_t)a.sc.bcode[brick] <= a.sc.code_max;
+                        near_w += (uint32_t)__popcll(__ballot(near && pos[k] < x0));
+                        if (in && pos[k] >= x0) tp = min(tp, pos[k]);
+                    }
+                    for (int off = 32; off > 0; off >>= 1) tp = min(tp, (uint32_t)__shfl_xor((int)tp, off));
+                    if (lane == 0u) {
+                        if (near_w) atomicAdd(&s_near[g], near_w);
+                        if (tp != 0xFFFFFFFFu) atomicMin(&s_tpos[g], tp);
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x >= g0 && threadIdx.x < g1 && s_tpos[threadIdx.x] != 0xFFFFFFFFu) {
+                const uint32_t g = threadIdx.x, tp = s_tpos[g];
+                if ((float)early_drop_upper(tp + 1u, S, s_near[g] + 1u) < accept_thresh) {
+                    const uint32_t hyp = a.h0 + h_first + g;
+                    o.counts[hyp] = 0u; /* dropped at the first checkpoint; its count is not known and not asked for */
+                    o.dropped_at[hyp] = 0;
+                    o.saved[hyp] = S - (tp + 1u);
+                    o.limit[hyp] = tp;
+                    a.sc.scores_fx[hyp] = 0ull;
+                    s_done[g] = 1u;
+                }
+            }
+            __syncthreads();
+            bool all_done = true;
+            for (uint32_t g = g0; g < g1; ++g) all_done = all_done && s_done[g] != 0u;
+            if (all_done) {
+                g0 = g1;
+                continue;
+            }
+        }
         for (uint32_t e0 = 0; e0 < n_e; e0 += 256u * kEdPK) {
             float4 P[kEdPK];
             uint32_t pos[kEdPK]; /* 0xFFFFFFFF = no entry */
@@ -1406,6 +1476,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
                 }
             }
             for (uint32_t g = g0; g < g1; ++g) {
+                if (s_done[g]) continue; /* settled by the bound pass (uniform over the workgroup) */
                 const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + h_first + g) * 16);
 #pragma unroll
                 for (uint32_t k = 0; k < kEdPK; ++k) {
@@ -1439,7 +1510,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
         drain();
         g0 = g1;
     }
-    if (threadIdx.x < n_g) {
+    if (threadIdx.x < n_g && !s_done[threadIdx.x]) {
         const uint32_t g = threadIdx.x, hl = h_first + g, hyp = a.h0 + hl;
         const unsigned long long key = s_min[g];
         bool decided = false;
@@ -1645,7 +1716,12 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
         const dim3 ggrid = n_ranges ? dim3((a.seg_len + G - 1u) / G, n_ranges) : dim3((n_hyp + G - 1u) / G);
         const uint32_t sb_words = a.sc.super_near ? (uint32_t)(((size_t)(a.sc.n_super + 255u) / 256u) * 8u) : 0u;
         const uint32_t sb_lds = sb_words * 4u <= 32u * 1024u ? sb_words : 0u;
-        hipLaunchKernelGGL(k_ed_prefix_group, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, a, o, accept_thresh,
+        ed_args ab = a;
+        /* a search step whose `sufficient` is not below the rule's own threshold: a dropped hypothesis has
+         * count <= upper(count) < accept_thresh <= sufficient, so it can never be the first sufficient one and nothing
+         * else of it is reported (ed_args::bound_first). A caller's smaller `sufficient` takes the exact pass. */
+        ab.bound_first = (check != nullptr && c->opt.ed_bound_first && check->sufficient >= accept_thresh) ? 1u : 0u;
+        hipLaunchKernelGGL(k_ed_prefix_group, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, ab, o, accept_thresh,
                            n_ranges ? 0u : n_hyp, G, sb_lds, s->ed_pending.p, d_n);
     } else {
         const dim3 pgrid = n_ranges ? dim3(a.seg_len, n_ranges) : dim3(n_hyp);

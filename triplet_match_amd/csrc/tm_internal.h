@@ -118,6 +118,7 @@ struct options {
     int model_host_build = 0; /* 1: tm_model_create sorts the cloud and builds a median kd-tree on the host (cross-check) */
     int ed_one_kernel = 0, ed_narrow = 0, ed_bruteforce = 0, ed_unfused = 0;
     int search_segment = -1;  /* hypotheses per segment of a search batch; -1 = 2048, 0 = no segments */
+    int ed_bound_first = 1;   /* search steps: drop on the near-point bound before the exact first checkpoint (ed_args::bound_first) */
     int ed_prefix_list = 1;   /* 0: the first step of the early-drop rule walks the neighbourhood list (scan order)
                                  instead of the same positions in the scene's curve order */
     int ed_wave_rows = 8;     /* pending hypotheses per batch the continuation of a search step takes first (in visit
