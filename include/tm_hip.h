@@ -77,7 +77,8 @@ int tm_memcpy_d2h(tm_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
  * score_grouped, ball_ungrouped, score_item_wgs, score_slot_mib, item_sort, near_metric, voxel_bruteforce,
  * voxel_packet, voxel_seed, curv_groups, model_host_build, ed_one_kernel, ed_narrow, ed_bruteforce, ed_unfused,
  * search_segment, search_per_range, search_step_check, ed_wave_rows, ed_prefix_list, ed_hist, ed_ball_list,
- * ed_prefix_group, score_off32, pool_mib (DESIGN.md section 6 says what each selects).
+ * ed_prefix_group, ed_bound_first, score_off32, pool_mib (what each selects: the comment at its field in
+ * csrc/tm_internal.h, struct options).
  * "ablate" (stage ablation: WRONG results, timing only) is refused with TM_ERR_UNSUPPORTED unless the library
  * was built with -DTM_TIMING_EXPERIMENTS; tm_version() of such a build says so. Unknown name / value out of
  * range: TM_ERR_INVALID. */
