@@ -1301,6 +1301,9 @@ constexpr uint32_t kEdPG = 16, kEdPK = TM_ED_PK, kEdPQ = 4096;
 #define TM_ED_NTQ 2
 #endif
 constexpr int kEdNTQ = TM_ED_NTQ; /* queue entries a lane evaluates together */
+/* BOUND: the bound pass of a search step (ed_args::bound_first) — an instantiation of its own: with it the kernel needs 142
+ * registers instead of 116, a wave per SIMD less, and the scoring calls (which never take the pass) lost 14 % */
+template <bool BOUND>
 __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, float accept_thresh, uint32_t n_hyp,
                                                          uint32_t G, uint32_t sb_lds_words,
                                                          uint32_t* __restrict__ pending,
@@ -1399,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
             if (threadIdx.x == 0) s_qn = 0u;
             __syncthreads();
         };
-        if (a.bound_first) {
+        if (BOUND) {
             /* The bound pass: transform + in-grid test + brick code only (the code array stays in L2; no voxel, model
              * or record line is touched). Per hypothesis: U = its NEAR points before x0 — every correspondence is a near
              * point — and the test position, the first in-grid position at or after x0 (what the exact pass finds too).
@@ -1476,7 +1479,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
                 }
             }
             for (uint32_t g = g0; g < g1; ++g) {
-                if (s_done[g]) continue; /* settled by the bound pass (uniform over the workgroup) */
+                if (BOUND && s_done[g]) continue; /* settled by the bound pass (uniform over the workgroup) */
                 const pose12 T = load_pose(a.sc.poses + (size_t)(a.h0 + h_first + g) * 16);
 #pragma unroll
                 for (uint32_t k = 0; k < kEdPK; ++k) {
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(256) void k_ed_prefix_group(ed_args a, ed_out o, fl
         drain();
         g0 = g1;
     }
-    if (threadIdx.x < n_g && !s_done[threadIdx.x]) {
+    if (threadIdx.x < n_g && !(BOUND && s_done[threadIdx.x])) {
         const uint32_t g = threadIdx.x, hl = h_first + g, hyp = a.h0 + hl;
         const unsigned long long key = s_min[g];
         bool decided = false;
@@ -1721,8 +1724,12 @@ static hipError_t launch_ed_fused(tm_scene* s, tm_ctx* c, uint32_t n_hyp, size_t
          * count <= upper(count) < accept_thresh <= sufficient, so it can never be the first sufficient one and nothing
          * else of it is reported (ed_args::bound_first). A caller's smaller `sufficient` takes the exact pass. */
         ab.bound_first = (check != nullptr && c->opt.ed_bound_first && check->sufficient >= accept_thresh) ? 1u : 0u;
-        hipLaunchKernelGGL(k_ed_prefix_group, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, ab, o, accept_thresh,
-                           n_ranges ? 0u : n_hyp, G, sb_lds, s->ed_pending.p, d_n);
+        if (ab.bound_first)
+            hipLaunchKernelGGL(k_ed_prefix_group<true>, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, ab, o, accept_thresh,
+                               n_ranges ? 0u : n_hyp, G, sb_lds, s->ed_pending.p, d_n);
+        else
+            hipLaunchKernelGGL(k_ed_prefix_group<false>, ggrid, dim3(256), (size_t)sb_lds * 4u, c->stream, ab, o, accept_thresh,
+                               n_ranges ? 0u : n_hyp, G, sb_lds, s->ed_pending.p, d_n);
     } else {
         const dim3 pgrid = n_ranges ? dim3(a.seg_len, n_ranges) : dim3(n_hyp);
         hipLaunchKernelGGL(k_ed_fused<true>, pgrid, dim3(256), 2 * (size_t)a.prefix_words * 8, c->stream, a, cu, o,
